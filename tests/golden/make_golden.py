@@ -1,0 +1,329 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ FROM THE REFERENCE ITSELF.
+
+Run only in the build container, where the reference is mounted read-only:
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz|json|tsv
+
+It imports ``ribotricer.statistics.phasescore`` and (with ``pysam``/``quicksect``
+stubbed in ``sys.modules`` because they are module-level imports of packages that
+are not installed here) ``ribotricer.detect_orfs.export_orf_coverages`` from
+/root/reference and records their outputs on seeded inputs.  Only inputs and
+expected outputs are written; no reference source is copied.  The GPU box has no
+/root/reference, so tests read these files and never this import path.
+
+Fixture sets:
+  g1_known_answers.json  quirk / state-machine vectors (Appendix A.5)
+  g2_poisson.npz         ~4900 Poisson ORFs, lambda 0.003..5, L 3..600
+  g3_adversarial.npz     6000 short vectors over {0,1,2}, L 0..24 (ties, resets)
+  g4_long.npz            long ORFs up to 99 999 nt
+  g5_float.json          float (metagene-like) profiles
+  g6_*                   end-to-end: index + alignments + the reference's TSVs
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import platform
+import sys
+import tempfile
+import types
+from collections import Counter, defaultdict
+
+import numpy as np
+import scipy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = os.environ.get("RIBOTRICER_REFERENCE", "/root/reference")
+
+sys.path.insert(0, REFERENCE)
+sys.path.insert(0, REPO)
+
+from ribotricer.statistics import phasescore  # noqa: E402  (the reference)
+
+for _m in ("pysam", "quicksect"):
+    sys.modules.setdefault(_m, types.ModuleType(_m))
+sys.modules["quicksect"].Interval = object
+sys.modules["quicksect"].IntervalTree = dict
+from ribotricer.detect_orfs import export_orf_coverages  # noqa: E402  (the reference)
+
+from oracle.phasescore_literal import combine_frames, phasescore_frames  # noqa: E402
+
+META = {
+    "generator": "tests/golden/make_golden.py",
+    "reference": "smithlabcode/ribotricer v1.5.0 (ribotricer.statistics.phasescore, "
+    "ribotricer.detect_orfs.export_orf_coverages)",
+    "numpy": np.__version__,
+    "scipy": scipy.__version__,
+    "python": platform.python_version(),
+    "machine": platform.processor() or platform.machine(),
+}
+
+
+def run_reference(vectors):
+    """Reference (phase, valid) + per-frame replay through the literal restatement.
+
+    The replay's combined result must equal the reference's bit for bit, which
+    is what licenses storing its per-frame values next to the reference's output.
+    """
+    n = len(vectors)
+    phase = np.empty(n, np.float64)
+    valid = np.empty(n, np.int32)
+    fscore = np.full((n, 3), np.nan, np.float64)
+    fn = np.zeros((n, 3), np.int32)
+    for k, vec in enumerate(vectors):
+        p, v = phasescore(vec)
+        frames = phasescore_frames(vec)
+        p2, v2 = combine_frames(frames)
+        same = (p == p2) or (np.isnan(p) and np.isnan(p2))
+        if not same or v != v2:
+            raise AssertionError(f"literal restatement diverges from reference on vector {k}: {(p, v)} vs {(p2, v2)}")
+        phase[k] = p
+        valid[k] = v
+        for f, (s, nseg) in enumerate(frames):
+            fn[k, f] = nseg
+            if s is not None:
+                fscore[k, f] = s
+    return phase, valid, fscore, fn
+
+
+def pack_csr(vectors):
+    lens = np.array([len(v) for v in vectors], np.int64)
+    offsets = np.zeros(len(vectors) + 1, np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    counts = np.zeros(int(offsets[-1]), np.int32)
+    for v, o in zip(vectors, offsets[:-1]):
+        counts[o : o + len(v)] = v
+    return counts, offsets
+
+
+def save_csr_set(name, vectors, extra=None):
+    phase, valid, fscore, fn = run_reference(vectors)
+    counts, offsets = pack_csr(vectors)
+    payload = dict(
+        counts=counts,
+        offsets=offsets,
+        phase=phase,
+        valid=valid,
+        frame_score=fscore,
+        frame_n=fn,
+        meta=np.array(json.dumps(META)),
+    )
+    if extra:
+        payload.update(extra)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **payload)
+    print(f"{name}: {len(vectors)} vectors, {counts.size} nt, {os.path.getsize(path) / 1e3:.0f} kB")
+
+
+# --------------------------------------------------------------------------- G1
+def g1():
+    vecs = [
+        [],
+        [1, 2],
+        [0] * 9,
+        [1, 0, 0],
+        [0, 0, 0, 5],
+        [1, 0, 0] * 2,
+        [5] + [0] * 299,
+        [0, 0, 0, 5] + [0] * 296,
+        [1, 1, 1] * 5,
+        [1, 1, 1] * 4 + [2, 0, 0],
+        [1, 0, 0, 1, 1, 1],
+        [1, 0, 0, 0, 1, 0, 0, 0, 1],
+        [3, 0, 0] * 30,
+        [0, 3, 0] * 30,
+        [0, 0, 3] * 30,
+        [2, 1, 0] * 10 + [4],
+        [3, 1, 0, 0, 0, 0, 2, 2, 2, 0, 5, 1, 7, 0, 0, 1, 1, 1, 0, 0, 4, 1],
+        [7, 0, 0, 7, 2, 0, 1, 0, 0, 5, 0, 0, 9, 0, 0, 8, 0, 0, 7, 0, 0, 5, 0, 0, 8, 0, 0, 6, 0, 0],
+        [0, 0, 7, 0, 0, 3, 0, 0, 9, 0, 0, 1, 0, 0, 2, 1],
+        [4, 4, 4, 0, 0, 0, 4, 4, 4, 1, 0, 0, 0, 0, 0, 2, 2, 2],
+        [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1],
+        [1000000, 0, 0, 999999, 1, 0, 1000000, 0, 1, 0, 0, 0, 5, 5, 5],
+        [12, 3, 1, 9, 2, 2, 15, 1, 0, 7, 7, 7, 11, 0, 3, 8],
+    ]
+    phase, valid, fscore, fn = run_reference(vecs)
+    rows = []
+    for v, p, va, fs, n in zip(vecs, phase, valid, fscore, fn):
+        rows.append(
+            {
+                "input": v,
+                "phase": float(p),
+                "phase_repr": repr(float(p)),
+                "valid": int(va),
+                "frame_score": [None if np.isnan(x) else float(x) for x in fs],
+                "frame_n": [int(x) for x in n],
+            }
+        )
+    with open(os.path.join(HERE, "g1_known_answers.json"), "w") as fh:
+        json.dump({"meta": META, "vectors": rows}, fh, indent=1)
+    print(f"g1_known_answers.json: {len(rows)} vectors")
+
+
+# --------------------------------------------------------------------------- G2
+def g2():
+    rng = np.random.default_rng(20260213)
+    vecs, lam_of = [], []
+    for lam in (0.003, 0.01, 0.03, 0.1, 0.3, 1.0, 5.0):
+        for k in range(700):
+            if k % 4 == 0:
+                length = int(rng.integers(3, 601))  # any length, incl. L%3 != 0
+            else:
+                length = 3 * int(rng.integers(20, 201))  # prepare-orfs lengths (multiples of 3, >= 60)
+            if k % 2 == 0:
+                w = np.array([2.0, 0.5, 0.5])  # framed
+            else:
+                w = np.array([1.0, 1.0, 1.0])
+            rate = lam * w[np.arange(length) % 3]
+            vecs.append(rng.poisson(rate).astype(np.int64).tolist())
+            lam_of.append(lam)
+    save_csr_set("g2_poisson.npz", vecs, {"lam": np.array(lam_of)})
+
+
+# --------------------------------------------------------------------------- G3
+def g3():
+    rng = np.random.default_rng(7)
+    vecs = []
+    for _ in range(6000):
+        length = int(rng.integers(0, 25))
+        p0 = rng.choice([0.5, 0.7, 0.9])
+        p = [p0, (1 - p0) * 0.6, (1 - p0) * 0.4]
+        vecs.append(rng.choice([0, 1, 2], size=length, p=p).astype(np.int64).tolist())
+    save_csr_set("g3_adversarial.npz", vecs)
+
+
+# --------------------------------------------------------------------------- G4
+def g4():
+    rng = np.random.default_rng(99)
+    spec = [(99999, 1.0)] + [(30000, l) for l in (0.05, 1.0, 50.0)]
+    spec += [(3000, l) for l in (0.05, 0.05, 0.3, 0.3, 1.0, 1.0, 5.0, 5.0, 50.0, 50.0)]
+    spec += [(12288, 0.5), (8193, 0.2), (16384, 2.0), (4097, 0.02)]
+    vecs = []
+    for length, lam in spec:
+        w = np.array([2.0, 0.5, 0.5])
+        vecs.append(rng.poisson(lam * w[np.arange(length) % 3]).astype(np.int64).tolist())
+    save_csr_set("g4_long.npz", vecs)
+
+
+# --------------------------------------------------------------------------- G5
+def g5():
+    rng = np.random.default_rng(5)
+    rows = []
+    vecs = [[0.5, 0.0, 0.25] * 7, [0.0] * 12, [1.5, 1.5, 1.5] * 4, [0.25, 0.0, 0.0, 0.0, 0.0, 0.125]]
+    for _ in range(8):
+        n = 620
+        base = rng.gamma(2.0, 50.0, size=n) * np.array([3.0, 1.0, 1.0])[np.arange(n) % 3]
+        vecs.append(np.round(base, 3).tolist())
+    for v in vecs:
+        p, va = phasescore(v)
+        rows.append({"input": v, "phase": float(p), "valid": int(va)})
+    with open(os.path.join(HERE, "g5_float.json"), "w") as fh:
+        json.dump({"meta": META, "vectors": rows}, fh)
+    print(f"g5_float.json: {len(rows)} vectors")
+
+
+# --------------------------------------------------------------------------- G6
+ORF_TYPES = ["annotated", "super_uORF", "super_dORF", "uORF", "dORF", "overlap_uORF", "overlap_dORF", "novel"]
+
+
+def g6():
+    rng = np.random.default_rng(606)
+    chroms = ["chrI", "chrII", "chrM"]
+    lines = []
+    align = defaultdict(Counter)
+    n_orfs = 220
+    for k in range(n_orfs):
+        # annotated rows come first in a real index (prepare_orfs.py:322-329)
+        otype = "annotated" if k < 60 else ORF_TYPES[1 + (k % 7)]
+        chrom = chroms[k % 3]
+        strand = "+" if (k // 3) % 2 == 0 else "-"
+        n_exons = int(rng.integers(1, 5))
+        total = 3 * int(rng.integers(20, 120))
+        if otype == "annotated" and k % 9 == 0:
+            total += int(rng.integers(1, 3))  # incomplete CDS, L % 3 != 0
+        if k == 7:
+            total = 2  # shorter than one codon
+        cuts = np.sort(rng.choice(np.arange(1, total), size=min(n_exons - 1, total - 1), replace=False)) if total > 1 else []
+        sizes = np.diff(np.concatenate([[0], cuts, [total]])).astype(int)
+        pos = int(rng.integers(100, 200000))
+        exons = []
+        for s in sizes:
+            exons.append((pos, pos + s - 1))
+            pos += s + int(rng.integers(20, 400))
+        # reads: a third of the ORFs stay empty; others framed or flat at several depths
+        mode = k % 3
+        if mode != 0:
+            lam = [0.02, 0.1, 0.5, 3.0][k % 4]
+            w = np.array([2.2, 0.4, 0.4]) if mode == 1 else np.array([1.0, 1.0, 1.0])
+            tpos = [p for a, b in exons for p in range(a, b + 1)]
+            if strand == "-":
+                tpos = tpos[::-1]
+            vals = rng.poisson(lam * w[np.arange(len(tpos)) % 3])
+            for p, v in zip(tpos, vals):
+                if v > 0:
+                    align[strand][(chrom, p)] += int(v)
+        coord = ",".join(f"{a}-{b}" for a, b in (exons if k % 5 else exons[::-1]))  # unsorted on purpose sometimes
+        start_codon = ["ATG", "CTG", "GTG", "TTG", "AT"][k % 5]
+        tid = f"tx{k:04d}"
+        lines.append(
+            "\t".join(
+                [
+                    f"{tid}_{exons[0][0]}_{exons[-1][1]}_{total}",
+                    otype,
+                    tid,
+                    "protein_coding" if k % 4 else "lncRNA",
+                    f"gene{k // 2:04d}",
+                    f"GN{k // 2}",
+                    "protein_coding",
+                    chrom,
+                    strand,
+                    start_codon,
+                    coord,
+                ]
+            )
+        )
+    header = "\t".join(
+        ["ORF_ID", "ORF_type", "transcript_id", "transcript_type", "gene_id", "gene_name", "gene_type", "chrom", "strand", "start_codon", "coordinate"]
+    )
+    index_path = os.path.join(HERE, "g6_index.tsv")
+    with open(index_path, "w") as fh:
+        fh.write(header + "\n")
+        fh.write("\n".join(lines) + "\n")
+    with open(os.path.join(HERE, "g6_alignments.tsv"), "w") as fh:
+        fh.write("strand\tchrom\tpos\tcount\n")
+        for strand in sorted(align):
+            for (chrom, p), c in sorted(align[strand].items()):
+                fh.write(f"{strand}\t{chrom}\t{p}\t{c}\n")
+    param_sets = {
+        "default": dict(),
+        "report_all": dict(report_all=True),
+        "strict": dict(
+            report_all=True,
+            phase_score_cutoff=0.3,
+            min_valid_codons=8,
+            min_reads_per_codon=1,
+            min_valid_codons_ratio=0.75,
+            min_density_over_orf=1.0,
+        ),
+    }
+    with open(os.path.join(HERE, "g6_params.json"), "w") as fh:
+        json.dump({"meta": META, "param_sets": param_sets}, fh, indent=1)
+    for name, kw in param_sets.items():
+        with tempfile.TemporaryDirectory() as tmp:
+            prefix = os.path.join(tmp, "out")
+            # reference signature: detect_orfs.py:206-216
+            export_orf_coverages(index_path, align, prefix, **kw)
+            with open(prefix + "_translating_ORFs.tsv") as src:
+                text = src.read()
+        with open(os.path.join(HERE, f"g6_expected_{name}.tsv"), "w") as dst:
+            dst.write(text)
+        print(f"g6_expected_{name}.tsv: {text.count(chr(10)) - 1} rows")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    for name in which:
+        globals()[name]()
