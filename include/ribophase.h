@@ -1,0 +1,177 @@
+/*
+ * ribophase.h -- C ABI of libribophase.so, the MI355X (gfx950) phase-score engine
+ * that sits behind ribotricer's `detect-orfs` hot loop.
+ *
+ * The reference (smithlabcode/ribotricer v1.5.0) is pure Python and has no FFI
+ * seam; the entry points below are what a binding for this path would bind.
+ * Each one names the reference interface it replaces (paths relative to the
+ * reference repository root).  INTEGRATION.md shows the ctypes stub a ribotricer
+ * maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++ / torch types, no exceptions.
+ *   - every function returns 0 (RP_OK) or a negative rp_status; rp_last_error()
+ *     returns a thread-local message for the last failure on the calling thread.
+ *   - pointers prefixed d_ are DEVICE pointers owned by the caller; the library
+ *     never allocates or frees device memory.  Inputs are read-only, outputs are
+ *     fully overwritten.  Work is enqueued on the caller's HIP stream and is
+ *     asynchronous with respect to the host unless stated otherwise.
+ *   - ORF P-site profiles are CSR-packed: counts[offsets[i] .. offsets[i+1]) is
+ *     the 5'->3' profile of ORF i (the list `cov` of detect_orfs.py:277);
+ *     offsets has n_orfs+1 monotone entries with offsets[0] == 0.
+ *   - counts must satisfy 0 <= counts[k] <= RP_MAX_COUNT.
+ *   - there is no CPU fallback: without a usable HIP device every compute entry
+ *     point fails with RP_ERR_DEVICE / RP_ERR_HIP.
+ */
+#ifndef RIBOPHASE_H
+#define RIBOPHASE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RP_VERSION_STRING "0.1.0"
+
+/* largest admissible P-site count per nucleotide (codon sums stay inside int32) */
+#define RP_MAX_COUNT 536870911 /* 2^29 - 1 */
+
+/* value of min_codon_cov for an ORF with an empty profile (min over no codons;
+ * numpy.all([]) is True in detect_orfs.py:288,293) */
+#define RP_MIN_CODON_COV_EMPTY 2147483647
+
+typedef enum rp_status {
+    RP_OK = 0,
+    RP_ERR_NULL = -1,      /* required pointer is NULL */
+    RP_ERR_SIZE = -2,      /* negative / inconsistent size */
+    RP_ERR_OFFSETS = -3,   /* offsets[0] != 0, not monotone, or offsets[n] != total_nt */
+    RP_ERR_HIP = -4,       /* HIP runtime error (see rp_last_error) */
+    RP_ERR_WORKSPACE = -5, /* workspace missing, misaligned or too small */
+    RP_ERR_DEVICE = -6,    /* no such device / no HIP device available */
+    RP_ERR_COUNTS = -7,    /* a count is negative or exceeds RP_MAX_COUNT */
+    RP_ERR_ARG = -8        /* invalid enum / option value */
+} rp_status;
+
+/* bits of the per-ORF flags byte */
+#define RP_FLAG_TIE 0x01u      /* two candidate frames score within RP_TIE_RTOL with different N
+                                  (the reference's pick is decided by scipy rounding noise,
+                                  SURVEY.md Appendix A.4); valid_codons follows the exact-
+                                  arithmetic rule: the earlier frame wins */
+#define RP_FLAG_RECHECK64 0x02u /* frame decision was re-derived in float64 on device */
+#define RP_FLAG_SPLIT 0x04u    /* profile spanned more than one tile (partials + finalize) */
+
+#define RP_TIE_RTOL 1e-9
+
+/* kernel family selector */
+typedef enum rp_algo {
+    RP_ALGO_AUTO = 0,
+    RP_ALGO_WAVE = 1, /* one wavefront per ORF, streaming straight from HBM */
+    RP_ALGO_TILE = 2  /* LDS-staged flat tiles, ragged lane packing, partials + finalize */
+} rp_algo;
+
+/*
+ * Thresholds of the status predicate, detect_orfs.py:289-299 (defaults const.py:20-39;
+ * CLI flags cli.py:173-219).  status = 1 ("translating") iff
+ *   phase >= phase_score_cutoff  and  valid >= min_valid_codons
+ *   and  min_codon_cov >= min_reads_per_codon
+ *   and  valid / n_codons >= min_valid_codons_ratio
+ *   and  read_count / n_codons >= min_density_over_orf,      n_codons = max(1, L // 3).
+ */
+typedef struct rp_filter_params {
+    double phase_score_cutoff;     /* const.py:20  CUTOFF = 0.428571428571 */
+    double min_valid_codons_ratio; /* const.py:35  0 */
+    double min_density_over_orf;   /* const.py:39  0.0 */
+    double min_reads_per_codon;    /* const.py:32  0 */
+    int32_t min_valid_codons;      /* const.py:27  5 */
+    int32_t reserved;
+} rp_filter_params;
+
+/* Library / error introspection. */
+const char *rp_version(void);
+const char *rp_last_error(void);
+const char *rp_status_string(int status);
+
+/* Number of visible HIP devices (RP_ERR_DEVICE if the runtime reports none). */
+int rp_device_count(int *n_devices);
+
+/* Fill *out with the reference defaults (const.py:20-39). */
+int rp_filter_defaults(rp_filter_params *out);
+
+/*
+ * Bytes of device workspace rp_phase_score_csr_dev needs for a batch of this
+ * shape (tile index + split-ORF partials).  16-byte aligned pointer required.
+ */
+int rp_workspace_bytes(int64_t n_orfs, int64_t total_nt, int algo, size_t *bytes);
+
+/*
+ * THE HOT PATH.  Replaces, for a whole batch of ORFs at once, the per-ORF body of
+ * export_orf_coverages (detect_orfs.py:274-299):
+ *     count = sum(cov); length = len(cov)                      detect_orfs.py:278-279
+ *     coh, valid_codons = phasescore(cov)                      detect_orfs.py:280
+ *                                                              -> statistics.py:48-115
+ *     codon_coverage = collapse_coverage_to_codon(cov)         detect_orfs.py:284
+ *                                                              -> common.py:164-180
+ *     valid_codons_ratio, orf_density, status                  detect_orfs.py:285-299
+ *
+ * Outputs per ORF i (arrays of n_orfs elements):
+ *     d_phase[i]          float64  phase score  (np.sqrt(coh), statistics.py:115)
+ *     d_valid[i]          int32    valid codons of the winning frame
+ *     d_read_count[i]     int64    sum(cov)
+ *     d_min_codon_cov[i]  int32    min over codon sums incl. the partial last codon
+ *                                  (RP_MIN_CODON_COV_EMPTY if the profile is empty)
+ *     d_flags[i]          uint8    RP_FLAG_* bits
+ *     d_status[i]         uint8    1 = translating, 0 = nontranslating; optional:
+ *                                  pass d_status = NULL or filter = NULL to skip
+ * total_nt must equal offsets[n_orfs] (the caller built the CSR and knows it);
+ * `filter` is a HOST pointer read before the call returns.
+ */
+int rp_phase_score_csr_dev(int device, const int32_t *d_counts, const int64_t *d_offsets,
+                           int64_t n_orfs, int64_t total_nt, double *d_phase, int32_t *d_valid,
+                           int64_t *d_read_count, int32_t *d_min_codon_cov, uint8_t *d_flags,
+                           uint8_t *d_status, const rp_filter_params *filter, void *d_workspace,
+                           size_t workspace_bytes, int algo, void *hip_stream);
+
+/*
+ * Per-frame diagnostics in float64: score_f (NaN when M_f == 0, 0 when N_f == 0),
+ * N_f, M_f for the three reading frames of every ORF, laid out [n_orfs][3].
+ * These are the quantities statistics.py:67-108 computes per frame and never
+ * exposes; used to analyse tie-flagged ORFs.
+ */
+int rp_phase_score_frames_dev(int device, const int32_t *d_counts, const int64_t *d_offsets,
+                              int64_t n_orfs, double *d_frame_score, int32_t *d_frame_n,
+                              int32_t *d_frame_m, void *hip_stream);
+
+/*
+ * float64 profiles (the metagene caller passes float sums: metagene.py:243-244
+ * -> statistics.py:48).  Same CSR convention, float64 values, float64 arithmetic.
+ */
+int rp_phase_score_f64_csr_dev(int device, const double *d_values, const int64_t *d_offsets,
+                               int64_t n_profiles, double *d_phase, int32_t *d_valid,
+                               uint8_t *d_flags, void *hip_stream);
+
+/*
+ * Synchronous input check (one pass over offsets and counts on the device, then a
+ * host sync): RP_ERR_OFFSETS / RP_ERR_COUNTS as documented above.
+ */
+int rp_validate_csr_dev(int device, const int32_t *d_counts, const int64_t *d_offsets,
+                        int64_t n_orfs, int64_t total_nt, void *hip_stream);
+
+/*
+ * Same as rp_phase_score_csr_dev but brackets each internal launch with HIP events
+ * on `hip_stream`, synchronises, and reports milliseconds: ms[0] tile-index pass,
+ * ms[1] main scoring kernel, ms[2] split-ORF finalize, ms[3] whole call.
+ * For bench.py's roofline figure; not for production use (it blocks the host).
+ */
+int rp_phase_score_csr_dev_timed(int device, const int32_t *d_counts, const int64_t *d_offsets,
+                                 int64_t n_orfs, int64_t total_nt, double *d_phase,
+                                 int32_t *d_valid, int64_t *d_read_count,
+                                 int32_t *d_min_codon_cov, uint8_t *d_flags, uint8_t *d_status,
+                                 const rp_filter_params *filter, void *d_workspace,
+                                 size_t workspace_bytes, int algo, void *hip_stream, float ms[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIBOPHASE_H */

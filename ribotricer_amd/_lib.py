@@ -1,0 +1,115 @@
+"""ctypes binding of libribophase.so (C ABI: include/ribophase.h).
+
+The shared library is the product: there is no Python or CPU stand-in for it.
+Importing this module without a built library raises immediately with the build
+command; calling a compute entry point without a usable HIP device raises
+``RibophaseError`` carrying the library's own message.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libribophase.so")
+
+RP_OK = 0
+RP_ALGO_AUTO, RP_ALGO_WAVE, RP_ALGO_TILE = 0, 1, 2
+ALGOS = {"auto": RP_ALGO_AUTO, "wave": RP_ALGO_WAVE, "tile": RP_ALGO_TILE}
+
+FLAG_TIE = 0x01
+FLAG_RECHECK64 = 0x02
+FLAG_SPLIT = 0x04
+MIN_CODON_COV_EMPTY = 2147483647
+MAX_COUNT = 536870911
+
+
+class RibophaseError(RuntimeError):
+    """A libribophase entry point returned a negative rp_status."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libribophase: {message} (status {status})")
+        self.status = status
+
+
+class FilterParams(ctypes.Structure):
+    """rp_filter_params -- thresholds of detect_orfs.py:289-299 (defaults const.py:20-39)."""
+
+    _fields_ = [
+        ("phase_score_cutoff", ctypes.c_double),
+        ("min_valid_codons_ratio", ctypes.c_double),
+        ("min_density_over_orf", ctypes.c_double),
+        ("min_reads_per_codon", ctypes.c_double),
+        ("min_valid_codons", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+# every symbol include/ribophase.h declares: name -> (restype, argtypes)
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_SCORE_ARGS = [_int, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(FilterParams), _vp, ctypes.c_size_t, _int, _vp]
+SYMBOLS = {
+    "rp_version": (ctypes.c_char_p, []),
+    "rp_last_error": (ctypes.c_char_p, []),
+    "rp_status_string": (ctypes.c_char_p, [_int]),
+    "rp_device_count": (_int, [ctypes.POINTER(_int)]),
+    "rp_filter_defaults": (_int, [ctypes.POINTER(FilterParams)]),
+    "rp_workspace_bytes": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_size_t)]),
+    "rp_phase_score_csr_dev": (_int, _SCORE_ARGS),
+    "rp_phase_score_csr_dev_timed": (_int, _SCORE_ARGS + [ctypes.POINTER(ctypes.c_float * 4)]),
+    "rp_phase_score_frames_dev": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "rp_phase_score_f64_csr_dev": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "rp_validate_csr_dev": (_int, [_int, _vp, _vp, _i64, _i64, _vp]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libribophase.so once; fail loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing. Build the HIP extension first: "
+            "`make -C ribotricer_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "ribotricer_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != RP_OK:
+        raise RibophaseError(status, load().rp_last_error().decode("utf-8", "replace"))
+
+
+def version() -> str:
+    return load().rp_version().decode()
+
+
+def device_count() -> int:
+    n = _int(0)
+    check(load().rp_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def filter_defaults() -> FilterParams:
+    fp = FilterParams()
+    check(load().rp_filter_defaults(ctypes.byref(fp)))
+    return fp
+
+
+def workspace_bytes(n_orfs: int, total_nt: int, algo: int) -> int:
+    out = ctypes.c_size_t(0)
+    check(load().rp_workspace_bytes(n_orfs, total_nt, algo, ctypes.byref(out)))
+    return out.value

@@ -1,0 +1,330 @@
+// ribophase.hip -- C ABI of libribophase.so (see include/ribophase.h).
+//
+// Host side of the MI355X phase-score engine: argument checking, workspace carving,
+// kernel selection and launches on the caller's stream.  No device allocation, no
+// CPU compute path: if HIP is unusable every compute entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/ribophase.h"
+#include "rp_device.hpp"
+#include "rp_tile.hpp"
+#include "rp_wave.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define RP_HIP(call)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fail(RP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                           \
+    } while (0)
+
+int select_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(RP_ERR_DEVICE, "no HIP device available (%s)",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    }
+    if (device < 0 || device >= n) return fail(RP_ERR_DEVICE, "device %d out of range [0,%d)", device, n);
+    RP_HIP(hipSetDevice(device));
+    return RP_OK;
+}
+
+int grid_for_waves(long long n_items, int waves_per_block)
+{
+    // memory-bound grid-stride launch: cap at 256 CUs x 8 workgroups
+    long long blocks = (n_items + waves_per_block - 1) / waves_per_block;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    return (int)blocks;
+}
+
+rp::FilterParams make_filter(const rp_filter_params *f, const uint8_t *d_status)
+{
+    rp::FilterParams fp;
+    memset(&fp, 0, sizeof(fp));
+    if (f != nullptr && d_status != nullptr) {
+        fp.phase_score_cutoff = f->phase_score_cutoff;
+        fp.min_valid_codons_ratio = f->min_valid_codons_ratio;
+        fp.min_density_over_orf = f->min_density_over_orf;
+        fp.min_reads_per_codon = f->min_reads_per_codon;
+        fp.min_valid_codons = f->min_valid_codons;
+        fp.enabled = 1;
+    }
+    return fp;
+}
+
+struct Timing {
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool on = false;
+};
+
+int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, int64_t n_orfs,
+               int64_t total_nt, double *d_phase, int32_t *d_valid, int64_t *d_read_count,
+               int32_t *d_min_codon_cov, uint8_t *d_flags, uint8_t *d_status,
+               const rp_filter_params *filter, void *d_workspace, size_t workspace_bytes, int algo,
+               void *hip_stream, Timing *tm)
+{
+    if (n_orfs < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "n_orfs=%lld total_nt=%lld must be >= 0", (long long)n_orfs, (long long)total_nt);
+    if (algo != RP_ALGO_AUTO && algo != RP_ALGO_WAVE && algo != RP_ALGO_TILE)
+        return fail(RP_ERR_ARG, "unknown algo %d", algo);
+    if (n_orfs > 0 && (!d_offsets || !d_phase || !d_valid || !d_read_count || !d_min_codon_cov || !d_flags))
+        return fail(RP_ERR_NULL, "offsets and the five output arrays must be non-null");
+    if (total_nt > 0 && !d_counts) return fail(RP_ERR_NULL, "d_counts is null but total_nt > 0");
+    int rc = select_device(device);
+    if (rc != RP_OK) return rc;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[0], stream));
+    if (n_orfs == 0) {
+        if (tm && tm->on)
+            for (int k = 1; k < 4; ++k) RP_HIP(hipEventRecord(tm->ev[k], stream));
+        return RP_OK;
+    }
+    const rp::OrfOutputs out{d_phase, d_valid, d_read_count, d_min_codon_cov, d_flags, d_status};
+    const rp::FilterParams fp = make_filter(filter, d_status);
+    if (algo == RP_ALGO_AUTO) algo = RP_ALGO_WAVE;
+
+    if (algo == RP_ALGO_WAVE) {
+        if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[1], stream));
+        const int grid = grid_for_waves(n_orfs, rp::kWaveBlock / rp::kWave);
+        hipLaunchKernelGGL(rp::k_wave_score, dim3(grid), dim3(rp::kWaveBlock), 0, stream, d_counts,
+                           d_offsets, (long long)n_orfs, out, fp);
+        RP_HIP(hipGetLastError());
+        if (tm && tm->on) {
+            RP_HIP(hipEventRecord(tm->ev[2], stream));
+            RP_HIP(hipEventRecord(tm->ev[3], stream));
+        }
+        return RP_OK;
+    }
+
+    // RP_ALGO_TILE
+    size_t need = 0;
+    rc = rp_workspace_bytes(n_orfs, total_nt, RP_ALGO_TILE, &need);
+    if (rc != RP_OK) return rc;
+    if (!d_workspace || workspace_bytes < need)
+        return fail(RP_ERR_WORKSPACE, "workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    if ((reinterpret_cast<uintptr_t>(d_workspace) & 15u) != 0)
+        return fail(RP_ERR_WORKSPACE, "workspace must be 16-byte aligned");
+    const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt);
+    rp::TileWorkspace ws = rp::carve_workspace(d_workspace, plan);
+
+    // 1. tile index: first ORF starting at or after each tile boundary
+    {
+        const long long threads = n_orfs + 1;
+        const int block = 256;
+        const int grid = (int)((threads + block - 1) / block);
+        hipLaunchKernelGGL(rp::k_tile_index, dim3(grid), dim3(block), 0, stream, d_offsets,
+                           (long long)n_orfs, plan, ws);
+        RP_HIP(hipGetLastError());
+    }
+    if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[1], stream));
+    // 2. main scoring pass over flat tiles
+    hipLaunchKernelGGL(rp::k_tile_score, dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
+                       d_counts, d_offsets, (long long)n_orfs, plan, ws, out, fp);
+    RP_HIP(hipGetLastError());
+    if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));
+    // 3. ORFs that straddle a tile boundary: combine partials
+    {
+        const int block = 256;
+        const int grid = (int)((plan.n_tiles + block - 1) / block);
+        hipLaunchKernelGGL(rp::k_tile_finalize, dim3(grid), dim3(block), 0, stream, d_counts,
+                           d_offsets, (long long)n_orfs, plan, ws, out, fp);
+        RP_HIP(hipGetLastError());
+    }
+    if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[3], stream));
+    return RP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rp_version(void) { return RP_VERSION_STRING; }
+
+const char *rp_last_error(void) { return g_err; }
+
+const char *rp_status_string(int status)
+{
+    switch (status) {
+        case RP_OK: return "ok";
+        case RP_ERR_NULL: return "null pointer";
+        case RP_ERR_SIZE: return "bad size";
+        case RP_ERR_OFFSETS: return "bad CSR offsets";
+        case RP_ERR_HIP: return "HIP runtime error";
+        case RP_ERR_WORKSPACE: return "bad workspace";
+        case RP_ERR_DEVICE: return "no such HIP device";
+        case RP_ERR_COUNTS: return "count out of range";
+        case RP_ERR_ARG: return "invalid argument";
+        default: return "unknown status";
+    }
+}
+
+int rp_device_count(int *n_devices)
+{
+    if (!n_devices) return fail(RP_ERR_NULL, "n_devices is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        *n_devices = 0;
+        return fail(RP_ERR_DEVICE, "no HIP device available (%s)",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    }
+    *n_devices = n;
+    return RP_OK;
+}
+
+int rp_filter_defaults(rp_filter_params *out)
+{
+    if (!out) return fail(RP_ERR_NULL, "out is null");
+    out->phase_score_cutoff = 0.428571428571;  // const.py:20
+    out->min_valid_codons_ratio = 0.0;         // const.py:35
+    out->min_density_over_orf = 0.0;           // const.py:39
+    out->min_reads_per_codon = 0.0;            // const.py:32
+    out->min_valid_codons = 5;                 // const.py:27
+    out->reserved = 0;
+    return RP_OK;
+}
+
+int rp_workspace_bytes(int64_t n_orfs, int64_t total_nt, int algo, size_t *bytes)
+{
+    if (!bytes) return fail(RP_ERR_NULL, "bytes is null");
+    if (n_orfs < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "negative size");
+    if (algo != RP_ALGO_AUTO && algo != RP_ALGO_WAVE && algo != RP_ALGO_TILE)
+        return fail(RP_ERR_ARG, "unknown algo %d", algo);
+    if (algo == RP_ALGO_WAVE) {
+        *bytes = 0;
+        return RP_OK;
+    }
+    *bytes = rp::workspace_bytes(rp::make_tile_plan(n_orfs, total_nt));
+    return RP_OK;
+}
+
+int rp_phase_score_csr_dev(int device, const int32_t *d_counts, const int64_t *d_offsets,
+                           int64_t n_orfs, int64_t total_nt, double *d_phase, int32_t *d_valid,
+                           int64_t *d_read_count, int32_t *d_min_codon_cov, uint8_t *d_flags,
+                           uint8_t *d_status, const rp_filter_params *filter, void *d_workspace,
+                           size_t workspace_bytes, int algo, void *hip_stream)
+{
+    return score_impl(device, d_counts, d_offsets, n_orfs, total_nt, d_phase, d_valid, d_read_count,
+                      d_min_codon_cov, d_flags, d_status, filter, d_workspace, workspace_bytes, algo,
+                      hip_stream, nullptr);
+}
+
+int rp_phase_score_csr_dev_timed(int device, const int32_t *d_counts, const int64_t *d_offsets,
+                                 int64_t n_orfs, int64_t total_nt, double *d_phase,
+                                 int32_t *d_valid, int64_t *d_read_count,
+                                 int32_t *d_min_codon_cov, uint8_t *d_flags, uint8_t *d_status,
+                                 const rp_filter_params *filter, void *d_workspace,
+                                 size_t workspace_bytes, int algo, void *hip_stream, float ms[4])
+{
+    if (!ms) return fail(RP_ERR_NULL, "ms is null");
+    int rc = select_device(device);
+    if (rc != RP_OK) return rc;
+    Timing tm;
+    tm.on = true;
+    for (int k = 0; k < 4; ++k) RP_HIP(hipEventCreate(&tm.ev[k]));
+    rc = score_impl(device, d_counts, d_offsets, n_orfs, total_nt, d_phase, d_valid, d_read_count,
+                    d_min_codon_cov, d_flags, d_status, filter, d_workspace, workspace_bytes, algo,
+                    hip_stream, &tm);
+    if (rc == RP_OK) {
+        hipError_t e = hipEventSynchronize(tm.ev[3]);
+        if (e != hipSuccess) rc = fail(RP_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
+    }
+    if (rc == RP_OK) {
+        (void)hipEventElapsedTime(&ms[0], tm.ev[0], tm.ev[1]);
+        (void)hipEventElapsedTime(&ms[1], tm.ev[1], tm.ev[2]);
+        (void)hipEventElapsedTime(&ms[2], tm.ev[2], tm.ev[3]);
+        (void)hipEventElapsedTime(&ms[3], tm.ev[0], tm.ev[3]);
+    }
+    for (int k = 0; k < 4; ++k) (void)hipEventDestroy(tm.ev[k]);
+    return rc;
+}
+
+int rp_phase_score_frames_dev(int device, const int32_t *d_counts, const int64_t *d_offsets,
+                              int64_t n_orfs, double *d_frame_score, int32_t *d_frame_n,
+                              int32_t *d_frame_m, void *hip_stream)
+{
+    if (n_orfs < 0) return fail(RP_ERR_SIZE, "n_orfs must be >= 0");
+    if (n_orfs > 0 && (!d_offsets || !d_frame_score || !d_frame_n || !d_frame_m))
+        return fail(RP_ERR_NULL, "offsets and the three output arrays must be non-null");
+    int rc = select_device(device);
+    if (rc != RP_OK) return rc;
+    if (n_orfs == 0) return RP_OK;
+    const int grid = grid_for_waves(n_orfs, rp::kWaveBlock / rp::kWave);
+    hipLaunchKernelGGL(rp::k_wave_frames, dim3(grid), dim3(rp::kWaveBlock), 0, (hipStream_t)hip_stream,
+                       d_counts, d_offsets, (long long)n_orfs, d_frame_score, d_frame_n, d_frame_m);
+    RP_HIP(hipGetLastError());
+    return RP_OK;
+}
+
+int rp_phase_score_f64_csr_dev(int device, const double *d_values, const int64_t *d_offsets,
+                               int64_t n_profiles, double *d_phase, int32_t *d_valid,
+                               uint8_t *d_flags, void *hip_stream)
+{
+    if (n_profiles < 0) return fail(RP_ERR_SIZE, "n_profiles must be >= 0");
+    if (n_profiles > 0 && (!d_offsets || !d_phase || !d_valid || !d_flags))
+        return fail(RP_ERR_NULL, "offsets and the three output arrays must be non-null");
+    int rc = select_device(device);
+    if (rc != RP_OK) return rc;
+    if (n_profiles == 0) return RP_OK;
+    const int grid = grid_for_waves(n_profiles, rp::kWaveBlock / rp::kWave);
+    hipLaunchKernelGGL(rp::k_wave_score_f64in, dim3(grid), dim3(rp::kWaveBlock), 0,
+                       (hipStream_t)hip_stream, d_values, d_offsets, (long long)n_profiles, d_phase,
+                       d_valid, d_flags);
+    RP_HIP(hipGetLastError());
+    return RP_OK;
+}
+
+int rp_validate_csr_dev(int device, const int32_t *d_counts, const int64_t *d_offsets,
+                        int64_t n_orfs, int64_t total_nt, void *hip_stream)
+{
+    if (n_orfs < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "negative size");
+    if (!d_offsets) return fail(RP_ERR_NULL, "d_offsets is null");
+    if (total_nt > 0 && !d_counts) return fail(RP_ERR_NULL, "d_counts is null but total_nt > 0");
+    int rc = select_device(device);
+    if (rc != RP_OK) return rc;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    int *d_err = nullptr;
+    // validation is a debugging aid, not the hot path: it owns a 4-byte scratch word
+    RP_HIP(hipMalloc(&d_err, sizeof(int)));
+    hipError_t e = hipMemsetAsync(d_err, 0, sizeof(int), stream);
+    int h_err = 0;
+    if (e == hipSuccess) {
+        long long work = total_nt > n_orfs ? total_nt : n_orfs + 1;
+        long long blocks = (work + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(rp::k_validate, dim3((unsigned)blocks), dim3(256), 0, stream, d_counts,
+                           d_offsets, (long long)n_orfs, (long long)total_nt, d_err);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_err);
+    if (e != hipSuccess) return fail(RP_ERR_HIP, "validate: %s", hipGetErrorString(e));
+    if (h_err & 1) return fail(RP_ERR_OFFSETS, "offsets must start at 0, be monotone and end at total_nt");
+    if (h_err & 2) return fail(RP_ERR_COUNTS, "counts must lie in [0, %d]", RP_MAX_COUNT);
+    return RP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,274 @@
+// rp_device.hpp -- device-side building blocks shared by every phase-score kernel.
+//
+// gfx950 only (wave64).  The arithmetic follows the closed form of
+// ribotricer/statistics.py:67-108 in an oblique integer
+// basis that keeps the per-codon work small:
+//
+//   codon (a,b,c):  d0 = a-b, d1 = b-c                    (exact int32)
+//                   q  = d0^2 + d0*d1 + d1^2  = |a + b w + c w^2|^2,  w = e^{2 pi i/3}
+//                   unit vector u = ((d0 + d1/2), (sqrt3/2) d1) / sqrt(q)
+//   frame sums:     P = sum d0/sqrt(q),  Q = sum d1/sqrt(q)
+//                   |sum u|^2 = P^2 + P*Q + Q^2
+//   score_f = |sum u|^2 / (N_f * M_f),   N_f = #codons not all-zero,
+//                                        M_f = #codons not a==b==c  (q != 0)
+//
+// q is an integer >= 1 whenever it is non-zero, so the all-equal test is exact
+// and no epsilon is involved anywhere before the final frame comparison.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ribophase.h"
+
+namespace rp {
+
+constexpr int kWave = 64;
+
+// absolute/relative margin under which an fp32 frame comparison is not trusted and
+// the ORF is re-derived in float64 (fp32 score error is <= ~3e-6 for the longest
+// per-lane sums we allow in fp32; see DESIGN.md "Precision").
+constexpr double kRecheckMargin = 1e-5;
+
+// ---------------------------------------------------------------------------
+// per-codon accumulation
+// ---------------------------------------------------------------------------
+template <typename Real>
+struct FrameAcc {
+    Real p;  // sum d0 / sqrt(q)
+    Real q;  // sum d1 / sqrt(q)
+    int n;   // codons that are not all-zero
+    int m;   // codons that are not a == b == c
+};
+
+template <typename Real>
+__device__ __forceinline__ void acc_clear(FrameAcc<Real> (&acc)[3])
+{
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        acc[f].p = Real(0);
+        acc[f].q = Real(0);
+        acc[f].n = 0;
+        acc[f].m = 0;
+    }
+}
+
+// fp32: one v_rsq_f32 (1 ulp) per codon; q >= 1 so no denormal handling is needed.
+__device__ __forceinline__ void codon_add(FrameAcc<float> &acc, int a, int b, int c, bool in_range)
+{
+    const int d0i = a - b;
+    const int d1i = b - c;
+    const bool nz = in_range && ((a | b | c) != 0);
+    const bool use = in_range && ((d0i | d1i) != 0);
+    const float d0 = (float)d0i;
+    const float d1 = (float)d1i;
+    const float qq = __builtin_fmaf(d0, d0 + d1, d1 * d1);
+    const float r = use ? __builtin_amdgcn_rsqf(qq) : 0.0f;
+    acc.p = __builtin_fmaf(d0, r, acc.p);
+    acc.q = __builtin_fmaf(d1, r, acc.q);
+    acc.n += nz ? 1 : 0;
+    acc.m += use ? 1 : 0;
+}
+
+// fp64: correctly rounded sqrt and divisions, so single-axis codons contribute
+// exactly +-1 / 0 and exact ties between frames stay exact.
+__device__ __forceinline__ void codon_add(FrameAcc<double> &acc, int a, int b, int c, bool in_range)
+{
+    const int d0i = a - b;
+    const int d1i = b - c;
+    const bool nz = in_range && ((a | b | c) != 0);
+    const bool use = in_range && ((d0i | d1i) != 0);
+    if (use) {
+        const double d0 = (double)d0i;
+        const double d1 = (double)d1i;
+        const double s = sqrt(__builtin_fma(d0, d0 + d1, d1 * d1));
+        acc.p += d0 / s;
+        acc.q += d1 / s;
+    }
+    acc.n += nz ? 1 : 0;
+    acc.m += use ? 1 : 0;
+}
+
+// float64 INPUT values (metagene-style profiles): same closed form, tests are
+// exact comparisons on the given doubles (statistics.py:72).
+__device__ __forceinline__ void codon_add_f64in(FrameAcc<double> &acc, double a, double b, double c,
+                                                bool in_range)
+{
+    const bool nz = in_range && !(a == 0.0 && b == 0.0 && c == 0.0);
+    const bool use = nz && !(a == b && b == c);
+    if (use) {
+        const double d0 = a - b;
+        const double d1 = b - c;
+        const double s = sqrt(__builtin_fma(d0, d0 + d1, d1 * d1));
+        acc.p += d0 / s;
+        acc.q += d1 / s;
+    }
+    acc.n += nz ? 1 : 0;
+    acc.m += use ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// wave64 butterflies (every lane ends with the total)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ long long wave_sum(long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ int wave_min(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// frame scores and the frame state machine
+// ---------------------------------------------------------------------------
+struct FrameScore {
+    double score;  // 0 when n == 0, NaN when m == 0 < n
+    int n;
+    int m;
+};
+
+__device__ __forceinline__ FrameScore frame_score(double p, double q, int n, int m)
+{
+    FrameScore r;
+    r.n = n;
+    r.m = m;
+    if (n == 0) {
+        r.score = 0.0;
+    } else if (m == 0) {
+        r.score = __builtin_nan("");
+    } else {
+        r.score = __builtin_fma(p, p + q, q * q) / ((double)n * (double)m);
+    }
+    return r;
+}
+
+__device__ __forceinline__ double tie_tol(double best)
+{
+    return RP_TIE_RTOL * (best > 1.0 ? best : 1.0);
+}
+
+// statistics.py:64-66,94-95,109-115.  An empty frame resets; a later frame wins only
+// when it beats the running best by more than the tie tolerance (exact-arithmetic
+// rule: a tie keeps the earlier frame); RP_FLAG_TIE marks ORFs where another live
+// frame with a different N sits within the tolerance of the final best.
+__device__ __forceinline__ void combine_frames(const FrameScore (&fr)[3], double &phase, int &valid,
+                                               unsigned &flags)
+{
+    double coh = 0.0;
+    int v = -1;
+    int first_live = 0;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        if (fr[f].n == 0) {
+            coh = 0.0;
+            v = 0;
+            first_live = f + 1;
+        } else {
+            if (fr[f].score > coh + tie_tol(coh)) {
+                coh = fr[f].score;
+                v = fr[f].n;
+            }
+            if (v == -1) v = fr[f].n;
+        }
+    }
+    unsigned fl = 0;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        if (f >= first_live && fr[f].n != v && fabs(fr[f].score - coh) <= tie_tol(coh)) fl |= RP_FLAG_TIE;
+    }
+    phase = sqrt(coh);
+    valid = v;
+    flags = fl;
+}
+
+// Can the frame decision made on fp32-accumulated scores be trusted?  It cannot when
+// two live frames with different N (or a live frame and the initial best of 0 with a
+// different fallback N) are closer than the fp32 error margin.
+__device__ __forceinline__ bool fp32_decision_unsafe(const FrameScore (&fr)[3])
+{
+    int first_live = 0;
+#pragma unroll
+    for (int f = 0; f < 3; ++f)
+        if (fr[f].n == 0) first_live = f + 1;
+    if (first_live >= 3) return false;
+    const int n_fallback = first_live == 0 ? fr[0].n : (first_live == 1 ? fr[1].n : fr[2].n);
+    bool unsafe = false;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        if (f < first_live) continue;
+        const double sf = fr[f].score;
+        if (fr[f].n != n_fallback && fabs(sf) <= kRecheckMargin) unsafe = true;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            if (g <= f || g < first_live) continue;
+            const double sg = fr[g].score;
+            const double scale = fmax(1.0, fmax(fabs(sf), fabs(sg)));
+            if (fr[f].n != fr[g].n && fabs(sf - sg) <= kRecheckMargin * scale) unsafe = true;
+        }
+    }
+    return unsafe;  // comparisons with NaN are false: NaN frames are decided by integers
+}
+
+// detect_orfs.py:281,285-299
+struct FilterParams {
+    double phase_score_cutoff;
+    double min_valid_codons_ratio;
+    double min_density_over_orf;
+    double min_reads_per_codon;
+    int min_valid_codons;
+    int enabled;
+};
+
+__device__ __forceinline__ unsigned char orf_status(const FilterParams &fp, double phase, int valid,
+                                                    long long read_count, int min_codon_cov,
+                                                    long long length)
+{
+    const long long n_codons = (length / 3) > 1 ? (length / 3) : 1;  // max(1, length // 3)
+    const double ratio = (double)valid / (double)n_codons;
+    const double density = (double)read_count / (double)n_codons;
+    const bool ok = phase >= fp.phase_score_cutoff && valid >= fp.min_valid_codons &&
+                    (double)min_codon_cov >= fp.min_reads_per_codon &&
+                    ratio >= fp.min_valid_codons_ratio && density >= fp.min_density_over_orf;
+    return ok ? 1 : 0;
+}
+
+struct OrfOutputs {
+    double *phase;
+    int32_t *valid;
+    int64_t *read_count;
+    int32_t *min_codon_cov;
+    uint8_t *flags;
+    uint8_t *status;  // may be null
+};
+
+__device__ __forceinline__ void store_orf(const OrfOutputs &out, const FilterParams &fp, int64_t i,
+                                          double phase, int valid, long long read_count,
+                                          int min_codon_cov, unsigned flags, long long length)
+{
+    out.phase[i] = phase;
+    out.valid[i] = valid;
+    out.read_count[i] = read_count;
+    out.min_codon_cov[i] = min_codon_cov;
+    out.flags[i] = (uint8_t)flags;
+    if (out.status != nullptr && fp.enabled)
+        out.status[i] = orf_status(fp, phase, valid, read_count, min_codon_cov, length);
+}
+
+}  // namespace rp

@@ -1,0 +1,213 @@
+"""Host-side mirror of the hot loop of ``ribotricer.detect_orfs``.
+
+``export_orf_coverages`` keeps the reference's signature, TSV header, column order
+and number formatting (ribotricer/detect_orfs.py:206-324) so that ``detect_orfs()``
+(detect_orfs.py:510-520), ``learn_cutoff`` (learn_cutoff.py:231-263) and the
+downstream parsers (count_orfs.py:63-77) work unchanged.  What changes is the loop
+body: profiles are packed CSR-style once, scored for all ORFs in one launch of the
+gfx950 kernels (phase score, valid codons, read count, codon minimum and the status
+predicate), and rows are formatted from the returned arrays.
+
+Index parsing and profile gathering (orf.py:122-182, detect_orfs.py:134-203) are
+build-owned minimal host code here -- the "next" rows of SURVEY.md section 8(f).
+"""
+
+from __future__ import annotations
+
+import sys
+from typing import NamedTuple
+
+import numpy as np
+
+from .const import (
+    CUTOFF,
+    MINIMUM_DENSITY_OVER_ORF,
+    MINIMUM_READS_PER_CODON,
+    MINIMUM_VALID_CODONS,
+    MINIMUM_VALID_CODONS_RATIO,
+)
+from .engine import get_engine, make_filter
+
+# detect_orfs.py:241-260 (the last name carries the newline, :259)
+COLUMNS = [
+    "ORF_ID",
+    "ORF_type",
+    "status",
+    "phase_score",
+    "read_count",
+    "length",
+    "valid_codons",
+    "valid_codons_ratio",
+    "read_density",
+    "transcript_id",
+    "transcript_type",
+    "gene_id",
+    "gene_name",
+    "gene_type",
+    "chrom",
+    "strand",
+    "start_codon",
+    "profile",
+]
+
+
+class IndexRecord(NamedTuple):
+    """One candidate ORF of a ribotricer index (the fields ORF.from_string keeps, orf.py:153-182)."""
+
+    oid: str
+    category: str
+    tid: str
+    ttype: str
+    gid: str
+    gname: str
+    gtype: str
+    chrom: str
+    strand: str
+    start_codon: object  # str, or None when the index field has < 3 characters (orf.py:117-118)
+    intervals: tuple  # ((start, end), ...) 1-based closed, ascending
+
+
+def parse_index_line(line: str) -> IndexRecord:
+    """Parse one line of ``{prefix}_candidate_orfs.tsv`` (format: prepare_orfs.py:370-404).
+
+    Error behaviour follows ORF.from_string (orf.py:143-152): a wrong column count
+    terminates with the reference's message.
+    """
+    fields = line.split("\t")
+    if len(fields) != 11:
+        sys.exit(
+            "{}\n{}".format(
+                "Error: unexpected number of columns found for index file",
+                "please run ribotricer prepare-orfs to regenerate",
+            )
+        )
+    blocks = []
+    for group in fields[10].split(","):
+        start, end = group.split("-")
+        blocks.append((int(start), int(end)))
+    blocks.sort(key=lambda b: b[0])  # orf.py:100
+    length = sum(e - s + 1 for s, e in blocks)
+    tid = fields[2]
+    oid = f"{tid}_{blocks[0][0]}_{blocks[-1][1]}_{length}"  # orf.py:103 (index column 0 is ignored)
+    seq = fields[9]
+    return IndexRecord(
+        oid, fields[1], tid, fields[3], fields[4], fields[5], fields[6], fields[7], fields[8],
+        seq[:3] if len(seq) >= 3 else None, tuple(blocks),
+    )
+
+
+def read_index(ribotricer_index: str) -> list:
+    """All records of an index file, header skipped (detect_orfs.py:273-276)."""
+    records = []
+    with open(ribotricer_index) as anno:
+        anno.readline()
+        for line in anno:
+            records.append(parse_index_line(line))
+    return records
+
+
+def orf_coverage(orf: IndexRecord, alignments, offset_5p: int = 0, offset_3p: int = 0) -> list:
+    """Per-nucleotide P-site counts of one ORF, 5'->3' (detect_orfs.py:134-203).
+
+    ``alignments[strand][(chrom, pos)]`` -> count; missing positions count 0; the
+    profile is reversed for '-' strand ORFs.
+    """
+    strand = orf.strand
+    if strand == "-":
+        offset_5p, offset_3p = offset_3p, offset_5p
+    table = alignments[strand] if strand in alignments else {}
+    chrom = orf.chrom
+    get = table.get
+    first_start = orf.intervals[0][0]
+    last_end = orf.intervals[-1][1]
+    coverage = [get((chrom, pos), 0) for pos in range(first_start - offset_5p, first_start)]
+    for start, end in orf.intervals:
+        coverage.extend(get((chrom, pos), 0) for pos in range(start, end + 1))
+    coverage.extend(get((chrom, pos), 0) for pos in range(last_end + 1, last_end + offset_3p + 1))
+    if strand == "-":
+        coverage.reverse()
+    return coverage
+
+
+def pack_profiles(records, merged_alignments):
+    """CSR-pack the profiles of all records: ``(counts int32[sum L], offsets int64[n+1])``."""
+    lengths = np.fromiter((sum(e - s + 1 for s, e in r.intervals) for r in records), np.int64, len(records))
+    offsets = np.zeros(len(records) + 1, np.int64)
+    np.cumsum(lengths, out=offsets[1:])
+    counts = np.zeros(int(offsets[-1]), np.int32)
+    for r, o in zip(records, offsets[:-1]):
+        cov = orf_coverage(r, merged_alignments)
+        counts[o : o + len(cov)] = cov
+    return counts, offsets
+
+
+def score_profiles(counts, offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
+                   min_valid_codons_ratio, min_density_over_orf, device=None) -> dict:
+    """One launch for the whole batch; host numpy arrays back (24 B + 2 B per ORF)."""
+    import torch
+
+    eng = get_engine(device)
+    thresholds = make_filter(
+        phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio, min_density_over_orf
+    )
+    res = eng.score(counts, offsets, thresholds=thresholds)
+    torch.cuda.synchronize(eng.device)
+    return res.cpu_numpy()
+
+
+def format_rows(records, counts, offsets, res, report_all: bool):
+    """Yield the TSV rows of detect_orfs.py:301-324 (same ``str.format('{}')`` renderings)."""
+    lengths = np.diff(offsets)
+    n_codons = np.maximum(1, lengths // 3)  # detect_orfs.py:281
+    formatter = "{}\t" * (len(COLUMNS) - 1) + "{}\n"
+    for i, r in enumerate(records):
+        translating = bool(res["status"][i])
+        if not report_all and not translating:
+            continue
+        valid = int(res["valid"][i])
+        count = int(res["read_count"][i])
+        nc = int(n_codons[i])
+        yield formatter.format(
+            r.oid,
+            r.category,
+            "translating" if translating else "nontranslating",
+            repr(float(res["phase"][i])),  # str(np.float64) == shortest round-trip repr
+            count,
+            int(lengths[i]),
+            valid,
+            valid / nc,  # detect_orfs.py:285
+            repr(count / nc),  # detect_orfs.py:287 (np.float64 str == float repr)
+            r.tid,
+            r.ttype,
+            r.gid,
+            r.gname,
+            r.gtype,
+            r.chrom,
+            r.strand,
+            r.start_codon,
+            counts[offsets[i] : offsets[i + 1]].tolist(),
+        )
+
+
+def export_orf_coverages(
+    ribotricer_index: str,
+    merged_alignments,
+    prefix: str,
+    phase_score_cutoff: float = CUTOFF,
+    min_valid_codons: int = MINIMUM_VALID_CODONS,
+    min_reads_per_codon: float = MINIMUM_READS_PER_CODON,
+    min_valid_codons_ratio: float = MINIMUM_VALID_CODONS_RATIO,
+    min_density_over_orf: float = MINIMUM_DENSITY_OVER_ORF,
+    report_all: bool = False,
+) -> None:
+    """Write ``{prefix}_translating_ORFs.tsv`` -- drop-in for detect_orfs.py:206-324."""
+    records = read_index(ribotricer_index)
+    counts, offsets = pack_profiles(records, merged_alignments)
+    res = score_profiles(
+        counts, offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
+        min_valid_codons_ratio, min_density_over_orf,
+    )
+    with open(f"{prefix}_translating_ORFs.tsv", "w") as output:
+        output.write("\t".join(COLUMNS) + "\n")
+        for row in format_rows(records, counts, offsets, res, report_all):
+            output.write(row)

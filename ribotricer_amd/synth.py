@@ -1,0 +1,100 @@
+"""Seeded synthetic CSR P-site batches for the BASELINE.json configs.
+
+cfg2  1 M ORFs, L = 3*k, k = max(20, round(lognormal(ln 80, 0.7)))  (mean ~300 nt,
+      min 60 nt = the reference CLI's --min_orf_length default, cli.py:64-69);
+      counts ~ Poisson(lambda_i * w_i[p mod 3]); lambda_i in {0 (20 % empty ORFs),
+      0.05, 0.3, 2.0}; frame weights (2, .5, .5) for half the ORFs, flat otherwise.
+cfg3  11 M ORFs, sigma = 0.9, 1 % of the ORFs with L % 3 != 0 (incomplete CDS).
+cfg5  long-tail stress: lognormal body (mean ~100 codons) + Pareto(1.5) tail clipped
+      at 33 333 codons (100 k nt).
+
+Lengths always come from numpy (identical on every machine for a given seed).  Counts
+come from numpy on the host (tests: the oracle and the GPU must see the same bytes) or
+from torch on the device (bench: no 13 GB H2D copy).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+CONFIGS = {
+    "cfg2": dict(sigma=0.7, median_codons=80, frac_non_mult3=0.0, pareto_frac=0.0),
+    "cfg3": dict(sigma=0.9, median_codons=80, frac_non_mult3=0.01, pareto_frac=0.0),
+    "cfg5": dict(sigma=0.7, median_codons=78, frac_non_mult3=0.01, pareto_frac=0.02),
+}
+LAMBDAS = np.array([0.0, 0.05, 0.3, 2.0])
+LAMBDA_P = np.array([0.2, 0.3, 0.3, 0.2])
+MAX_CODONS = 33333
+
+
+def orf_lengths(n_orfs: int, seed: int, cfg: str = "cfg2") -> np.ndarray:
+    c = CONFIGS[cfg]
+    rng = np.random.default_rng(seed)
+    k = np.rint(rng.lognormal(np.log(c["median_codons"]), c["sigma"], size=n_orfs))
+    if c["pareto_frac"] > 0:
+        tail = rng.random(n_orfs) < c["pareto_frac"]
+        k[tail] = 300.0 * (1.0 + rng.pareto(1.5, size=int(tail.sum())))
+    k = np.clip(k, 20, MAX_CODONS).astype(np.int64)
+    lengths = 3 * k
+    if c["frac_non_mult3"] > 0:
+        odd = rng.random(n_orfs) < c["frac_non_mult3"]
+        lengths[odd] += rng.integers(1, 3, size=int(odd.sum()))
+    return lengths
+
+
+def orf_rates(n_orfs: int, seed: int):
+    """Per-ORF Poisson rate and whether the ORF is framed (weights 2/.5/.5)."""
+    rng = np.random.default_rng(seed + 1)
+    lam = rng.choice(LAMBDAS, size=n_orfs, p=LAMBDA_P)
+    framed = rng.random(n_orfs) < 0.5
+    return lam, framed
+
+
+def offsets_from_lengths(lengths: np.ndarray) -> np.ndarray:
+    offsets = np.zeros(lengths.size + 1, np.int64)
+    np.cumsum(lengths, out=offsets[1:])
+    return offsets
+
+
+def synth_csr_host(n_orfs: int, seed: int = 20260213, cfg: str = "cfg2"):
+    """(counts int32, offsets int64) as numpy arrays."""
+    lengths = orf_lengths(n_orfs, seed, cfg)
+    offsets = offsets_from_lengths(lengths)
+    lam, framed = orf_rates(n_orfs, seed)
+    total = int(offsets[-1])
+    orf_id = np.repeat(np.arange(n_orfs), lengths)
+    frame = (np.arange(total, dtype=np.int64) - offsets[:-1][orf_id]) % 3
+    w = np.where(framed[orf_id], np.where(frame == 0, 2.0, 0.5), 1.0)
+    rate = lam[orf_id] * w
+    rng = np.random.default_rng(seed + 2)
+    counts = rng.poisson(rate).astype(np.int32)
+    return counts, offsets
+
+
+def synth_csr_device(n_orfs: int, seed: int = 20260213, cfg: str = "cfg2", device="cuda", chunk_orfs: int = 2_000_000):
+    """(counts int32, offsets int64) as device tensors; counts drawn by torch.poisson on the GPU."""
+    import torch
+
+    dev = torch.device(device)
+    lengths = orf_lengths(n_orfs, seed, cfg)
+    offsets_np = offsets_from_lengths(lengths)
+    lam_np, framed_np = orf_rates(n_orfs, seed)
+    total = int(offsets_np[-1])
+    counts = torch.empty(total, dtype=torch.int32, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed + 2)
+    for lo in range(0, n_orfs, chunk_orfs):
+        hi = min(n_orfs, lo + chunk_orfs)
+        ln = torch.from_numpy(lengths[lo:hi]).to(dev)
+        off = torch.from_numpy(offsets_np[lo:hi] - offsets_np[lo]).to(dev)
+        lam = torch.from_numpy(lam_np[lo:hi].astype(np.float32)).to(dev)
+        framed = torch.from_numpy(framed_np[lo:hi]).to(dev)
+        orf_id = torch.repeat_interleave(torch.arange(hi - lo, device=dev), ln)
+        pos = torch.arange(orf_id.numel(), device=dev) - off[orf_id]
+        w = torch.where(framed[orf_id], torch.where(pos % 3 == 0, 2.0, 0.5), 1.0)
+        rate = lam[orf_id] * w
+        a, b = int(offsets_np[lo]), int(offsets_np[hi])
+        counts[a:b] = torch.poisson(rate, generator=gen).to(torch.int32)
+        del ln, off, lam, framed, orf_id, pos, w, rate
+    offsets = torch.from_numpy(offsets_np).to(dev)
+    return counts, offsets

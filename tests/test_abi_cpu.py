@@ -1,0 +1,85 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol the header
+declares, and fails loudly (no fallback) when no HIP device is present.  No compute
+call is made here."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+from ribotricer_amd import _lib
+
+HEADER = os.path.join(REPO, "include", "ribophase.h")
+
+
+def header_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_is_built_in_tree():
+    assert os.path.exists(_lib.LIB_PATH), "run `make -C ribotricer_amd/csrc` (build() does)"
+    assert os.path.dirname(_lib.LIB_PATH).startswith(REPO)
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = header_symbols()
+    assert declared, "no rp_* declarations found in the header"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ribophase.h but not exported"
+    assert sorted(_lib.SYMBOLS) == declared, "Python binding table and header disagree"
+
+
+def test_version_and_status_strings():
+    assert _lib.version() == "0.1.0"
+    lib = _lib.load()
+    assert lib.rp_status_string(0) == b"ok"
+    assert lib.rp_status_string(-3) == b"bad CSR offsets"
+
+
+def test_filter_defaults_match_reference_constants():
+    fp = _lib.filter_defaults()
+    # ribotricer/const.py:20-39
+    assert fp.phase_score_cutoff == 0.428571428571
+    assert fp.min_valid_codons == 5
+    assert fp.min_reads_per_codon == 0 and fp.min_valid_codons_ratio == 0 and fp.min_density_over_orf == 0.0
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    lib = _lib.load()
+    assert lib.rp_workspace_bytes(1, 1, 0, None) == -1
+    out = ctypes.c_size_t()
+    assert lib.rp_workspace_bytes(-1, 1, 0, ctypes.byref(out)) == -2
+    assert lib.rp_workspace_bytes(1, 1, 99, ctypes.byref(out)) == -8
+    assert b"unknown algo" in lib.rp_last_error()
+    assert lib.rp_workspace_bytes(10, 3000, _lib.RP_ALGO_WAVE, ctypes.byref(out)) == 0 and out.value == 0
+    assert lib.rp_workspace_bytes(10, 3000, _lib.RP_ALGO_TILE, ctypes.byref(out)) == 0 and out.value > 0
+    assert lib.rp_device_count(None) == -1
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.RibophaseError) as e:
+        _lib.device_count()
+    assert e.value.status == -6
+    from ribotricer_amd import engine
+
+    with pytest.raises(_lib.RibophaseError):
+        engine.phase_score_csr([1, 0, 0], [0, 3])
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "ribotricer_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+                assert "phase_oracle" not in text, f

@@ -1,0 +1,247 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against
+  (a) outputs of the reference itself (tests/golden fixtures), and
+  (b) the C oracle on the same seeded bytes,
+for every kernel family.  Bars: phase score <= 1e-6 absolute (BASELINE.json
+north_star), integer outputs bit-exact; valid_codons bit-exact vs the reference on
+every ORF not flagged as an exact frame tie.
+"""
+
+import numpy as np
+import pytest
+
+from conftest import split_csr
+from helpers import INT32_MAX, assert_matches_fixture, assert_matches_oracle, reference_status
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+PHASE_TOL = 1e-6
+ALGOS = ["wave", "tile"]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from ribotricer_amd.engine import get_engine
+
+    return get_engine("cuda:0")
+
+
+def run(eng, counts, offsets, algo, thresholds=None):
+    import torch
+
+    res = eng.score(np.asarray(counts, np.int32), np.asarray(offsets, np.int64), thresholds=thresholds, algo=algo)
+    torch.cuda.synchronize()
+    return res.cpu_numpy()
+
+
+def csr_of(vectors):
+    lens = np.array([len(v) for v in vectors], np.int64)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    counts = np.concatenate([np.asarray(v, np.int32) for v in vectors]) if len(vectors) and offsets[-1] else np.zeros(0, np.int32)
+    return counts, offsets
+
+
+# ------------------------------------------------------------------ reference fixtures
+@pytest.mark.parametrize("algo", ALGOS)
+def test_known_answers(eng, g1, algo):
+    counts, offsets = csr_of([row["input"] for row in g1])
+    res = run(eng, counts, offsets, algo)
+    for i, row in enumerate(g1):
+        assert abs(res["phase"][i] - row["phase"]) <= PHASE_TOL, row["input"]
+        if not res["flags"][i] & 1:
+            assert res["valid"][i] == row["valid"], row["input"]
+    assert_matches_oracle(res, counts, offsets)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("name", ["g2", "g3", "g4"])
+def test_reference_fixtures(eng, request, name, algo):
+    g = request.getfixturevalue(name)
+    res = run(eng, g["counts"], g["offsets"], algo)
+    tie = assert_matches_fixture(res, g, PHASE_TOL)
+    assert tie.mean() < 0.05
+    assert_matches_oracle(res, g["counts"], g["offsets"])
+
+
+def test_float_profiles(eng, g5):
+    import torch
+
+    vecs = [np.asarray(r["input"], np.float64) for r in g5]
+    lens = np.array([len(v) for v in vecs])
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    phase, valid, flags = eng.score_float_profiles(np.concatenate(vecs), offsets)
+    torch.cuda.synchronize()
+    phase, valid, flags = phase.cpu().numpy(), valid.cpu().numpy(), flags.cpu().numpy()
+    for i, r in enumerate(g5):
+        assert abs(phase[i] - r["phase"]) <= 1e-9
+        if not flags[i] & 1:
+            assert valid[i] == r["valid"]
+
+
+def test_frame_diagnostics(eng, g2):
+    import torch
+
+    d = eng.frames(g2["counts"], g2["offsets"])
+    torch.cuda.synchronize()
+    o = c_oracle.phase_score_csr(g2["counts"], g2["offsets"])
+    assert np.array_equal(d.n.cpu().numpy(), o.frame_n)
+    assert np.array_equal(d.m.cpu().numpy(), o.frame_m)
+    s = d.score.cpu().numpy()
+    assert np.array_equal(np.isnan(s), np.isnan(o.frame_score))
+    ok = ~np.isnan(s)
+    assert np.abs(s - o.frame_score)[ok].max() <= 1e-12
+
+
+# ------------------------------------------------------------------ oracle on seeded synthetic data
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("cfg,n", [("cfg2", 30000), ("cfg3", 30000), ("cfg5", 20000)])
+def test_synthetic_vs_oracle(eng, algo, cfg, n):
+    from ribotricer_amd.synth import synth_csr_host
+
+    counts, offsets = synth_csr_host(n, seed=1234, cfg=cfg)
+    res = run(eng, counts, offsets, algo)
+    assert_matches_oracle(res, counts, offsets)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_sparse_coverage_many_ties(eng, algo):
+    rng = np.random.default_rng(5)
+    lens = 3 * rng.integers(20, 200, size=20000)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    counts = rng.poisson(0.01, size=int(offsets[-1])).astype(np.int32)
+    res = run(eng, counts, offsets, algo)
+    o = assert_matches_oracle(res, counts, offsets)
+    assert ((o.flags & 1) != 0).sum() > 20  # the set does exercise the tie rule
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_edge_cases(eng, algo):
+    vectors = [
+        [],
+        [7],
+        [0, 4],
+        [],
+        [1, 0, 0],
+        [0, 0, 0, 5],
+        [],
+        [5] + [0] * 299,
+        [1, 1, 1] * 5,
+        [3, 0, 0] * 30,
+        [2, 1, 0] * 10 + [4],
+        [],
+        [],
+    ]
+    counts, offsets = csr_of(vectors)
+    res = run(eng, counts, offsets, algo)
+    assert_matches_oracle(res, counts, offsets)
+    assert res["min_codon_cov"][0] == INT32_MAX and res["read_count"][0] == 0
+    assert res["min_codon_cov"][1] == 7 and res["read_count"][1] == 7 and res["valid"][1] == 0
+    assert res["phase"][7] == 0.0 and res["valid"][7] == 0  # reset by an empty later frame
+    assert res["phase"][8] == 0.0 and res["valid"][8] == 5  # all-equal codons: NaN never wins
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_empty_batches(eng, algo):
+    res = run(eng, np.zeros(0, np.int32), np.zeros(1, np.int64), algo)
+    assert res["phase"].size == 0
+    # only empty profiles
+    res = run(eng, np.zeros(0, np.int32), np.zeros(6, np.int64), algo)
+    assert np.all(res["phase"] == 0) and np.all(res["valid"] == 0) and np.all(res["min_codon_cov"] == INT32_MAX)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_ragged_long_tail(eng, algo):
+    """A few very long profiles between many short ones, lengths not multiples of 3."""
+    rng = np.random.default_rng(11)
+    lens = rng.integers(1, 400, size=3000)
+    lens[[5, 700, 701, 2999]] = [100003, 40000, 9000, 65537]
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    w = np.array([2.0, 0.5, 0.5])
+    counts = rng.poisson(0.4 * w[np.arange(offsets[-1]) % 3]).astype(np.int32)
+    res = run(eng, counts, offsets, algo)
+    assert_matches_oracle(res, counts, offsets)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_large_counts(eng, algo):
+    rng = np.random.default_rng(13)
+    lens = 3 * rng.integers(20, 100, size=500)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    counts = rng.integers(0, 3_000_000, size=int(offsets[-1])).astype(np.int32)
+    counts[rng.random(counts.size) < 0.5] = 0
+    res = run(eng, counts, offsets, algo)
+    assert_matches_oracle(res, counts, offsets)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_status_predicate(eng, algo):
+    from ribotricer_amd.engine import make_filter
+    from ribotricer_amd.synth import synth_csr_host
+
+    counts, offsets = synth_csr_host(20000, seed=77, cfg="cfg3")
+    lengths = np.diff(offsets)
+    for kw in (
+        dict(),
+        dict(phase_score_cutoff=0.3, min_valid_codons=8, min_reads_per_codon=1, min_valid_codons_ratio=0.75, min_density_over_orf=1.0),
+        dict(phase_score_cutoff=0.0, min_valid_codons=0),
+    ):
+        res = run(eng, counts, offsets, algo, thresholds=make_filter(**kw))
+        o = assert_matches_oracle(res, counts, offsets)
+        expect = reference_status(
+            res["phase"], o.valid, o.read_count, o.min_codon_cov, lengths,
+            cutoff=kw.get("phase_score_cutoff", 0.428571428571), min_valid=kw.get("min_valid_codons", 5),
+            min_reads=kw.get("min_reads_per_codon", 0), min_ratio=kw.get("min_valid_codons_ratio", 0),
+            min_density=kw.get("min_density_over_orf", 0.0),
+        )
+        assert np.array_equal(res["status"], expect)
+        assert 0 < res["status"].mean() < 1 or not kw
+
+
+def test_validate_rejects_bad_input(eng):
+    from ribotricer_amd._lib import RibophaseError
+
+    eng.validate(np.array([1, 0, 0, 2], np.int32), np.array([0, 3, 4], np.int64))
+    with pytest.raises(RibophaseError) as e:
+        eng.validate(np.array([1, 0, 0, 2], np.int32), np.array([0, 3, 2], np.int64))
+    assert e.value.status == -3
+    with pytest.raises(RibophaseError) as e:
+        eng.validate(np.array([1, -1, 0, 2], np.int32), np.array([0, 3, 4], np.int64))
+    assert e.value.status == -7
+
+
+# ------------------------------------------------------------------ size-independent properties at full size
+@pytest.mark.parametrize("algo", ALGOS)
+def test_full_size_properties(eng, algo):
+    """BASELINE config 2 (1 M ORFs): checksum of read counts, idempotence, permutation
+    invariance of per-ORF results, and shard-concat == whole."""
+    import torch
+
+    from ribotricer_amd.synth import synth_csr_device
+
+    counts, offsets = synth_csr_device(1_000_000, seed=20260213, cfg="cfg2", device="cuda:0")
+    a = eng.score(counts, offsets, algo=algo)
+    b = eng.score(counts, offsets, algo=algo)
+    torch.cuda.synchronize()
+    for x, y in zip(a[:5], b[:5]):
+        assert torch.equal(x, y), "two runs over the same bytes must agree bit for bit"
+    assert int(a.read_count.sum()) == int(counts.sum(dtype=torch.int64))
+    lengths = offsets[1:] - offsets[:-1]
+    assert bool((a.valid <= torch.clamp(lengths // 3, min=0)).all())
+    assert bool(((a.phase >= 0) & (a.phase <= 1.0 + 1e-6)).all())
+    # shard at an arbitrary ORF boundary: results must concatenate to the whole
+    cut = 412_345
+    o_cut = int(offsets[cut])
+    left = eng.score(counts[:o_cut], offsets[: cut + 1], algo=algo)
+    right = eng.score(counts[o_cut:].clone(), offsets[cut:] - o_cut, algo=algo)
+    torch.cuda.synchronize()
+    for whole, l, r in zip(a[:4], left[:4], right[:4]):
+        cat = torch.cat([l, r])
+        if whole.dtype == torch.float64:
+            assert float((whole - cat).abs().max()) <= 1e-9
+        else:
+            assert torch.equal(whole, cat)
+    # spot-check 20 000 ORFs of the full batch against the oracle
+    n_chk = 20000
+    o_end = int(offsets[n_chk])
+    res = {k: v[:n_chk].cpu().numpy() for k, v in a._asdict().items() if v is not None}
+    assert_matches_oracle(res, counts[:o_end].cpu().numpy(), offsets[: n_chk + 1].cpu().numpy())
