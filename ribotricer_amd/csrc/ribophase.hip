@@ -101,7 +101,7 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     }
     const rp::OrfOutputs out{d_phase, d_valid, d_read_count, d_min_codon_cov, d_flags, d_status};
     const rp::FilterParams fp = make_filter(filter, d_status);
-    if (algo == RP_ALGO_AUTO) algo = RP_ALGO_WAVE;
+    if (algo == RP_ALGO_AUTO) algo = RP_ALGO_TILE;
 
     if (algo == RP_ALGO_WAVE) {
         if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[1], stream));
@@ -124,8 +124,8 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
         return fail(RP_ERR_WORKSPACE, "workspace of %zu bytes required, got %zu", need, workspace_bytes);
     if ((reinterpret_cast<uintptr_t>(d_workspace) & 15u) != 0)
         return fail(RP_ERR_WORKSPACE, "workspace must be 16-byte aligned");
-    const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt);
-    rp::TileWorkspace ws = rp::carve_workspace(d_workspace, plan);
+    const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt, d_counts);
+    rp::TileWorkspace ws = rp::carve_workspace(d_workspace, total_nt);
 
     // 1. tile index: first ORF starting at or after each tile boundary
     {
@@ -145,7 +145,7 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     // 3. ORFs that straddle a tile boundary: combine partials
     {
         const int block = 256;
-        const int grid = (int)((plan.n_tiles + block - 1) / block);
+        const int grid = (int)((plan.n_tiles + (block / rp::kWave) - 1) / (block / rp::kWave));
         hipLaunchKernelGGL(rp::k_tile_finalize, dim3(grid), dim3(block), 0, stream, d_counts,
                            d_offsets, (long long)n_orfs, plan, ws, out, fp);
         RP_HIP(hipGetLastError());
@@ -215,7 +215,7 @@ int rp_workspace_bytes(int64_t n_orfs, int64_t total_nt, int algo, size_t *bytes
         *bytes = 0;
         return RP_OK;
     }
-    *bytes = rp::workspace_bytes(rp::make_tile_plan(n_orfs, total_nt));
+    *bytes = rp::workspace_bytes(total_nt);
     return RP_OK;
 }
 
