@@ -35,8 +35,9 @@ extern "C" {
 
 #define RP_VERSION_STRING "0.1.0"
 
-/* largest admissible P-site count per nucleotide (codon sums stay inside int32) */
-#define RP_MAX_COUNT 536870911 /* 2^29 - 1 */
+/* largest admissible P-site count per nucleotide (codon sums stay inside int32 and a
+ * lane's 27-position partial read count inside uint32) */
+#define RP_MAX_COUNT 67108863 /* 2^26 - 1: 27 counts still sum inside uint32 */
 
 /* value of min_codon_cov for an ORF with an empty profile (min over no codons;
  * numpy.all([]) is True in detect_orfs.py:288,293) */

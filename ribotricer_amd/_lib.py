@@ -22,7 +22,7 @@ FLAG_TIE = 0x01
 FLAG_RECHECK64 = 0x02
 FLAG_SPLIT = 0x04
 MIN_CODON_COV_EMPTY = 2147483647
-MAX_COUNT = 536870911
+MAX_COUNT = 67108863
 
 
 class RibophaseError(RuntimeError):

@@ -145,7 +145,7 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     // 3. ORFs that straddle a tile boundary: combine partials
     {
         const int block = 256;
-        const int grid = (int)((plan.n_tiles + (block / rp::kWave) - 1) / (block / rp::kWave));
+        const int grid = (int)((plan.n_tiles + block - 1) / block);
         hipLaunchKernelGGL(rp::k_tile_finalize, dim3(grid), dim3(block), 0, stream, d_counts,
                            d_offsets, (long long)n_orfs, plan, ws, out, fp);
         RP_HIP(hipGetLastError());

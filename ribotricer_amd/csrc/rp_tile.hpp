@@ -36,9 +36,9 @@ constexpr int kTile = 6144;     // positions per tile (24 KiB of int32)
 constexpr int kRun = 9;         // triplets per lane run; odd => lane stride 27 dwords, conflict free
 constexpr int kSegChunk = 64;   // segments set up per round (one per lane of wave 0)
 constexpr int kHalo = 8;        // dwords staged past the tile end (4 needed, 2 chunks loaded)
-constexpr int kLdsCounts = kTile + kHalo + 3 * kRun + 8;
+constexpr int kLdsCounts = kTile + kHalo + 3 * kRun + 8;  // runs may read (masked) past the halo
 constexpr int kLoadRounds = (kTile / 4 + kTileBlock - 1) / kTileBlock;  // dwordx4 chunks per thread
-constexpr int kMaxRecs = kSegChunk + 8;
+constexpr int kMaxRecs = kSegChunk + (kTile / (3 * kRun) + kSegChunk + 2 * 64) / 16 + 1;  // one per (segment, 16-lane row)
 
 enum SegKind : int { kSegComplete = 0, kSegHead = 1, kSegTail = 2 };
 
@@ -121,14 +121,15 @@ __global__ void k_tile_index(const int64_t *__restrict__ offsets, long long n_or
 // ---------------------------------------------------------------------------
 // pass 2: the scoring kernel
 // ---------------------------------------------------------------------------
-struct RunRec {  // what one wave contributes to one segment
+struct RunRec {  // what one 16-lane row contributes to one segment
     float p[3];
     float q[3];
     unsigned nn;  // n[0] | n[1] << 10 | n[2] << 20
     unsigned mm;
-    unsigned long long count;
-    int min_codon;
-    int pad;
+    unsigned clo;  // sum of the low / high 16-bit halves of the lane read counts
+    unsigned chi;
+    unsigned min_codon;
+    unsigned pad;
 };
 
 __device__ __forceinline__ void load_tile_to_lds(const int32_t *__restrict__ counts, long long t0,
@@ -161,13 +162,142 @@ __device__ __forceinline__ void load_tile_to_lds(const int32_t *__restrict__ cou
     }
 }
 
-// Hillis-Steele segmented inclusive scan over the wave; keys are non-decreasing in lane.
-template <typename T, typename Op>
-__device__ __forceinline__ T seg_scan_step(T x, int d, bool take, Op op)
+// --- DPP building blocks (gfx9 row_shr / row_bcast controls) ------------------------------
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_row(int src)
 {
-    const T up = __shfl_up(x, d, kWave);
-    return take ? op(x, up) : x;
+    // row_shr within the 16-lane row; lanes without a source read 0 (bound_ctrl)
+    return __builtin_amdgcn_update_dpp(0, src, CTRL, 0xf, 0xf, true);
 }
+
+struct ScanVals {
+    float p[3];
+    float q[3];
+    unsigned nn, mm, clo, chi, mn;
+};
+
+// One step of the segmented inclusive scan inside each 16-lane row: lanes whose DPP
+// source carries the same segment key (keys are >= 1) fold the source's running value
+// into their own.  Masking with all-ones / zero bits instead of a select keeps it at
+// (fetch, and, add) per value.
+template <int CTRL>
+__device__ __forceinline__ void seg_scan_step(ScanVals &v, int key)
+{
+    const int bits = (dpp_row<CTRL>(key) == key) ? -1 : 0;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        v.p[f] += __int_as_float(dpp_row<CTRL>(__float_as_int(v.p[f])) & bits);
+        v.q[f] += __int_as_float(dpp_row<CTRL>(__float_as_int(v.q[f])) & bits);
+    }
+    v.nn += (unsigned)(dpp_row<CTRL>((int)v.nn) & bits);
+    v.mm += (unsigned)(dpp_row<CTRL>((int)v.mm) & bits);
+    v.clo += (unsigned)(dpp_row<CTRL>((int)v.clo) & bits);
+    v.chi += (unsigned)(dpp_row<CTRL>((int)v.chi) & bits);
+    v.mn = min(v.mn, (unsigned)(dpp_row<CTRL>((int)v.mn) | ~bits));
+}
+
+__device__ __forceinline__ void seg_scan_rows(ScanVals &v, int key)
+{
+    seg_scan_step<kDppRowShr1>(v, key);
+    seg_scan_step<kDppRowShr2>(v, key);
+    seg_scan_step<kDppRowShr4>(v, key);
+    seg_scan_step<kDppRowShr8>(v, key);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_fetch(int old, int src)
+{
+    // lanes without a valid source (or outside ROW_MASK) keep `old`
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+
+// inclusive max-scan over the wave (unsegmented), values >= 0
+__device__ __forceinline__ int wave_max_scan(int x)
+{
+    x = max(x, dpp_row<kDppRowShr1>(x));
+    x = max(x, dpp_row<kDppRowShr2>(x));
+    x = max(x, dpp_row<kDppRowShr4>(x));
+    x = max(x, dpp_row<kDppRowShr8>(x));
+    x = max(x, dpp_fetch<kDppRowBcast15, 0xa>(0, x));
+    x = max(x, dpp_fetch<kDppRowBcast31, 0xc>(0, x));
+    return x;
+}
+
+// inclusive add-scan over the wave (unsegmented)
+__device__ __forceinline__ int wave_add_scan(int x)
+{
+    x += dpp_row<kDppRowShr1>(x);
+    x += dpp_row<kDppRowShr2>(x);
+    x += dpp_row<kDppRowShr4>(x);
+    x += dpp_row<kDppRowShr8>(x);
+    x += dpp_fetch<kDppRowBcast15, 0xa>(0, x);
+    x += dpp_fetch<kDppRowBcast31, 0xc>(0, x);
+    return x;
+}
+
+// The lane run: kRun triplets = 3*kRun codon starts read from 3*kRun + 2 consecutive LDS
+// dwords.  `lim` = number of leading codon starts that are real codons of this lane's ORF
+// and owned by this run.  Predicates are evaluated once per POSITION (is the count zero?
+// does it equal its successor?) and combined per codon on the scalar unit.
+__device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, ScanVals &o)
+{
+    // rolling window over positions c, c+1, c+2: value, "is zero", difference to the
+    // successor (int exact, then float), "equals successor", squared difference
+    int v0 = s[0], v1 = s[1];
+    bool z0 = (v0 == 0), z1 = (v1 == 0);
+    int d = v0 - v1;
+    bool e0 = (d == 0);
+    float df0 = (float)d;
+    float P[3] = {0.f, 0.f, 0.f}, Q[3] = {0.f, 0.f, 0.f};
+    int n[3] = {0, 0, 0}, m[3] = {0, 0, 0};
+    unsigned cnt = 0, mn = (unsigned)RP_MIN_CODON_COV_EMPTY;
+#pragma unroll
+    for (int c = 0; c < 3 * kRun; ++c) {
+        const int f = c % 3;
+        const int v2 = s[c + 2];
+        const bool z2 = (v2 == 0);
+        d = v1 - v2;
+        const bool e1 = (d == 0);
+        const float df1 = (float)d;
+        // the tiny addend keeps q > 0 for a == b == c, so 0 * rsq(q) is 0 instead of NaN;
+        // q >= 1 otherwise and is unchanged by it
+        const float sq1 = __builtin_fmaf(df1, df1, 1e-30f);
+        const bool valid = c < lim;
+        const bool nz = valid && !(z0 && z1 && z2);
+        const bool use = valid && !(e0 && e1);
+        const float qq = __builtin_fmaf(df0, df0 + df1, sq1);
+        const float r = valid ? __builtin_amdgcn_rsqf(qq) : 0.0f;
+        P[f] = __builtin_fmaf(df0, r, P[f]);
+        Q[f] = __builtin_fmaf(df1, r, Q[f]);
+        n[f] += nz ? 1 : 0;
+        m[f] += use ? 1 : 0;
+        if (f == 0) {
+            const unsigned codon = (unsigned)(v0 + v1 + v2);
+            cnt += valid ? codon : 0u;
+            mn = min(mn, valid ? codon : (unsigned)RP_MIN_CODON_COV_EMPTY);
+        }
+        v0 = v1;
+        v1 = v2;
+        z0 = z1;
+        z1 = z2;
+        e0 = e1;
+        df0 = df1;
+    }
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        o.p[f] = P[f];
+        o.q[f] = Q[f];
+    }
+    o.nn = (unsigned)n[0] | ((unsigned)n[1] << 10) | ((unsigned)n[2] << 20);
+    o.mm = (unsigned)m[0] | ((unsigned)m[1] << 10) | ((unsigned)m[2] << 20);
+    o.clo = cnt;
+    o.mn = mn;
+}
+
+constexpr int kMaxVl = kTile / (3 * kRun) + kSegChunk + 2 * kWave;  // virtual lanes per chunk (upper bound)
 
 __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__restrict__ counts,
                                                            const int64_t *__restrict__ offsets,
@@ -181,6 +311,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
     __shared__ int s_ntrip[kSegChunk];    // owned triplets
     __shared__ int s_kind[kSegChunk];
     __shared__ int s_vlstart[kSegChunk + 1];
+    __shared__ int s_owner[kMaxVl];       // segment+1 at the first lane of a segment / wave, else 0
     __shared__ RunRec s_rec[kMaxRecs];
     __shared__ int s_recheck[kSegChunk];
     __shared__ int s_n_recheck;
@@ -201,10 +332,11 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
     const int has_head = (a0 > 0 && (long long)offsets[a0] > t0) ? 1 : 0;
     const long long n_seg_total = has_head + (a1 - a0);
     if (tid == 0) s_n_recheck = 0;
-    __syncthreads();
 
     for (long long chunk = 0; chunk < n_seg_total; chunk += kSegChunk) {
         const int nseg = (int)((n_seg_total - chunk) < kSegChunk ? (n_seg_total - chunk) : kSegChunk);
+        for (int k = tid; k < kMaxVl; k += kTileBlock) s_owner[k] = 0;
+        __syncthreads();  // also orders the tile stores / the previous chunk's readers
 
         // ---- segment setup + lane allocation (wave 0) ---------------------------------
         if (wave == 0) {
@@ -229,15 +361,15 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
                 s_kind[lane] = (has_head && s == 0) ? kSegHead : (jhi == ntrip_all ? kSegComplete : kSegTail);
                 lanes = (int)((ntrip + kRun - 1) / kRun);
             }
-            // exclusive prefix sum of lanes over the wave
-            int incl = lanes;
-#pragma unroll
-            for (int d = 1; d < kWave; d <<= 1) {
-                const int up = __shfl_up(incl, d, kWave);
-                if (lane >= d) incl += up;
-            }
-            s_vlstart[lane] = incl - lanes;
+            const int incl = wave_add_scan(lanes);
+            const int vs = incl - lanes;
+            s_vlstart[lane] = vs;
             if (lane == kWave - 1) s_vlstart[kSegChunk] = incl;
+            if (lanes > 0) {
+                s_owner[vs] = lane + 1;
+                // every wave-pass must find its segment at its first lane
+                for (int w = (vs >> 6) + 1; (w << 6) < incl; ++w) s_owner[w << 6] = lane + 1;
+            }
         }
         __syncthreads();
         const int total_vl = s_vlstart[kSegChunk];
@@ -246,90 +378,48 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
         for (int vbase = wave * kWave; vbase < total_vl; vbase += kTileBlock) {
             const int vl = vbase + lane;
             const bool active = vl < total_vl;
-            // largest s with vlstart[s] <= vl  (zero-lane segments are skipped automatically)
-            int lo = 0, hi = nseg;
-#pragma unroll
-            for (int it = 0; it < 7; ++it) {  // range <= kSegChunk = 2^6: at most 7 halvings
-                if (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_vlstart[mid] <= vl)
-                        lo = mid + 1;
-                    else
-                        hi = mid;
-                }
-            }
-            int seg = lo - 1;
-            if (!active || seg < 0) seg = 0;
+            const int seg = wave_max_scan(s_owner[vl]) - 1;  // >= 0: lane 0 of the pass is marked
             const int r = vl - s_vlstart[seg];
             int n_run = s_ntrip[seg] - r * kRun;
             n_run = n_run > kRun ? kRun : n_run;
-            if (!active) n_run = 0;
-            const int endq = s_endq[seg];
-            int q = s_qfirst[seg] + 3 * kRun * r;
-            if (!active) q = 0;
+            const int q0 = active ? s_qfirst[seg] + 3 * kRun * r : 0;
+            const int rem0 = s_endq[seg] - q0;  // positions of the ORF from q0 on (clamped far end)
+            int lim = rem0 - 2 < 3 * n_run ? rem0 - 2 : 3 * n_run;
+            if (!active) lim = 0;
 
-            FrameAcc<float> acc[3];
-            acc_clear(acc);
-            unsigned long long cnt = 0;
-            int mn = RP_MIN_CODON_COV_EMPTY;
-            int v0 = s_counts[q];
-            int v1 = s_counts[q + 1];
-#pragma unroll
-            for (int i = 0; i < kRun; ++i) {
-                const int v2 = s_counts[q + 2];
-                const int v3 = s_counts[q + 3];
-                const int v4 = s_counts[q + 4];
-                const int rem = (i < n_run) ? endq - q : 0;  // positions left in the ORF from q
-                const int codon = (rem > 0 ? v0 : 0) + (rem > 1 ? v1 : 0) + (rem > 2 ? v2 : 0);
-                cnt += (unsigned)codon;
-                mn = rem > 0 ? min(mn, codon) : mn;
-                codon_add(acc[0], v0, v1, v2, rem > 2);
-                codon_add(acc[1], v1, v2, v3, rem > 3);
-                codon_add(acc[2], v2, v3, v4, rem > 4);
-                v0 = v3;
-                v1 = v4;
-                q += 3;
-            }
+            ScanVals sv;
+            lane_run(s_counts + q0, lim, sv);
 
-            // segmented inclusive scan keyed by segment (inactive lanes share a key past the end)
-            const int key = active ? seg : kSegChunk;
-            unsigned nn = (unsigned)acc[0].n | ((unsigned)acc[1].n << 10) | ((unsigned)acc[2].n << 20);
-            unsigned mm = (unsigned)acc[0].m | ((unsigned)acc[1].m << 10) | ((unsigned)acc[2].m << 20);
-            float p0 = acc[0].p, p1 = acc[1].p, p2 = acc[2].p;
-            float q0 = acc[0].q, q1 = acc[1].q, q2 = acc[2].q;
-#pragma unroll
-            for (int d = 1; d < kWave; d <<= 1) {
-                const int kup = __shfl_up(key, d, kWave);
-                const bool take = (lane >= d) && (kup == key);
-                auto addf = [](float a, float c) { return a + c; };
-                auto addu = [](unsigned a, unsigned c) { return a + c; };
-                auto addl = [](unsigned long long a, unsigned long long c) { return a + c; };
-                auto mini = [](int a, int c) { return a < c ? a : c; };
-                p0 = seg_scan_step(p0, d, take, addf);
-                p1 = seg_scan_step(p1, d, take, addf);
-                p2 = seg_scan_step(p2, d, take, addf);
-                q0 = seg_scan_step(q0, d, take, addf);
-                q1 = seg_scan_step(q1, d, take, addf);
-                q2 = seg_scan_step(q2, d, take, addf);
-                nn = seg_scan_step(nn, d, take, addu);
-                mm = seg_scan_step(mm, d, take, addu);
-                cnt = seg_scan_step(cnt, d, take, addl);
-                mn = seg_scan_step(mn, d, take, mini);
+            // partial last codon (L % 3 != 0): common.py:164-180 still sums it
+            const int ip = (rem0 % 3 != 0) ? rem0 / 3 : -1;
+            const bool has_partial = active && ip >= 0 && ip < n_run;
+            if (__any(has_partial)) {
+                if (has_partial) {
+                    unsigned codon = (unsigned)s_counts[q0 + 3 * ip];
+                    if (rem0 - 3 * ip == 2) codon += (unsigned)s_counts[q0 + 3 * ip + 1];
+                    sv.clo += codon;
+                    sv.mn = min(sv.mn, codon);
+                }
             }
-            const int key_next = __shfl_down(key, 1, kWave);
-            const bool run_end = active && (lane == kWave - 1 || key_next != key);
+            sv.chi = sv.clo >> 16;
+            sv.clo &= 0xffffu;
+
+            const int key = active ? seg + 1 : kSegChunk + 1;
+            seg_scan_rows(sv, key);
+            const int key_next = dpp_fetch<0x101 /* row_shl:1 */, 0xf>(0, key);  // 0 at the row's last lane
+            const bool run_end = active && (key_next != key);
             if (run_end) {
-                RunRec &rec = s_rec[seg + (vbase >> 6)];
-                rec.p[0] = p0;
-                rec.p[1] = p1;
-                rec.p[2] = p2;
-                rec.q[0] = q0;
-                rec.q[1] = q1;
-                rec.q[2] = q2;
-                rec.nn = nn;
-                rec.mm = mm;
-                rec.count = cnt;
-                rec.min_codon = mn;
+                RunRec &rec = s_rec[seg + (vl >> 4)];
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    rec.p[f] = sv.p[f];
+                    rec.q[f] = sv.q[f];
+                }
+                rec.nn = sv.nn;
+                rec.mm = sv.mm;
+                rec.clo = sv.clo;
+                rec.chi = sv.chi;
+                rec.min_codon = sv.mn;
             }
         }
         __syncthreads();
@@ -352,8 +442,8 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
             t.min_codon = RP_MIN_CODON_COV_EMPTY;
             t.pad = 0;
             if (ve > vs) {
-                const int w_first = vs >> 6;
-                const int w_last = (ve - 1) >> 6;
+                const int w_first = vs >> 4;
+                const int w_last = (ve - 1) >> 4;
                 for (int w = w_first; w <= w_last; ++w) {
                     const RunRec &rec = s_rec[seg + w];
 #pragma unroll
@@ -363,8 +453,8 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
                         t.n[f] += (int)((rec.nn >> (10 * f)) & 1023u);
                         t.m[f] += (int)((rec.mm >> (10 * f)) & 1023u);
                     }
-                    t.count += (long long)rec.count;
-                    t.min_codon = min(t.min_codon, rec.min_codon);
+                    t.count += (long long)rec.clo + ((long long)rec.chi << 16);
+                    t.min_codon = min(t.min_codon, (int)rec.min_codon);
                 }
             }
             const int kind = s_kind[seg];
@@ -391,33 +481,34 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
 
         // ---- float64 re-walk of the too-close-to-call ORFs, one wave each -----------------
         const int n_re = s_n_recheck;
-        for (int k = wave; k < n_re; k += kTileBlock / kWave) {
-            const long long orf = a0 - has_head + chunk + s_recheck[k];
-            const long long beg = offsets[orf];
-            const long long len = (long long)offsets[orf + 1] - beg;
-            WalkResult<double> w;
-            wave_walk<double>(counts + beg, len, lane, w);
-            FrameScore fr[3];
-            long long count;
-            int min_codon;
-            wave_reduce_frames(w, fr, count, min_codon);
-            double phase;
-            int valid;
-            unsigned flags;
-            combine_frames(fr, phase, valid, flags);
-            if (lane == 0)
-                store_orf(out, fp, orf, phase, valid, count, min_codon, flags | RP_FLAG_RECHECK64, len);
+        if (n_re > 0) {
+            for (int k = wave; k < n_re; k += kTileBlock / kWave) {
+                const long long orf = a0 - has_head + chunk + s_recheck[k];
+                const long long beg = offsets[orf];
+                const long long len = (long long)offsets[orf + 1] - beg;
+                WalkResult<double> w;
+                wave_walk<double>(counts + beg, len, lane, w);
+                FrameScore fr[3];
+                long long count;
+                int min_codon;
+                wave_reduce_frames(w, fr, count, min_codon);
+                double phase;
+                int valid;
+                unsigned flags;
+                combine_frames(fr, phase, valid, flags);
+                if (lane == 0)
+                    store_orf(out, fp, orf, phase, valid, count, min_codon, flags | RP_FLAG_RECHECK64, len);
+            }
+            __syncthreads();
+            if (tid == 0) s_n_recheck = 0;
         }
-        __syncthreads();
-        if (tid == 0) s_n_recheck = 0;
-        __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------
-// pass 3: ORFs that straddle a tile boundary -- one wave per tile whose last ORF
-// does not end inside it; sums the tail partial of that tile and the head partials
-// of the tiles the ORF runs through.
+// pass 3: ORFs that straddle a tile boundary -- one LANE per tile whose last ORF does
+// not end inside it; sums the tail partial of that tile and the head partials of the
+// tiles the ORF runs through.  Too-close-to-call ORFs are re-walked by the whole wave.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kTileBlock) void k_tile_finalize(const int32_t *__restrict__ counts,
                                                               const int64_t *__restrict__ offsets,
@@ -426,56 +517,76 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_finalize(const int32_t *__r
                                                               FilterParams fp)
 {
     const int lane = threadIdx.x & (kWave - 1);
-    const long long b = (long long)blockIdx.x * (kTileBlock / kWave) + (threadIdx.x >> 6);
-    if (b >= plan.n_tiles) return;
-    const long long a0 = ws.tile_first[b];
-    const long long a1 = ws.tile_first[b + 1];
-    if (a1 <= a0) return;  // no ORF starts in this tile
-    const long long orf = a1 - 1;
-    const long long beg = offsets[orf];
-    const long long len = (long long)offsets[orf + 1] - beg;
-    const long long ntrip_all = (len + 2) / 3;
-    if (ntrip_all == 0) return;
-    long long t1 = (b + 1) * (long long)kTile - plan.mis;
-    if (t1 > plan.total_nt) t1 = plan.total_nt;
-    const long long last_first = beg + 3 * (ntrip_all - 1);  // first position of the last triplet
-    if (last_first < t1) return;                             // the ORF was finished inside its tile
-    const long long b_end = (last_first + plan.mis) / kTile;
-
-    double p[3] = {0, 0, 0}, q[3] = {0, 0, 0};
-    int n[3] = {0, 0, 0}, m[3] = {0, 0, 0};
-    long long count = 0;
-    int min_codon = RP_MIN_CODON_COV_EMPTY;
-    for (long long k = lane; k <= b_end - b; k += kWave) {
-        const TilePartial &t = (k == 0) ? ws.partials[2 * b + 1] : ws.partials[2 * (b + k)];
-#pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            p[f] += t.p[f];
-            q[f] += t.q[f];
-            n[f] += t.n[f];
-            m[f] += t.m[f];
+    const long long b = (long long)blockIdx.x * kTileBlock + threadIdx.x;
+    bool work = false;
+    long long orf = 0, beg = 0, len = 0, b_end = 0;
+    if (b < plan.n_tiles) {
+        const long long a0 = ws.tile_first[b];
+        const long long a1 = ws.tile_first[b + 1];
+        if (a1 > a0) {  // some ORF starts in this tile; only the last one can leave it
+            orf = a1 - 1;
+            beg = offsets[orf];
+            len = (long long)offsets[orf + 1] - beg;
+            const long long ntrip_all = (len + 2) / 3;
+            long long t1 = (b + 1) * (long long)kTile - plan.mis;
+            if (t1 > plan.total_nt) t1 = plan.total_nt;
+            const long long last_first = beg + 3 * (ntrip_all - 1);  // first position of the last triplet
+            if (ntrip_all > 0 && last_first >= t1) {
+                work = true;
+                b_end = (last_first + plan.mis) / kTile;
+            }
         }
-        count += t.count;
-        min_codon = min(min_codon, t.min_codon);
     }
     FrameScore fr[3];
+    long long count = 0;
+    int min_codon = RP_MIN_CODON_COV_EMPTY;
+    bool unsafe = false;
+    if (work) {
+        double p[3] = {0, 0, 0}, q[3] = {0, 0, 0};
+        int n[3] = {0, 0, 0}, m[3] = {0, 0, 0};
+        for (long long k = 0; k <= b_end - b; ++k) {
+            const TilePartial &t = (k == 0) ? ws.partials[2 * b + 1] : ws.partials[2 * (b + k)];
 #pragma unroll
-    for (int f = 0; f < 3; ++f)
-        fr[f] = frame_score(wave_sum(p[f]), wave_sum(q[f]), wave_sum(n[f]), wave_sum(m[f]));
-    count = wave_sum(count);
-    min_codon = wave_min(min_codon);
-    unsigned extra = RP_FLAG_SPLIT;
-    if (fp32_decision_unsafe(fr)) {  // wave-uniform
-        WalkResult<double> w;
-        wave_walk<double>(counts + beg, len, lane, w);
-        wave_reduce_frames(w, fr, count, min_codon);
-        extra |= RP_FLAG_RECHECK64;
+            for (int f = 0; f < 3; ++f) {
+                p[f] += t.p[f];
+                q[f] += t.q[f];
+                n[f] += t.n[f];
+                m[f] += t.m[f];
+            }
+            count += t.count;
+            min_codon = min(min_codon, t.min_codon);
+        }
+#pragma unroll
+        for (int f = 0; f < 3; ++f) fr[f] = frame_score(p[f], q[f], n[f], m[f]);
+        unsafe = fp32_decision_unsafe(fr);
+        if (!unsafe) {
+            double phase;
+            int valid;
+            unsigned flags;
+            combine_frames(fr, phase, valid, flags);
+            store_orf(out, fp, orf, phase, valid, count, min_codon, flags | RP_FLAG_SPLIT, len);
+        }
     }
-    double phase;
-    int valid;
-    unsigned flags;
-    combine_frames(fr, phase, valid, flags);
-    if (lane == 0) store_orf(out, fp, orf, phase, valid, count, min_codon, flags | extra, len);
+    unsigned long long todo = __ballot(unsafe);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const long long orf_s = __shfl(orf, src, kWave);
+        const long long beg_s = __shfl(beg, src, kWave);
+        const long long len_s = __shfl(len, src, kWave);
+        WalkResult<double> w;
+        wave_walk<double>(counts + beg_s, len_s, lane, w);
+        FrameScore fr2[3];
+        long long count2;
+        int min2;
+        wave_reduce_frames(w, fr2, count2, min2);
+        double phase;
+        int valid;
+        unsigned flags;
+        combine_frames(fr2, phase, valid, flags);
+        if (lane == 0)
+            store_orf(out, fp, orf_s, phase, valid, count2, min2, flags | RP_FLAG_SPLIT | RP_FLAG_RECHECK64, len_s);
+    }
 }
 
 }  // namespace rp

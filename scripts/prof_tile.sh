@@ -1,0 +1,34 @@
+#!/bin/bash
+# rocprofv3 kernel-trace stats + two PMC passes of the bench command (run on the GPU box).
+# usage: bash scripts/prof_tile.sh <tag> [bench args...]
+TAG=${1:-r01}; shift
+ARGS=${@:---algo tile}
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+OUT=$R/gpurun_out/prof_$TAG
+W=/tmp/prof_$TAG
+rm -rf $W; mkdir -p $W $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $W/stats -o stats -- python3 bench.py $ARGS --steps 20 --warmup 3 --cpu-sample 0 > $OUT/stats_bench.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $W/pmc1 -o pmc1 -- python3 bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 > $OUT/pmc1_bench.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $W/pmc2 -o pmc2 -- python3 bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 > $OUT/pmc2_bench.log 2>&1
+find $W -name "*.csv" | while read f; do echo "$f $(wc -c < $f)"; done
+cp $(find $W/stats -name "*kernel_stats.csv") $OUT/kernel_stats.csv 2>/dev/null
+# per-kernel mean of every counter (counter_collection csv is one row per dispatch x counter)
+python3 - "$W" "$OUT" <<'PY'
+import csv, glob, sys, collections
+W, OUT = sys.argv[1], sys.argv[2]
+for tag in ("pmc1", "pmc2"):
+    files = glob.glob(f"{W}/{tag}/**/*counter_collection.csv", recursive=True)
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            k = (row.get("Kernel_Name", "?")[:60], row.get("Counter_Name", "?"))
+            acc[k][0] += float(row.get("Counter_Value", 0)); acc[k][1] += 1
+    with open(f"{OUT}/{tag}_summary.csv", "w") as fh:
+        fh.write("kernel,counter,mean_per_dispatch,dispatches\n")
+        for (k, c), (s, n) in sorted(acc.items()):
+            fh.write(f"\"{k}\",{c},{s/n:.1f},{n}\n")
+PY
+head -12 $OUT/kernel_stats.csv
+grep -E "k_tile|k_wave" $OUT/pmc1_summary.csv $OUT/pmc2_summary.csv
