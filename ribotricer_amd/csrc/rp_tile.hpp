@@ -32,8 +32,8 @@
 namespace rp {
 
 constexpr int kTileBlock = 256;
-constexpr int kTile = 6144;     // positions per tile (24 KiB of int32)
-constexpr int kRun = 9;         // triplets per lane run; odd => lane stride 27 dwords, conflict free
+constexpr int kTile = 8192;    // positions per tile (40 KiB of int32)
+constexpr int kRun = 15;        // triplets per lane run; odd => lane stride 45 dwords, conflict free
 constexpr int kSegChunk = 64;   // segments set up per round (one per lane of wave 0)
 constexpr int kHalo = 8;        // dwords staged past the tile end (4 needed, 2 chunks loaded)
 constexpr int kLdsCounts = kTile + kHalo + 3 * kRun + 8;  // runs may read (masked) past the halo
@@ -121,44 +121,59 @@ __global__ void k_tile_index(const int64_t *__restrict__ offsets, long long n_or
 // ---------------------------------------------------------------------------
 // pass 2: the scoring kernel
 // ---------------------------------------------------------------------------
-struct RunRec {  // what one 16-lane row contributes to one segment
+struct alignas(16) RunRec {  // float sums one 16-lane row contributes to one segment
     float p[3];
     float q[3];
-    unsigned nn;  // n[0] | n[1] << 10 | n[2] << 20
-    unsigned mm;
-    unsigned clo;  // sum of the low / high 16-bit halves of the lane read counts
-    unsigned chi;
+    float pad[2];
+};
+
+// integer sums of one segment, accumulated with LDS atomics (order independent, exact)
+struct SegInts {
+    unsigned long long nn;     // n[0] | n[1] << 21 | n[2] << 42
+    unsigned long long mm;     // same packing
+    unsigned long long count;  // read count
     unsigned min_codon;
     unsigned pad;
 };
 
+// Stage positions [t0, t0 + kTile + kHalo) into LDS.  (counts + t0) is 16-byte aligned.
+// Interior tiles use the LDS-DMA form of global_load (no VGPR round trip, one instruction
+// per KiB per wave); the first / last tile take the guarded path with zero fill.
 __device__ __forceinline__ void load_tile_to_lds(const int32_t *__restrict__ counts, long long t0,
                                                  long long total_nt, int *s_counts, int tid)
 {
-    // chunk c covers LDS dwords [4c, 4c+4) = positions t0 + 4c ..; (counts + t0) is 16-byte aligned
-    constexpr int n_chunks = (kTile + kHalo) / 4;
-    int4 regs[kLoadRounds + 1];
+    constexpr int n_chunks = (kTile + kHalo) / 4;  // 16-byte chunks
+    static_assert(kTile % (4 * kTileBlock) == 0, "tile must be a whole number of 256 x 16 B rounds");
+    static_assert(kHalo == 8, "halo is loaded as two extra chunks");
+    const bool interior = (t0 >= 0) && (t0 + kTile + kHalo <= total_nt);  // workgroup-uniform
+    if (interior) {
+        typedef const __attribute__((address_space(1))) void *gptr_t;
+        typedef __attribute__((address_space(3))) void *lptr_t;
+        const int32_t *src = counts + t0 + 4 * tid;
+        const int wave_base = (tid & ~(kWave - 1)) * 4;  // LDS dword index of this wave's lane 0
 #pragma unroll
-    for (int k = 0; k <= kLoadRounds; ++k) {
-        const int c = tid + k * kTileBlock;
-        const long long pos = t0 + 4LL * c;
-        int4 v = make_int4(0, 0, 0, 0);
-        if (c < n_chunks) {
-            if (pos >= 0 && pos + 4 <= total_nt) {
-                v = *reinterpret_cast<const int4 *>(counts + pos);
-            } else {
-                if (pos + 0 >= 0 && pos + 0 < total_nt) v.x = counts[pos + 0];
-                if (pos + 1 >= 0 && pos + 1 < total_nt) v.y = counts[pos + 1];
-                if (pos + 2 >= 0 && pos + 2 < total_nt) v.z = counts[pos + 2];
-                if (pos + 3 >= 0 && pos + 3 < total_nt) v.w = counts[pos + 3];
+        for (int k = 0; k < kLoadRounds; ++k) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 4 * kTileBlock),
+                                             (lptr_t)(s_counts + k * 4 * kTileBlock + wave_base), 16, 0, 0);
+        }
+        if (tid < kWave) {  // halo: 2 chunks, lanes 0-1 of wave 0 (the DMA writes lane*16 past the base)
+            if (tid < n_chunks - kLoadRounds * kTileBlock) {
+                const int4 v = *reinterpret_cast<const int4 *>(counts + t0 + kTile + 4 * tid);
+                *reinterpret_cast<int4 *>(s_counts + kTile + 4 * tid) = v;
             }
         }
-        regs[k] = v;
-    }
-#pragma unroll
-    for (int k = 0; k <= kLoadRounds; ++k) {
-        const int c = tid + k * kTileBlock;
-        if (c < n_chunks) *reinterpret_cast<int4 *>(s_counts + 4 * c) = regs[k];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA is tracked by vmcnt only
+    } else {
+#pragma unroll 1
+        for (int c = tid; c < n_chunks; c += kTileBlock) {
+            const long long pos = t0 + 4LL * c;
+            int4 v = make_int4(0, 0, 0, 0);
+            if (pos + 0 >= 0 && pos + 0 < total_nt) v.x = counts[pos + 0];
+            if (pos + 1 >= 0 && pos + 1 < total_nt) v.y = counts[pos + 1];
+            if (pos + 2 >= 0 && pos + 2 < total_nt) v.z = counts[pos + 2];
+            if (pos + 3 >= 0 && pos + 3 < total_nt) v.w = counts[pos + 3];
+            *reinterpret_cast<int4 *>(s_counts + 4 * c) = v;
+        }
     }
 }
 
@@ -173,10 +188,12 @@ __device__ __forceinline__ int dpp_row(int src)
     return __builtin_amdgcn_update_dpp(0, src, CTRL, 0xf, 0xf, true);
 }
 
-struct ScanVals {
+struct LaneSums {
     float p[3];
     float q[3];
-    unsigned nn, mm, clo, chi, mn;
+    unsigned nn, mm;  // n[0] | n[1] << 10 | n[2] << 20 (per lane: <= kRun each)
+    unsigned count;   // <= 3 * kRun * RP_MAX_COUNT < 2^32
+    unsigned mn;
 };
 
 // One step of the segmented inclusive scan inside each 16-lane row: lanes whose DPP
@@ -184,7 +201,7 @@ struct ScanVals {
 // into their own.  Masking with all-ones / zero bits instead of a select keeps it at
 // (fetch, and, add) per value.
 template <int CTRL>
-__device__ __forceinline__ void seg_scan_step(ScanVals &v, int key)
+__device__ __forceinline__ void seg_scan_step(LaneSums &v, int key)
 {
     const int bits = (dpp_row<CTRL>(key) == key) ? -1 : 0;
 #pragma unroll
@@ -192,14 +209,9 @@ __device__ __forceinline__ void seg_scan_step(ScanVals &v, int key)
         v.p[f] += __int_as_float(dpp_row<CTRL>(__float_as_int(v.p[f])) & bits);
         v.q[f] += __int_as_float(dpp_row<CTRL>(__float_as_int(v.q[f])) & bits);
     }
-    v.nn += (unsigned)(dpp_row<CTRL>((int)v.nn) & bits);
-    v.mm += (unsigned)(dpp_row<CTRL>((int)v.mm) & bits);
-    v.clo += (unsigned)(dpp_row<CTRL>((int)v.clo) & bits);
-    v.chi += (unsigned)(dpp_row<CTRL>((int)v.chi) & bits);
-    v.mn = min(v.mn, (unsigned)(dpp_row<CTRL>((int)v.mn) | ~bits));
 }
 
-__device__ __forceinline__ void seg_scan_rows(ScanVals &v, int key)
+__device__ __forceinline__ void seg_scan_rows(LaneSums &v, int key)
 {
     seg_scan_step<kDppRowShr1>(v, key);
     seg_scan_step<kDppRowShr2>(v, key);
@@ -242,49 +254,51 @@ __device__ __forceinline__ int wave_add_scan(int x)
 // dwords.  `lim` = number of leading codon starts that are real codons of this lane's ORF
 // and owned by this run.  Predicates are evaluated once per POSITION (is the count zero?
 // does it equal its successor?) and combined per codon on the scalar unit.
-__device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, ScanVals &o)
+constexpr int kRunBlock = 3;  // triplets per fully unrolled block of the lane run
+static_assert(kRun % kRunBlock == 0, "kRun must be a multiple of kRunBlock");
+
+__device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, LaneSums &o)
 {
-    // rolling window over positions c, c+1, c+2: value, "is zero", difference to the
-    // successor (int exact, then float), "equals successor", squared difference
+    // rolling window over positions c, c+1, c+2: value, difference to the successor (int
+    // exact, then float) and "equals successor"
     int v0 = s[0], v1 = s[1];
-    bool z0 = (v0 == 0), z1 = (v1 == 0);
     int d = v0 - v1;
     bool e0 = (d == 0);
     float df0 = (float)d;
     float P[3] = {0.f, 0.f, 0.f}, Q[3] = {0.f, 0.f, 0.f};
     int n[3] = {0, 0, 0}, m[3] = {0, 0, 0};
     unsigned cnt = 0, mn = (unsigned)RP_MIN_CODON_COV_EMPTY;
+#pragma unroll 1
+    for (int blk = 0; blk < kRun / kRunBlock; ++blk) {
 #pragma unroll
-    for (int c = 0; c < 3 * kRun; ++c) {
-        const int f = c % 3;
-        const int v2 = s[c + 2];
-        const bool z2 = (v2 == 0);
-        d = v1 - v2;
-        const bool e1 = (d == 0);
-        const float df1 = (float)d;
-        // the tiny addend keeps q > 0 for a == b == c, so 0 * rsq(q) is 0 instead of NaN;
-        // q >= 1 otherwise and is unchanged by it
-        const float sq1 = __builtin_fmaf(df1, df1, 1e-30f);
-        const bool valid = c < lim;
-        const bool nz = valid && !(z0 && z1 && z2);
-        const bool use = valid && !(e0 && e1);
-        const float qq = __builtin_fmaf(df0, df0 + df1, sq1);
-        const float r = valid ? __builtin_amdgcn_rsqf(qq) : 0.0f;
-        P[f] = __builtin_fmaf(df0, r, P[f]);
-        Q[f] = __builtin_fmaf(df1, r, Q[f]);
-        n[f] += nz ? 1 : 0;
-        m[f] += use ? 1 : 0;
-        if (f == 0) {
-            const unsigned codon = (unsigned)(v0 + v1 + v2);
-            cnt += valid ? codon : 0u;
-            mn = min(mn, valid ? codon : (unsigned)RP_MIN_CODON_COV_EMPTY);
+        for (int c = 0; c < 3 * kRunBlock; ++c) {
+            const int f = c % 3;
+            const int v2 = s[c + 2];
+            const bool valid = c < lim;
+            d = v1 - v2;
+            const bool e1 = (d == 0);
+            const float df1 = (float)d;
+            // the tiny addend keeps q > 0 for a == b == c, so 0 * rsq(q) is 0 instead of
+            // NaN; q >= 1 otherwise and is unchanged by it
+            const float sq1 = __builtin_fmaf(df1, df1, 1e-30f);
+            const float qq = __builtin_fmaf(df0, df0 + df1, sq1);
+            const float r = valid ? __builtin_amdgcn_rsqf(qq) : 0.0f;
+            P[f] = __builtin_fmaf(df0, r, P[f]);
+            Q[f] = __builtin_fmaf(df1, r, Q[f]);
+            n[f] += (valid && ((v0 | v1 | v2) != 0)) ? 1 : 0;
+            m[f] += (valid && !(e0 && e1)) ? 1 : 0;
+            if (f == 0) {
+                const unsigned codon = (unsigned)(v0 + v1 + v2);
+                cnt += valid ? codon : 0u;
+                mn = min(mn, valid ? codon : (unsigned)RP_MIN_CODON_COV_EMPTY);
+            }
+            v0 = v1;
+            v1 = v2;
+            e0 = e1;
+            df0 = df1;
         }
-        v0 = v1;
-        v1 = v2;
-        z0 = z1;
-        z1 = z2;
-        e0 = e1;
-        df0 = df1;
+        s += 3 * kRunBlock;
+        lim -= 3 * kRunBlock;
     }
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
@@ -293,7 +307,7 @@ __device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, Sca
     }
     o.nn = (unsigned)n[0] | ((unsigned)n[1] << 10) | ((unsigned)n[2] << 20);
     o.mm = (unsigned)m[0] | ((unsigned)m[1] << 10) | ((unsigned)m[2] << 20);
-    o.clo = cnt;
+    o.count = cnt;
     o.mn = mn;
 }
 
@@ -313,6 +327,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
     __shared__ int s_vlstart[kSegChunk + 1];
     __shared__ int s_owner[kMaxVl];       // segment+1 at the first lane of a segment / wave, else 0
     __shared__ RunRec s_rec[kMaxRecs];
+    __shared__ SegInts s_ints[kSegChunk];
     __shared__ int s_recheck[kSegChunk];
     __shared__ int s_n_recheck;
 
@@ -336,6 +351,12 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
     for (long long chunk = 0; chunk < n_seg_total; chunk += kSegChunk) {
         const int nseg = (int)((n_seg_total - chunk) < kSegChunk ? (n_seg_total - chunk) : kSegChunk);
         for (int k = tid; k < kMaxVl; k += kTileBlock) s_owner[k] = 0;
+        if (tid < kSegChunk) {
+            s_ints[tid].nn = 0;
+            s_ints[tid].mm = 0;
+            s_ints[tid].count = 0;
+            s_ints[tid].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
+        }
         __syncthreads();  // also orders the tile stores / the previous chunk's readers
 
         // ---- segment setup + lane allocation (wave 0) ---------------------------------
@@ -346,20 +367,28 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
                 const long long orf = a0 - has_head + s;
                 const long long beg = offsets[orf];
                 const long long end = offsets[orf + 1];
-                const long long len = end - beg;
-                const long long rel0 = t0 - beg;  // > 0 only for the head segment
-                const long long jlo = rel0 > 0 ? (rel0 + 2) / 3 : 0;
-                const long long ntrip_all = (len + 2) / 3;
-                long long jhi = (t1 - beg + 2) / 3;  // triplets whose first position is < t1
-                if (jhi > ntrip_all) jhi = ntrip_all;
-                const long long ntrip = jhi > jlo ? jhi - jlo : 0;
-                long long endq = end - t0;
-                if (endq > kTile + kHalo) endq = kTile + kHalo;
-                s_qfirst[lane] = (int)(beg + 3 * jlo - t0);
-                s_endq[lane] = (int)endq;
-                s_ntrip[lane] = (int)ntrip;
-                s_kind[lane] = (has_head && s == 0) ? kSegHead : (jhi == ntrip_all ? kSegComplete : kSegTail);
-                lanes = (int)((ntrip + kRun - 1) / kRun);
+                const bool head = has_head && s == 0;
+                const int kt = (int)(t1 - t0);  // tile length in positions (<= kTile)
+                int qfirst;                     // LDS index of the first triplet start >= tile start
+                if (head) {
+                    const unsigned long long rel0 = (unsigned long long)(t0 - beg);  // > 0
+                    // 2^32 == 1 (mod 3)
+                    const unsigned m3 = ((unsigned)(rel0 >> 32) % 3u + (unsigned)(rel0 & 0xffffffffu) % 3u) % 3u;
+                    qfirst = m3 == 0 ? 0 : 3 - (int)m3;
+                } else {
+                    qfirst = (int)(beg - t0);
+                }
+                const long long rem = end - t0;  // >= 0
+                const bool end_in_lds = rem <= kTile + kHalo;
+                const int endq = end_in_lds ? (int)rem : kTile + kHalo;
+                const int lim_q = kt < endq ? kt : endq;  // owned triplets start below this
+                const int ntrip = lim_q > qfirst ? (lim_q - qfirst + 2) / 3 : 0;
+                const bool complete = !head && end_in_lds && ntrip == (endq - qfirst + 2) / 3;
+                s_qfirst[lane] = qfirst;
+                s_endq[lane] = endq;
+                s_ntrip[lane] = ntrip;
+                s_kind[lane] = head ? kSegHead : (complete ? kSegComplete : kSegTail);
+                lanes = (ntrip + kRun - 1) / kRun;
             }
             const int incl = wave_add_scan(lanes);
             const int vs = incl - lanes;
@@ -387,7 +416,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
             int lim = rem0 - 2 < 3 * n_run ? rem0 - 2 : 3 * n_run;
             if (!active) lim = 0;
 
-            ScanVals sv;
+            LaneSums sv;
             lane_run(s_counts + q0, lim, sv);
 
             // partial last codon (L % 3 != 0): common.py:164-180 still sums it
@@ -397,13 +426,25 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
                 if (has_partial) {
                     unsigned codon = (unsigned)s_counts[q0 + 3 * ip];
                     if (rem0 - 3 * ip == 2) codon += (unsigned)s_counts[q0 + 3 * ip + 1];
-                    sv.clo += codon;
+                    sv.count += codon;
                     sv.mn = min(sv.mn, codon);
                 }
             }
-            sv.chi = sv.clo >> 16;
-            sv.clo &= 0xffffu;
-
+            // integer sums: exact and order independent -> LDS atomics straight per segment
+            if (active) {
+                SegInts &acc = s_ints[seg];
+                const unsigned long long nn64 = (unsigned long long)(sv.nn & 1023u) |
+                                                ((unsigned long long)((sv.nn >> 10) & 1023u) << 21) |
+                                                ((unsigned long long)((sv.nn >> 20) & 1023u) << 42);
+                const unsigned long long mm64 = (unsigned long long)(sv.mm & 1023u) |
+                                                ((unsigned long long)((sv.mm >> 10) & 1023u) << 21) |
+                                                ((unsigned long long)((sv.mm >> 20) & 1023u) << 42);
+                atomicAdd(&acc.nn, nn64);
+                atomicAdd(&acc.mm, mm64);
+                atomicAdd(&acc.count, (unsigned long long)sv.count);
+                atomicMin(&acc.min_codon, sv.mn);
+            }
+            // float sums: deterministic segmented scan inside each 16-lane row
             const int key = active ? seg + 1 : kSegChunk + 1;
             seg_scan_rows(sv, key);
             const int key_next = dpp_fetch<0x101 /* row_shl:1 */, 0xf>(0, key);  // 0 at the row's last lane
@@ -415,11 +456,6 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
                     rec.p[f] = sv.p[f];
                     rec.q[f] = sv.q[f];
                 }
-                rec.nn = sv.nn;
-                rec.mm = sv.mm;
-                rec.clo = sv.clo;
-                rec.chi = sv.chi;
-                rec.min_codon = sv.mn;
             }
         }
         __syncthreads();
@@ -450,12 +486,16 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
                     for (int f = 0; f < 3; ++f) {
                         t.p[f] += (double)rec.p[f];
                         t.q[f] += (double)rec.q[f];
-                        t.n[f] += (int)((rec.nn >> (10 * f)) & 1023u);
-                        t.m[f] += (int)((rec.mm >> (10 * f)) & 1023u);
                     }
-                    t.count += (long long)rec.clo + ((long long)rec.chi << 16);
-                    t.min_codon = min(t.min_codon, (int)rec.min_codon);
                 }
+                const SegInts &acc = s_ints[seg];
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    t.n[f] = (int)((acc.nn >> (21 * f)) & 0x1fffffu);
+                    t.m[f] = (int)((acc.mm >> (21 * f)) & 0x1fffffu);
+                }
+                t.count = (long long)acc.count;
+                t.min_codon = (int)acc.min_codon;
             }
             const int kind = s_kind[seg];
             if (kind == kSegComplete) {
@@ -567,13 +607,20 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_finalize(const int32_t *__r
             store_orf(out, fp, orf, phase, valid, count, min_codon, flags | RP_FLAG_SPLIT, len);
         }
     }
-    unsigned long long todo = __ballot(unsafe);
-    while (todo) {
-        const int src = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const long long orf_s = __shfl(orf, src, kWave);
-        const long long beg_s = __shfl(beg, src, kWave);
-        const long long len_s = __shfl(len, src, kWave);
+    // too-close-to-call ORFs: queue them per workgroup and let the four waves share the
+    // float64 re-walks (a wave-serial loop over its own lanes was 3x slower)
+    __shared__ int s_list[kTileBlock];
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (unsafe) s_list[atomicAdd(&s_n, 1)] = (int)(b - (long long)blockIdx.x * kTileBlock);
+    __syncthreads();
+    const int n_list = s_n;
+    for (int k = threadIdx.x >> 6; k < n_list; k += kTileBlock / kWave) {
+        const long long bb = (long long)blockIdx.x * kTileBlock + s_list[k];
+        const long long orf_s = ws.tile_first[bb + 1] - 1;
+        const long long beg_s = offsets[orf_s];
+        const long long len_s = (long long)offsets[orf_s + 1] - beg_s;
         WalkResult<double> w;
         wave_walk<double>(counts + beg_s, len_s, lane, w);
         FrameScore fr2[3];

@@ -33,12 +33,19 @@ __device__ __forceinline__ void wave_walk(const int32_t *__restrict__ v, long lo
     for (long long j = lane; j < n_trip; j += kWave) {
         const long long p = 3 * j;
         const long long rem = len - p;  // >= 1
-        const int32_t *s = v + p;
-        const int v0 = s[0];
-        const int v1 = rem > 1 ? s[1] : 0;
-        const int v2 = rem > 2 ? s[2] : 0;
-        const int v3 = rem > 3 ? s[3] : 0;
-        const int v4 = rem > 4 ? s[4] : 0;
+        // five back-to-back loads at clamped (always in-range) indices, masked afterwards:
+        // a select per value instead of a branch + wait per load
+        const long long last = len - 1;
+        const int l0 = v[p];
+        const int l1 = v[p + 1 < last ? p + 1 : last];
+        const int l2 = v[p + 2 < last ? p + 2 : last];
+        const int l3 = v[p + 3 < last ? p + 3 : last];
+        const int l4 = v[p + 4 < last ? p + 4 : last];
+        const int v0 = l0;
+        const int v1 = rem > 1 ? l1 : 0;
+        const int v2 = rem > 2 ? l2 : 0;
+        const int v3 = rem > 3 ? l3 : 0;
+        const int v4 = rem > 4 ? l4 : 0;
         const int codon = v0 + v1 + v2;
         w.count += codon;
         w.min_codon = min(w.min_codon, codon);
