@@ -70,21 +70,30 @@ __device__ __forceinline__ void codon_add(FrameAcc<float> &acc, int a, int b, in
     acc.m += use ? 1 : 0;
 }
 
-// fp64: correctly rounded sqrt and divisions, so single-axis codons contribute
-// exactly +-1 / 0 and exact ties between frames stay exact.
+// fp64: q is an exact integer-valued double, r = rsqrt(q) after one Newton step is good
+// to ~1 ulp.  Frames that tie in exact arithmetic may then differ by ~1e-16 relative,
+// which the RP_TIE_RTOL rule of combine_frames absorbs (a correctly rounded sqrt + two
+// divisions cost 4x more and made the float64 re-walks the slowest part of finalize).
+__device__ __forceinline__ double rsqrt_f64(double q)
+{
+    double r = __builtin_amdgcn_rsq(q);          // v_rsq_f64, ~2^-26 relative
+    const double e = __builtin_fma(-q * r, r, 1.0);  // 1 - q r^2
+    r = __builtin_fma(r * e, __builtin_fma(e, 0.375, 0.5), r);  // r (1 + e/2 + 3 e^2/8)
+    return r;
+}
+
 __device__ __forceinline__ void codon_add(FrameAcc<double> &acc, int a, int b, int c, bool in_range)
 {
     const int d0i = a - b;
     const int d1i = b - c;
     const bool nz = in_range && ((a | b | c) != 0);
     const bool use = in_range && ((d0i | d1i) != 0);
-    if (use) {
-        const double d0 = (double)d0i;
-        const double d1 = (double)d1i;
-        const double s = sqrt(__builtin_fma(d0, d0 + d1, d1 * d1));
-        acc.p += d0 / s;
-        acc.q += d1 / s;
-    }
+    const double d0 = (double)d0i;
+    const double d1 = (double)d1i;
+    const double q = __builtin_fma(d0, d0 + d1, d1 * d1);
+    const double r = use ? rsqrt_f64(q) : 0.0;
+    acc.p = __builtin_fma(d0, r, acc.p);
+    acc.q = __builtin_fma(d1, r, acc.q);
     acc.n += nz ? 1 : 0;
     acc.m += use ? 1 : 0;
 }

@@ -607,31 +607,82 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_finalize(const int32_t *__r
             store_orf(out, fp, orf, phase, valid, count, min_codon, flags | RP_FLAG_SPLIT, len);
         }
     }
-    // too-close-to-call ORFs: queue them per workgroup and let the four waves share the
-    // float64 re-walks (a wave-serial loop over its own lanes was 3x slower)
+    // too-close-to-call ORFs: queue them per workgroup; short ones are re-walked in float64
+    // by one wave each, long ones (a single wave needs ~3 us per 1000 nt) by all four waves
+    constexpr long long kBlockWalkLen = 2048;
     __shared__ int s_list[kTileBlock];
     __shared__ int s_n;
+    __shared__ double s_part[kTileBlock / kWave][6];
+    __shared__ int s_parti[kTileBlock / kWave][7];
+    __shared__ long long s_partc[kTileBlock / kWave];
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     if (unsafe) s_list[atomicAdd(&s_n, 1)] = (int)(b - (long long)blockIdx.x * kTileBlock);
     __syncthreads();
     const int n_list = s_n;
-    for (int k = threadIdx.x >> 6; k < n_list; k += kTileBlock / kWave) {
+    const int wave = threadIdx.x >> 6;
+    for (int k = 0; k < n_list; ++k) {  // workgroup-uniform loop
         const long long bb = (long long)blockIdx.x * kTileBlock + s_list[k];
         const long long orf_s = ws.tile_first[bb + 1] - 1;
         const long long beg_s = offsets[orf_s];
         const long long len_s = (long long)offsets[orf_s + 1] - beg_s;
+        const bool block_walk = len_s > kBlockWalkLen;
+        if (!block_walk && (k & (kTileBlock / kWave - 1)) != wave) continue;
         WalkResult<double> w;
-        wave_walk<double>(counts + beg_s, len_s, lane, w);
+        if (block_walk)
+            wave_walk<double>(counts + beg_s, len_s, (int)threadIdx.x, w, kTileBlock);
+        else
+            wave_walk<double>(counts + beg_s, len_s, lane, w);
         FrameScore fr2[3];
         long long count2;
         int min2;
-        wave_reduce_frames(w, fr2, count2, min2);
+        if (block_walk) {
+            // per-wave sums -> LDS -> every thread adds the four partials in the same order
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                const double ps = wave_sum(w.acc[f].p), qs = wave_sum(w.acc[f].q);
+                const int ns = wave_sum(w.acc[f].n), ms = wave_sum(w.acc[f].m);
+                if (lane == 0) {
+                    s_part[wave][2 * f] = ps;
+                    s_part[wave][2 * f + 1] = qs;
+                    s_parti[wave][2 * f] = ns;
+                    s_parti[wave][2 * f + 1] = ms;
+                }
+            }
+            const long long cs = wave_sum(w.count);
+            const int mins = wave_min(w.min_codon);
+            if (lane == 0) {
+                s_partc[wave] = cs;
+                s_parti[wave][6] = mins;
+            }
+            __syncthreads();
+            count2 = 0;
+            min2 = RP_MIN_CODON_COV_EMPTY;
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                double ps = 0.0, qs = 0.0;
+                int ns = 0, ms = 0;
+                for (int wv = 0; wv < kTileBlock / kWave; ++wv) {
+                    ps += s_part[wv][2 * f];
+                    qs += s_part[wv][2 * f + 1];
+                    ns += s_parti[wv][2 * f];
+                    ms += s_parti[wv][2 * f + 1];
+                }
+                fr2[f] = frame_score(ps, qs, ns, ms);
+            }
+            for (int wv = 0; wv < kTileBlock / kWave; ++wv) {
+                count2 += s_partc[wv];
+                min2 = min(min2, s_parti[wv][6]);
+            }
+            __syncthreads();  // partial slots are reused by the next long item
+        } else {
+            wave_reduce_frames(w, fr2, count2, min2);
+        }
         double phase;
         int valid;
         unsigned flags;
         combine_frames(fr2, phase, valid, flags);
-        if (lane == 0)
+        if (lane == 0 && (!block_walk || wave == 0))
             store_orf(out, fp, orf_s, phase, valid, count2, min2, flags | RP_FLAG_SPLIT | RP_FLAG_RECHECK64, len_s);
     }
 }

@@ -21,16 +21,17 @@ struct WalkResult {
     int min_codon;    // min of those codon sums (frame-0 codons incl. the partial last one)
 };
 
-// Walk ORF [v, v+len) with the 64 lanes of a wave; int32 counts.
+// Walk ORF [v, v+len): this thread takes triplets first, first + stride, ...  (a wave
+// passes lane / 64, a whole workgroup tid / 256); int32 counts.
 template <typename Real>
-__device__ __forceinline__ void wave_walk(const int32_t *__restrict__ v, long long len, int lane,
-                                          WalkResult<Real> &w)
+__device__ __forceinline__ void wave_walk(const int32_t *__restrict__ v, long long len, int first,
+                                          WalkResult<Real> &w, int stride = kWave)
 {
     acc_clear(w.acc);
     w.count = 0;
     w.min_codon = RP_MIN_CODON_COV_EMPTY;
     const long long n_trip = (len + 2) / 3;  // ceil(len/3): common.py:164-180 codon count
-    for (long long j = lane; j < n_trip; j += kWave) {
+    for (long long j = first; j < n_trip; j += stride) {
         const long long p = 3 * j;
         const long long rem = len - p;  // >= 1
         // five back-to-back loads at clamped (always in-range) indices, masked afterwards:
