@@ -200,7 +200,7 @@ __device__ __forceinline__ FrameScore frame_score(double p, double q, int n, int
     } else if (m == 0) {
         r.score = __builtin_nan("");
     } else {
-        r.score = __builtin_fma(p, p + q, q * q) / ((double)n * (double)m);
+        r.score = __builtin_fma(p, p + q, q * q) / ((double)n * (double)m);  // IEEE division: exact ties stay exact
     }
     return r;
 }
@@ -286,12 +286,16 @@ __device__ __forceinline__ unsigned char orf_status(const FilterParams &fp, doub
                                                     long long read_count, int min_codon_cov,
                                                     long long length)
 {
-    const long long n_codons = (length / 3) > 1 ? (length / 3) : 1;  // max(1, length // 3)
-    const double ratio = (double)valid / (double)n_codons;
-    const double density = (double)read_count / (double)n_codons;
-    const bool ok = phase >= fp.phase_score_cutoff && valid >= fp.min_valid_codons &&
-                    (double)min_codon_cov >= fp.min_reads_per_codon &&
-                    ratio >= fp.min_valid_codons_ratio && density >= fp.min_density_over_orf;
+    bool ok = phase >= fp.phase_score_cutoff && valid >= fp.min_valid_codons &&
+              (double)min_codon_cov >= fp.min_reads_per_codon;
+    // ratio and density are >= 0, so the two IEEE divisions only matter for positive
+    // thresholds (the reference defaults are 0, const.py:35,39); wave-uniform branch
+    if (fp.min_valid_codons_ratio > 0.0 || fp.min_density_over_orf > 0.0) {
+        const long long n_codons = (length / 3) > 1 ? (length / 3) : 1;  // max(1, length // 3)
+        const double ratio = (double)valid / (double)n_codons;
+        const double density = (double)read_count / (double)n_codons;
+        ok = ok && ratio >= fp.min_valid_codons_ratio && density >= fp.min_density_over_orf;
+    }
     return ok ? 1 : 0;
 }
 

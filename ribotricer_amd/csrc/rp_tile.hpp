@@ -32,12 +32,11 @@
 namespace rp {
 
 constexpr int kTileBlock = 256;
-constexpr int kTile = 8192;    // positions per tile (40 KiB of int32)
+constexpr int kTile = 7680;    // positions per tile (40 KiB of int32)
 constexpr int kRun = 15;        // triplets per lane run; odd => lane stride 45 dwords, conflict free
 constexpr int kSegChunk = 64;   // segments set up per round (one per lane of wave 0)
 constexpr int kHalo = 8;        // dwords staged past the tile end (4 needed, 2 chunks loaded)
 constexpr int kLdsCounts = kTile + kHalo + 3 * kRun + 8;  // runs may read (masked) past the halo
-constexpr int kLoadRounds = (kTile / 4 + kTileBlock - 1) / kTileBlock;  // dwordx4 chunks per thread
 constexpr int kMaxRecs = kSegChunk + (kTile / (3 * kRun) + kSegChunk + 2 * 64) / 16 + 1;  // one per (segment, 16-lane row)
 
 enum SegKind : int { kSegComplete = 0, kSegHead = 1, kSegTail = 2 };
@@ -138,31 +137,32 @@ struct SegInts {
 
 // Stage positions [t0, t0 + kTile + kHalo) into LDS.  (counts + t0) is 16-byte aligned.
 // Interior tiles use the LDS-DMA form of global_load (no VGPR round trip, one instruction
-// per KiB per wave); the first / last tile take the guarded path with zero fill.
+// per KiB row, rows dealt round-robin to the four waves); the first / last tile take the
+// guarded path with zero fill.  The DMA is NOT waited for here.
 __device__ __forceinline__ void load_tile_to_lds(const int32_t *__restrict__ counts, long long t0,
                                                  long long total_nt, int *s_counts, int tid)
 {
     constexpr int n_chunks = (kTile + kHalo) / 4;  // 16-byte chunks
-    static_assert(kTile % (4 * kTileBlock) == 0, "tile must be a whole number of 256 x 16 B rounds");
+    constexpr int kRowPos = 256;                    // positions per DMA row (64 lanes x 16 B)
+    static_assert(kTile % kRowPos == 0, "tile must be a whole number of 1 KiB rows");
     static_assert(kHalo == 8, "halo is loaded as two extra chunks");
     const bool interior = (t0 >= 0) && (t0 + kTile + kHalo <= total_nt);  // workgroup-uniform
     if (interior) {
         typedef const __attribute__((address_space(1))) void *gptr_t;
         typedef __attribute__((address_space(3))) void *lptr_t;
-        const int32_t *src = counts + t0 + 4 * tid;
-        const int wave_base = (tid & ~(kWave - 1)) * 4;  // LDS dword index of this wave's lane 0
+        const int lane = tid & (kWave - 1);
+        const int32_t *src = counts + t0 + 4 * lane;
 #pragma unroll
-        for (int k = 0; k < kLoadRounds; ++k) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 4 * kTileBlock),
-                                             (lptr_t)(s_counts + k * 4 * kTileBlock + wave_base), 16, 0, 0);
+        for (int row = 0; row < kTile / kRowPos; ++row) {
+            if ((row & (kTileBlock / kWave - 1)) == (tid >> 6))  // rows dealt round-robin to the waves
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + row * kRowPos), (lptr_t)(s_counts + row * kRowPos), 16, 0, 0);
         }
-        if (tid < kWave) {  // halo: 2 chunks, lanes 0-1 of wave 0 (the DMA writes lane*16 past the base)
-            if (tid < n_chunks - kLoadRounds * kTileBlock) {
-                const int4 v = *reinterpret_cast<const int4 *>(counts + t0 + kTile + 4 * tid);
-                *reinterpret_cast<int4 *>(s_counts + kTile + 4 * tid) = v;
-            }
+        if (tid < 2) {  // halo: 2 chunks past the tile
+            const int4 v = *reinterpret_cast<const int4 *>(counts + t0 + kTile + 4 * tid);
+            *reinterpret_cast<int4 *>(s_counts + kTile + 4 * tid) = v;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA is tracked by vmcnt only
+        // NOTE: no wait here -- the caller waits (vmcnt only tracks the DMA) after it has
+        // issued its own independent loads
     } else {
 #pragma unroll 1
         for (int c = tid; c < n_chunks; c += kTileBlock) {
@@ -324,6 +324,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
     __shared__ int s_endq[kSegChunk];     // ORF end in LDS coordinates (clamped)
     __shared__ int s_ntrip[kSegChunk];    // owned triplets
     __shared__ int s_kind[kSegChunk];
+    __shared__ long long s_len[kSegChunk];  // ORF length (for n_codons and the float64 re-walk)
     __shared__ int s_vlstart[kSegChunk + 1];
     __shared__ int s_owner[kMaxVl];       // segment+1 at the first lane of a segment / wave, else 0
     __shared__ RunRec s_rec[kMaxRecs];
@@ -339,23 +340,33 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
     long long t1 = t0 + kTile;
     if (t1 > plan.total_nt) t1 = plan.total_nt;
 
+    // issue the tile DMA, then everything that does not depend on it, then wait once
     load_tile_to_lds(counts, t0, plan.total_nt, s_counts, tid);
-
     const long long a0 = ws.tile_first[b];
     const long long a1 = ws.tile_first[b + 1];
+    for (int k = tid; k < kMaxVl; k += kTileBlock) s_owner[k] = 0;
+    if (tid < kSegChunk) {
+        s_ints[tid].nn = 0;
+        s_ints[tid].mm = 0;
+        s_ints[tid].count = 0;
+        s_ints[tid].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
+    }
+    if (tid == 0) s_n_recheck = 0;
     // the ORF that straddles in from the left, if any (offsets[a0] is the first start >= t0)
     const int has_head = (a0 > 0 && (long long)offsets[a0] > t0) ? 1 : 0;
     const long long n_seg_total = has_head + (a1 - a0);
-    if (tid == 0) s_n_recheck = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is tracked by vmcnt only
 
     for (long long chunk = 0; chunk < n_seg_total; chunk += kSegChunk) {
         const int nseg = (int)((n_seg_total - chunk) < kSegChunk ? (n_seg_total - chunk) : kSegChunk);
-        for (int k = tid; k < kMaxVl; k += kTileBlock) s_owner[k] = 0;
-        if (tid < kSegChunk) {
-            s_ints[tid].nn = 0;
-            s_ints[tid].mm = 0;
-            s_ints[tid].count = 0;
-            s_ints[tid].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
+        if (chunk > 0) {  // (the first chunk's scratch was cleared while the tile streamed in)
+            for (int k = tid; k < kMaxVl; k += kTileBlock) s_owner[k] = 0;
+            if (tid < kSegChunk) {
+                s_ints[tid].nn = 0;
+                s_ints[tid].mm = 0;
+                s_ints[tid].count = 0;
+                s_ints[tid].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
+            }
         }
         __syncthreads();  // also orders the tile stores / the previous chunk's readers
 
@@ -388,6 +399,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
                 s_endq[lane] = endq;
                 s_ntrip[lane] = ntrip;
                 s_kind[lane] = head ? kSegHead : (complete ? kSegComplete : kSegTail);
+                s_len[lane] = end - beg;
                 lanes = (ntrip + kRun - 1) / kRun;
             }
             const int incl = wave_add_scan(lanes);
@@ -510,8 +522,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
                     int valid;
                     unsigned flags;
                     combine_frames(fr, phase, valid, flags);
-                    const long long len = (long long)offsets[orf + 1] - (long long)offsets[orf];
-                    store_orf(out, fp, orf, phase, valid, t.count, t.min_codon, flags, len);
+                    store_orf(out, fp, orf, phase, valid, t.count, t.min_codon, flags, s_len[seg]);
                 }
             } else {
                 ws.partials[2 * b + (kind == kSegHead ? 0 : 1)] = t;
@@ -523,11 +534,12 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
         const int n_re = s_n_recheck;
         if (n_re > 0) {
             for (int k = wave; k < n_re; k += kTileBlock / kWave) {
-                const long long orf = a0 - has_head + chunk + s_recheck[k];
-                const long long beg = offsets[orf];
-                const long long len = (long long)offsets[orf + 1] - beg;
+                const int seg = s_recheck[k];
+                const long long orf = a0 - has_head + chunk + seg;
+                const long long len = s_len[seg];
                 WalkResult<double> w;
-                wave_walk<double>(counts + beg, len, lane, w);
+                // a complete segment starts in this tile and ends inside tile + halo: walk LDS
+                wave_walk<double>(s_counts + s_qfirst[seg], len, lane, w);
                 FrameScore fr[3];
                 long long count;
                 int min_codon;
