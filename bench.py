@@ -31,6 +31,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+CFG_NAMES = {"cfg2": "BASELINE configs[1]", "cfg3": "BASELINE configs[2]", "cfg5": "BASELINE configs[4]"}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -81,6 +82,21 @@ def cpu_baseline(counts_host, offsets_host, n_sample):
     extra = {"value": n_c / dt_c, "unit": "ORFs/s", "cores": cores, "kind": "port",
              "sample": f"first {n_c} ORFs, oracle/phase_oracle.c closed form + OpenMP, {dt_c:.2f} s"}
     return out, extra
+
+
+def measured_traffic(args, n_orfs, algo):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json: FETCH_SIZE and WRITE_SIZE in KiB, separate --pmc runs of this
+    very command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 wide
+    streaming reads).  None when no profile matches the workload being run."""
+    path = os.path.join(REPO, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        for rec in json.load(fh):
+            if rec["cfg"] == args.cfg and rec["orfs_per_gpu"] == n_orfs and rec["algo"] == algo and rec["seed"] == args.seed:
+                return int((2 * rec["fetch_size_kib"] + rec["write_size_kib"]) * 1024)
+    return None
 
 
 def main():
@@ -153,6 +169,8 @@ def main():
     if rank == 0:
         algo_bytes = 4 * total_nt + 8 * (n_orfs + 1) + 24 * n_orfs
         achieved = algo_bytes / (k_main * 1e-3) / 1e9
+        resolved = "tile" if algo == "auto" else algo  # RP_ALGO_AUTO -> RP_ALGO_TILE (ribophase.hip)
+        traffic = measured_traffic(args, n_orfs, resolved)
         flags = out.flags
         result = {
             "metric": "ORFs phase-scored/sec (whole node)",
@@ -168,7 +186,7 @@ def main():
             "dtype": "f32 codon math, f64 reduction/score (int32 counts)",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[1]: synthetic {n_orfs} ORFs/GPU, mean {total_nt / n_orfs:.0f} nt, "
+                "workload": f"{CFG_NAMES[args.cfg]}: synthetic {n_orfs} ORFs/GPU, mean {total_nt / n_orfs:.0f} nt, "
                 f"Poisson P-site counts ({args.cfg}), resident in HBM",
                 "orfs_per_gpu": n_orfs,
                 "nt_per_gpu": total_nt,
@@ -181,8 +199,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "kernel": "k_tile_score" if algo != "wave" else "k_wave_score",
+                "traffic": traffic,
+                "kernel": "rp::k_tile_score" if resolved == "tile" else "rp::k_wave_score",
                 "kernel_ms": k_main,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "step_device_ms": dev_ms_per_step,

@@ -12,13 +12,15 @@ rm -rf $W; mkdir -p $W $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $W/stats -o stats -- python3 bench.py $ARGS --steps 20 --warmup 3 --cpu-sample 0 > $OUT/stats_bench.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $W/pmc1 -o pmc1 -- python3 bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 > $OUT/pmc1_bench.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $W/pmc2 -o pmc2 -- python3 bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 > $OUT/pmc2_bench.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $W/pmc3 -o pmc3 -- python3 bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 > $OUT/pmc3_bench.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $W/pmc4 -o pmc4 -- python3 bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 > $OUT/pmc4_bench.log 2>&1
 find $W -name "*.csv" | while read f; do echo "$f $(wc -c < $f)"; done
 cp $(find $W/stats -name "*kernel_stats.csv") $OUT/kernel_stats.csv 2>/dev/null
 # per-kernel mean of every counter (counter_collection csv is one row per dispatch x counter)
 python3 - "$W" "$OUT" <<'PY'
 import csv, glob, sys, collections
 W, OUT = sys.argv[1], sys.argv[2]
-for tag in ("pmc1", "pmc2"):
+for tag in ("pmc1", "pmc2", "pmc3", "pmc4"):
     files = glob.glob(f"{W}/{tag}/**/*counter_collection.csv", recursive=True)
     acc = collections.defaultdict(lambda: [0.0, 0])
     for f in files:
@@ -31,4 +33,4 @@ for tag in ("pmc1", "pmc2"):
             fh.write(f"\"{k}\",{c},{s/n:.1f},{n}\n")
 PY
 head -12 $OUT/kernel_stats.csv
-grep -E "k_tile|k_wave" $OUT/pmc1_summary.csv $OUT/pmc2_summary.csv
+grep -E "k_tile|k_wave" $OUT/pmc1_summary.csv $OUT/pmc2_summary.csv $OUT/pmc3_summary.csv $OUT/pmc4_summary.csv
