@@ -42,7 +42,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--orfs", type=int, default=1_000_000, help="ORFs per GPU")
     ap.add_argument("--cfg", default="cfg2", choices=["cfg2", "cfg3", "cfg5"])
-    ap.add_argument("--algo", default="auto", choices=["auto", "wave", "tile"])
+    ap.add_argument("--algo", default="auto", choices=["auto", "wave", "tile", "pipe"])
     ap.add_argument("--cpu-sample", type=int, default=30000, help="ORFs for the CPU baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=20260213)
     return ap.parse_args()

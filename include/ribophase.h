@@ -35,9 +35,9 @@ extern "C" {
 
 #define RP_VERSION_STRING "0.1.0"
 
-/* largest admissible P-site count per nucleotide (codon sums stay inside int32 and a
- * lane's 27-position partial read count inside uint32) */
-#define RP_MAX_COUNT 67108863 /* 2^26 - 1: 27 counts still sum inside uint32 */
+/* largest admissible P-site count per nucleotide (exact in fp32; codon sums stay inside
+ * int32 and a lane's 45-position partial read count inside uint32) */
+#define RP_MAX_COUNT 16777215 /* 2^24 - 1: counts convert to fp32 exactly */
 
 /* value of min_codon_cov for an ORF with an empty profile (min over no codons;
  * numpy.all([]) is True in detect_orfs.py:288,293) */
@@ -69,7 +69,9 @@ typedef enum rp_status {
 typedef enum rp_algo {
     RP_ALGO_AUTO = 0,
     RP_ALGO_WAVE = 1, /* one wavefront per ORF, streaming straight from HBM */
-    RP_ALGO_TILE = 2  /* LDS-staged flat tiles, ragged lane packing, partials + finalize */
+    RP_ALGO_TILE = 2, /* LDS-staged flat tiles, ragged lane packing, partials + finalize */
+    RP_ALGO_TILE_PIPE = 3 /* same tiles, persistent workgroups: finish / setup / DMA of neighbouring
+                             tiles overlap */
 } rp_algo;
 
 /*

@@ -15,14 +15,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libribophase.so")
 
 RP_OK = 0
-RP_ALGO_AUTO, RP_ALGO_WAVE, RP_ALGO_TILE = 0, 1, 2
-ALGOS = {"auto": RP_ALGO_AUTO, "wave": RP_ALGO_WAVE, "tile": RP_ALGO_TILE}
+RP_ALGO_AUTO, RP_ALGO_WAVE, RP_ALGO_TILE, RP_ALGO_TILE_PIPE = 0, 1, 2, 3
+ALGOS = {"auto": RP_ALGO_AUTO, "wave": RP_ALGO_WAVE, "tile": RP_ALGO_TILE, "pipe": RP_ALGO_TILE_PIPE}
 
 FLAG_TIE = 0x01
 FLAG_RECHECK64 = 0x02
 FLAG_SPLIT = 0x04
 MIN_CODON_COV_EMPTY = 2147483647
-MAX_COUNT = 67108863
+MAX_COUNT = 16777215
 
 
 class RibophaseError(RuntimeError):

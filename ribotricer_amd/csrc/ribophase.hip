@@ -8,10 +8,12 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 #include "../../include/ribophase.h"
 #include "rp_device.hpp"
 #include "rp_tile.hpp"
+#include "rp_tile_pipe.hpp"
 #include "rp_wave.hpp"
 
 namespace {
@@ -85,7 +87,7 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
                void *hip_stream, Timing *tm)
 {
     if (n_orfs < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "n_orfs=%lld total_nt=%lld must be >= 0", (long long)n_orfs, (long long)total_nt);
-    if (algo != RP_ALGO_AUTO && algo != RP_ALGO_WAVE && algo != RP_ALGO_TILE)
+    if (algo != RP_ALGO_AUTO && algo != RP_ALGO_WAVE && algo != RP_ALGO_TILE && algo != RP_ALGO_TILE_PIPE)
         return fail(RP_ERR_ARG, "unknown algo %d", algo);
     if (n_orfs > 0 && (!d_offsets || !d_phase || !d_valid || !d_read_count || !d_min_codon_cov || !d_flags))
         return fail(RP_ERR_NULL, "offsets and the five output arrays must be non-null");
@@ -116,14 +118,50 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
         return RP_OK;
     }
 
-    // RP_ALGO_TILE
     size_t need = 0;
-    rc = rp_workspace_bytes(n_orfs, total_nt, RP_ALGO_TILE, &need);
+    rc = rp_workspace_bytes(n_orfs, total_nt, algo, &need);
     if (rc != RP_OK) return rc;
     if (!d_workspace || workspace_bytes < need)
         return fail(RP_ERR_WORKSPACE, "workspace of %zu bytes required, got %zu", need, workspace_bytes);
     if ((reinterpret_cast<uintptr_t>(d_workspace) & 15u) != 0)
         return fail(RP_ERR_WORKSPACE, "workspace must be 16-byte aligned");
+    if (algo == RP_ALGO_TILE_PIPE) {
+        // persistent, software-pipelined workgroups: 4 per CU
+        const rp::TilePlan plan = rp::make_pipe_plan(n_orfs, total_nt, d_counts);
+        rp::TileWorkspace ws = rp::pipe_carve_workspace(d_workspace, total_nt);
+        {
+            const long long threads = n_orfs + 1;
+            const int block = 256;
+            const int grid = (int)((threads + block - 1) / block);
+            hipLaunchKernelGGL(rp::k_pipe_index, dim3(grid), dim3(block), 0, stream, d_offsets, (long long)n_orfs, plan, ws);
+            RP_HIP(hipGetLastError());
+        }
+        if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[1], stream));
+        int n_cu = 256;
+        {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        }
+        int per_cu = 4;
+        if (const char *e = getenv("RP_PIPE_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 4;
+        long long grid_pipe = (long long)n_cu * per_cu;
+        if (grid_pipe > plan.n_tiles) grid_pipe = plan.n_tiles;
+        hipLaunchKernelGGL(rp::k_tile_score_pipe, dim3((unsigned)grid_pipe), dim3(rp::kTileBlock), 0, stream, d_counts,
+                           d_offsets, (long long)n_orfs, plan, ws, out, fp);
+        RP_HIP(hipGetLastError());
+        if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));
+        {
+            const int block = 256;
+            const int grid = (int)((plan.n_tiles + block - 1) / block);
+            hipLaunchKernelGGL(rp::k_tile_finalize<rp::kPipeTile>, dim3(grid), dim3(block), 0, stream, d_counts,
+                               d_offsets, (long long)n_orfs, plan, ws, out, fp);
+            RP_HIP(hipGetLastError());
+        }
+        if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[3], stream));
+        return RP_OK;
+    }
+
+    // RP_ALGO_TILE
     const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt, d_counts);
     rp::TileWorkspace ws = rp::carve_workspace(d_workspace, total_nt);
 
@@ -146,7 +184,7 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     {
         const int block = 256;
         const int grid = (int)((plan.n_tiles + block - 1) / block);
-        hipLaunchKernelGGL(rp::k_tile_finalize, dim3(grid), dim3(block), 0, stream, d_counts,
+        hipLaunchKernelGGL(rp::k_tile_finalize<rp::kTile>, dim3(grid), dim3(block), 0, stream, d_counts,
                            d_offsets, (long long)n_orfs, plan, ws, out, fp);
         RP_HIP(hipGetLastError());
     }
@@ -209,13 +247,16 @@ int rp_workspace_bytes(int64_t n_orfs, int64_t total_nt, int algo, size_t *bytes
 {
     if (!bytes) return fail(RP_ERR_NULL, "bytes is null");
     if (n_orfs < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "negative size");
-    if (algo != RP_ALGO_AUTO && algo != RP_ALGO_WAVE && algo != RP_ALGO_TILE)
+    if (algo != RP_ALGO_AUTO && algo != RP_ALGO_WAVE && algo != RP_ALGO_TILE && algo != RP_ALGO_TILE_PIPE)
         return fail(RP_ERR_ARG, "unknown algo %d", algo);
     if (algo == RP_ALGO_WAVE) {
         *bytes = 0;
         return RP_OK;
     }
-    *bytes = rp::workspace_bytes(total_nt);
+    {   // AUTO may resolve to either tile family: size for the larger
+        const size_t a = rp::workspace_bytes(total_nt), p = rp::pipe_workspace_bytes(total_nt);
+        *bytes = a > p ? a : p;
+    }
     return RP_OK;
 }
 

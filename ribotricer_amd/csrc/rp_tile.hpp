@@ -32,7 +32,7 @@
 namespace rp {
 
 constexpr int kTileBlock = 256;
-constexpr int kTile = 7680;    // positions per tile (40 KiB of int32)
+constexpr int kTile = 7936;    // positions per tile (40 KiB of int32)
 constexpr int kRun = 15;        // triplets per lane run; odd => lane stride 45 dwords, conflict free
 constexpr int kSegChunk = 64;   // segments set up per round (one per lane of wave 0)
 constexpr int kHalo = 8;        // dwords staged past the tile end (4 needed, 2 chunks loaded)
@@ -257,16 +257,33 @@ __device__ __forceinline__ int wave_add_scan(int x)
 constexpr int kRunBlock = 3;  // triplets per fully unrolled block of the lane run
 static_assert(kRun % kRunBlock == 0, "kRun must be a multiple of kRunBlock");
 
+// min(x, hi) for x >= 0 as v_med3_f32(x, 0, hi): a compiler-visible instruction (hipcc
+// inserts no hazard wait states around inline asm, and v_rsq_f32 results need them) that
+// does not drag in the NaN-canonicalising v_max(x, x) pair of fminf().
+__device__ __forceinline__ float min_nonneg(float x, float hi) { return __builtin_amdgcn_fmed3f(x, 0.0f, hi); }
+
+// clamp(x, 0, 1): folds into the producing instruction's clamp modifier
+__device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
+
+// The lane run, predicate-free: every test is folded into fp32 arithmetic so the loop is
+// 16 VALU instructions per codon with no v_cmp / v_cndmask / scalar mask traffic:
+//   vF  = clamp(lim - c, 0, 1)          1 while codon c is a real codon of this run
+//   r   = min(rsq(q), vF)               1/sqrt(q);  a == b == c gives rsq(0) = inf -> 1, and
+//                                       its d0 = d1 = 0 make the products below exactly 0
+//   P  += d0 r,  Q += d1 r              unit-vector sums
+//   u   = min(q, vF)                    q is an integer: 0 or >= 1, so u is exactly 1 for a
+//                                       counted codon, 0 otherwise                  -> M
+//   E  += (vF - u) * min(a, 1)          flat non-zero codons; N = M + E
+// M and E are sums of <= kRun exact 0/1 values per frame.
+// Counts are converted to fp32 first, exact below 2^24 (RP_MAX_COUNT).
 __device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, LaneSums &o)
 {
-    // rolling window over positions c, c+1, c+2: value, difference to the successor (int
-    // exact, then float) and "equals successor"
     int v0 = s[0], v1 = s[1];
-    int d = v0 - v1;
-    bool e0 = (d == 0);
-    float df0 = (float)d;
+    float f0 = (float)v0, f1 = (float)v1;
+    float df0 = f0 - f1;
+    float limf = (float)lim;
     float P[3] = {0.f, 0.f, 0.f}, Q[3] = {0.f, 0.f, 0.f};
-    int n[3] = {0, 0, 0}, m[3] = {0, 0, 0};
+    float M[3] = {0.f, 0.f, 0.f}, E[3] = {0.f, 0.f, 0.f};
     unsigned cnt = 0, mn = (unsigned)RP_MIN_CODON_COV_EMPTY;
 #pragma unroll 1
     for (int blk = 0; blk < kRun / kRunBlock; ++blk) {
@@ -274,46 +291,51 @@ __device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, Lan
         for (int c = 0; c < 3 * kRunBlock; ++c) {
             const int f = c % 3;
             const int v2 = s[c + 2];
-            const bool valid = c < lim;
-            d = v1 - v2;
-            const bool e1 = (d == 0);
-            const float df1 = (float)d;
-            // the tiny addend keeps q > 0 for a == b == c, so 0 * rsq(q) is 0 instead of
-            // NaN; q >= 1 otherwise and is unchanged by it
-            const float sq1 = __builtin_fmaf(df1, df1, 1e-30f);
-            const float qq = __builtin_fmaf(df0, df0 + df1, sq1);
-            const float r = valid ? __builtin_amdgcn_rsqf(qq) : 0.0f;
+            const float f2 = (float)v2;
+            const float df1 = f1 - f2;
+            const float qq = __builtin_fmaf(df0, df0 + df1, df1 * df1);
+            const float vF = clamp01(limf - (float)c);
+            const float r = min_nonneg(__builtin_amdgcn_rsqf(qq), vF);
             P[f] = __builtin_fmaf(df0, r, P[f]);
             Q[f] = __builtin_fmaf(df1, r, Q[f]);
-            n[f] += (valid && ((v0 | v1 | v2) != 0)) ? 1 : 0;
-            m[f] += (valid && !(e0 && e1)) ? 1 : 0;
+            const float u = min_nonneg(qq, vF);  // q is 0 or >= 1: exactly 1 for a counted codon
+            M[f] += u;
+            E[f] = __builtin_fmaf(vF - u, clamp01(f0), E[f]);
             if (f == 0) {
+                const bool valid = c < lim;
                 const unsigned codon = (unsigned)(v0 + v1 + v2);
                 cnt += valid ? codon : 0u;
                 mn = min(mn, valid ? codon : (unsigned)RP_MIN_CODON_COV_EMPTY);
             }
             v0 = v1;
             v1 = v2;
-            e0 = e1;
+            f0 = f1;
+            f1 = f2;
             df0 = df1;
         }
         s += 3 * kRunBlock;
         lim -= 3 * kRunBlock;
+        limf -= (float)(3 * kRunBlock);
     }
+    unsigned nn = 0, mm = 0;
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         o.p[f] = P[f];
         o.q[f] = Q[f];
+        const unsigned m = (unsigned)__builtin_rintf(M[f]);
+        const unsigned n = m + (unsigned)__builtin_rintf(E[f]);
+        nn |= n << (10 * f);
+        mm |= m << (10 * f);
     }
-    o.nn = (unsigned)n[0] | ((unsigned)n[1] << 10) | ((unsigned)n[2] << 20);
-    o.mm = (unsigned)m[0] | ((unsigned)m[1] << 10) | ((unsigned)m[2] << 20);
+    o.nn = nn;
+    o.mm = mm;
     o.count = cnt;
     o.mn = mn;
 }
 
 constexpr int kMaxVl = kTile / (3 * kRun) + kSegChunk + 2 * kWave;  // virtual lanes per chunk (upper bound)
 
-__global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__restrict__ counts,
+__global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__restrict__ counts,
                                                            const int64_t *__restrict__ offsets,
                                                            long long n_orfs, TilePlan plan,
                                                            TileWorkspace ws, OrfOutputs out,
@@ -562,6 +584,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_score(const int32_t *__rest
 // not end inside it; sums the tail partial of that tile and the head partials of the
 // tiles the ORF runs through.  Too-close-to-call ORFs are re-walked by the whole wave.
 // ---------------------------------------------------------------------------
+template <int TILE>
 __global__ __launch_bounds__(kTileBlock) void k_tile_finalize(const int32_t *__restrict__ counts,
                                                               const int64_t *__restrict__ offsets,
                                                               long long n_orfs, TilePlan plan,
@@ -580,12 +603,12 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_finalize(const int32_t *__r
             beg = offsets[orf];
             len = (long long)offsets[orf + 1] - beg;
             const long long ntrip_all = (len + 2) / 3;
-            long long t1 = (b + 1) * (long long)kTile - plan.mis;
+            long long t1 = (b + 1) * (long long)TILE - plan.mis;
             if (t1 > plan.total_nt) t1 = plan.total_nt;
             const long long last_first = beg + 3 * (ntrip_all - 1);  // first position of the last triplet
             if (ntrip_all > 0 && last_first >= t1) {
                 work = true;
-                b_end = (last_first + plan.mis) / kTile;
+                b_end = (last_first + plan.mis) / TILE;
             }
         }
     }

@@ -16,7 +16,7 @@ from oracle import c_oracle
 pytestmark = pytest.mark.gpu
 
 PHASE_TOL = 1e-6
-ALGOS = ["wave", "tile"]
+ALGOS = ["wave", "tile", "pipe"]
 
 
 @pytest.fixture(scope="module")
