@@ -39,7 +39,7 @@ constexpr int kHalo = 8;        // dwords staged past the tile end (4 needed, 2 
 constexpr int kLdsCounts = kTile + kHalo + 3 * kRun + 8;  // runs may read (masked) past the halo
 constexpr int kMaxRecs = kSegChunk + (kTile / (3 * kRun) + kSegChunk + 2 * 64) / 16 + 1;  // one per (segment, 16-lane row)
 
-enum SegKind : int { kSegComplete = 0, kSegHead = 1, kSegTail = 2 };
+enum SegKind : int { kSegComplete = 0, kSegHead = 1, kSegTail = 2, kSegNone = 3 };
 
 struct TilePlan {
     long long n_tiles;
@@ -362,7 +362,10 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
     long long t1 = t0 + kTile;
     if (t1 > plan.total_nt) t1 = plan.total_nt;
 
-    // issue the tile DMA, then everything that does not depend on it, then wait once
+    // Issue the tile DMA, then everything that does not depend on it -- the tile index, the
+    // scratch clear and (wave 0) the offsets of the first 64 segment slots -- then wait once.
+    // Slot L of a chunk holds ORF c0 + L; the first chunk starts at c0 = a0 - 1, so slot 0 is
+    // the ORF that straddles in from the left, when there is one.
     load_tile_to_lds(counts, t0, plan.total_nt, s_counts, tid);
     const long long a0 = ws.tile_first[b];
     const long long a1 = ws.tile_first[b + 1];
@@ -374,14 +377,19 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
         s_ints[tid].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
     }
     if (tid == 0) s_n_recheck = 0;
-    // the ORF that straddles in from the left, if any (offsets[a0] is the first start >= t0)
-    const int has_head = (a0 > 0 && (long long)offsets[a0] > t0) ? 1 : 0;
-    const long long n_seg_total = has_head + (a1 - a0);
+    long long beg0 = 0, end0 = 0;
+    if (wave == 0) {
+        const long long orf = a0 - 1 + lane;
+        if (orf >= 0 && orf < a1) {
+            beg0 = offsets[orf];
+            end0 = offsets[orf + 1];
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is tracked by vmcnt only
 
-    for (long long chunk = 0; chunk < n_seg_total; chunk += kSegChunk) {
-        const int nseg = (int)((n_seg_total - chunk) < kSegChunk ? (n_seg_total - chunk) : kSegChunk);
-        if (chunk > 0) {  // (the first chunk's scratch was cleared while the tile streamed in)
+    for (long long c0 = a0 - 1; c0 < a1; c0 += kSegChunk) {
+        const bool first_chunk = c0 == a0 - 1;
+        if (!first_chunk) {  // (the first chunk's scratch was cleared while the tile streamed in)
             for (int k = tid; k < kMaxVl; k += kTileBlock) s_owner[k] = 0;
             if (tid < kSegChunk) {
                 s_ints[tid].nn = 0;
@@ -389,41 +397,44 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
                 s_ints[tid].count = 0;
                 s_ints[tid].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
             }
+            __syncthreads();  // previous chunk's readers are done, scratch is clear
         }
-        __syncthreads();  // also orders the tile stores / the previous chunk's readers
 
-        // ---- segment setup + lane allocation (wave 0) ---------------------------------
+        // ---- segment setup + lane allocation (wave 0; needs only offsets, not the tile) ----
         if (wave == 0) {
             int lanes = 0;
-            if (lane < nseg) {
-                const long long s = chunk + lane;
-                const long long orf = a0 - has_head + s;
-                const long long beg = offsets[orf];
-                const long long end = offsets[orf + 1];
-                const bool head = has_head && s == 0;
-                const int kt = (int)(t1 - t0);  // tile length in positions (<= kTile)
-                int qfirst;                     // LDS index of the first triplet start >= tile start
-                if (head) {
-                    const unsigned long long rel0 = (unsigned long long)(t0 - beg);  // > 0
-                    // 2^32 == 1 (mod 3)
-                    const unsigned m3 = ((unsigned)(rel0 >> 32) % 3u + (unsigned)(rel0 & 0xffffffffu) % 3u) % 3u;
-                    qfirst = m3 == 0 ? 0 : 3 - (int)m3;
-                } else {
-                    qfirst = (int)(beg - t0);
+            int kind = kSegNone;
+            const long long orf = c0 + lane;
+            if (orf >= 0 && orf < a1) {
+                const long long beg = first_chunk ? beg0 : (long long)offsets[orf];
+                const long long end = first_chunk ? end0 : (long long)offsets[orf + 1];
+                const bool head = orf < a0;  // only ORF a0 - 1 can be; it counts if it reaches the tile
+                if (!head || end > t0) {
+                    const int kt = (int)(t1 - t0);  // tile length in positions (<= kTile)
+                    int qfirst;                     // LDS index of the first triplet start >= tile start
+                    if (head) {
+                        const unsigned long long rel0 = (unsigned long long)(t0 - beg);  // > 0
+                        // 2^32 == 1 (mod 3)
+                        const unsigned m3 = ((unsigned)(rel0 >> 32) % 3u + (unsigned)(rel0 & 0xffffffffu) % 3u) % 3u;
+                        qfirst = m3 == 0 ? 0 : 3 - (int)m3;
+                    } else {
+                        qfirst = (int)(beg - t0);
+                    }
+                    const long long rem = end - t0;  // >= 0
+                    const bool end_in_lds = rem <= kTile + kHalo;
+                    const int endq = end_in_lds ? (int)rem : kTile + kHalo;
+                    const int lim_q = kt < endq ? kt : endq;  // owned triplets start below this
+                    const int ntrip = lim_q > qfirst ? (lim_q - qfirst + 2) / 3 : 0;
+                    const bool complete = !head && end_in_lds && ntrip == (endq - qfirst + 2) / 3;
+                    s_qfirst[lane] = qfirst;
+                    s_endq[lane] = endq;
+                    s_ntrip[lane] = ntrip;
+                    s_len[lane] = end - beg;
+                    kind = head ? kSegHead : (complete ? kSegComplete : kSegTail);
+                    lanes = (ntrip + kRun - 1) / kRun;
                 }
-                const long long rem = end - t0;  // >= 0
-                const bool end_in_lds = rem <= kTile + kHalo;
-                const int endq = end_in_lds ? (int)rem : kTile + kHalo;
-                const int lim_q = kt < endq ? kt : endq;  // owned triplets start below this
-                const int ntrip = lim_q > qfirst ? (lim_q - qfirst + 2) / 3 : 0;
-                const bool complete = !head && end_in_lds && ntrip == (endq - qfirst + 2) / 3;
-                s_qfirst[lane] = qfirst;
-                s_endq[lane] = endq;
-                s_ntrip[lane] = ntrip;
-                s_kind[lane] = head ? kSegHead : (complete ? kSegComplete : kSegTail);
-                s_len[lane] = end - beg;
-                lanes = (ntrip + kRun - 1) / kRun;
             }
+            s_kind[lane] = kind;
             const int incl = wave_add_scan(lanes);
             const int vs = incl - lanes;
             s_vlstart[lane] = vs;
@@ -495,9 +506,9 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
         __syncthreads();
 
         // ---- one thread per segment: float64 combine, finish or emit a partial ------------
-        if (tid < nseg) {
+        if (tid < kSegChunk && s_kind[tid] != kSegNone) {
             const int seg = tid;
-            const long long orf = a0 - has_head + chunk + seg;
+            const long long orf = c0 + seg;
             const int vs = s_vlstart[seg];
             const int ve = s_vlstart[seg + 1];
             TilePartial t;
@@ -557,7 +568,7 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
         if (n_re > 0) {
             for (int k = wave; k < n_re; k += kTileBlock / kWave) {
                 const int seg = s_recheck[k];
-                const long long orf = a0 - has_head + chunk + seg;
+                const long long orf = c0 + seg;
                 const long long len = s_len[seg];
                 WalkResult<double> w;
                 // a complete segment starts in this tile and ends inside tile + halo: walk LDS

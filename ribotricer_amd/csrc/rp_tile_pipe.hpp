@@ -26,7 +26,6 @@ constexpr int kPipeTile = 7168;  // positions per tile: 28 DMA rows, 3 lane-run 
 constexpr int kPipeLdsCounts = kPipeTile + kHalo + 3 * kRun + 8;
 constexpr int kPipeMaxVl = kPipeTile / (3 * kRun) + kSegChunk + 2 * kWave;
 constexpr int kPipeMaxRecs = kSegChunk + kPipeMaxVl / 16 + 1;
-constexpr int kSegNone = 3;
 
 struct SegSet {  // the segment table of one tile chunk
     long long len[kSegChunk];  // ORF length
