@@ -152,14 +152,20 @@ __device__ __forceinline__ void load_tile_to_lds(const int32_t *__restrict__ cou
         typedef __attribute__((address_space(3))) void *lptr_t;
         const int lane = tid & (kWave - 1);
         const int32_t *src = counts + t0 + 4 * lane;
+        // rows dealt round-robin to waves 1-3: issuing stalls a wave until the memory pipe has
+        // taken its requests, and wave 0 builds the segment table meanwhile
+        const int w = (tid >> 6) - 1;
+        if (w >= 0) {
 #pragma unroll
-        for (int row = 0; row < kTile / kRowPos; ++row) {
-            if ((row & (kTileBlock / kWave - 1)) == (tid >> 6))  // rows dealt round-robin to the waves
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + row * kRowPos), (lptr_t)(s_counts + row * kRowPos), 16, 0, 0);
+            for (int row = 0; row < kTile / kRowPos; ++row) {
+                if (row % 3 == w)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src + row * kRowPos), (lptr_t)(s_counts + row * kRowPos), 16, 0, 0);
+            }
         }
-        if (tid < 2) {  // halo: 2 chunks past the tile
-            const int4 v = *reinterpret_cast<const int4 *>(counts + t0 + kTile + 4 * tid);
-            *reinterpret_cast<int4 *>(s_counts + kTile + 4 * tid) = v;
+        if (tid >= kWave && tid < kWave + 2) {  // halo: 2 chunks past the tile
+            const int h = tid - kWave;
+            const int4 v = *reinterpret_cast<const int4 *>(counts + t0 + kTile + 4 * h);
+            *reinterpret_cast<int4 *>(s_counts + kTile + 4 * h) = v;
         }
         // NOTE: no wait here -- the caller waits (vmcnt only tracks the DMA) after it has
         // issued its own independent loads
@@ -369,16 +375,16 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
     load_tile_to_lds(counts, t0, plan.total_nt, s_counts, tid);
     const long long a0 = ws.tile_first[b];
     const long long a1 = ws.tile_first[b + 1];
-    for (int k = tid; k < kMaxVl; k += kTileBlock) s_owner[k] = 0;
-    if (tid < kSegChunk) {
-        s_ints[tid].nn = 0;
-        s_ints[tid].mm = 0;
-        s_ints[tid].count = 0;
-        s_ints[tid].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
-    }
-    if (tid == 0) s_n_recheck = 0;
     long long beg0 = 0, end0 = 0;
     if (wave == 0) {
+        // wave 0 owns the segment scratch until the first barrier: it alone clears it (the
+        // other waves are still busy issuing DMA rows and must not clobber its marks later)
+        for (int k = lane; k < kMaxVl; k += kWave) s_owner[k] = 0;
+        s_ints[lane].nn = 0;
+        s_ints[lane].mm = 0;
+        s_ints[lane].count = 0;
+        s_ints[lane].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
+        if (lane == 0) s_n_recheck = 0;
         const long long orf = a0 - 1 + lane;
         if (orf >= 0 && orf < a1) {
             beg0 = offsets[orf];
