@@ -197,7 +197,7 @@ __device__ __forceinline__ int dpp_row(int src)
 struct LaneSums {
     float p[3];
     float q[3];
-    unsigned nn, mm;  // n[0] | n[1] << 10 | n[2] << 20 (per lane: <= kRun each)
+    unsigned n[3], m[3];  // per lane: <= kRun each
     unsigned count;   // <= 3 * kRun * RP_MAX_COUNT < 2^32
     unsigned mn;
 };
@@ -323,18 +323,13 @@ __device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, Lan
         lim -= 3 * kRunBlock;
         limf -= (float)(3 * kRunBlock);
     }
-    unsigned nn = 0, mm = 0;
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         o.p[f] = P[f];
         o.q[f] = Q[f];
-        const unsigned m = (unsigned)__builtin_rintf(M[f]);
-        const unsigned n = m + (unsigned)__builtin_rintf(E[f]);
-        nn |= n << (10 * f);
-        mm |= m << (10 * f);
+        o.m[f] = (unsigned)(int)M[f];            // exact small integers
+        o.n[f] = o.m[f] + (unsigned)(int)E[f];
     }
-    o.nn = nn;
-    o.mm = mm;
     o.count = cnt;
     o.mn = mn;
 }
@@ -484,12 +479,11 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
             // integer sums: exact and order independent -> LDS atomics straight per segment
             if (active) {
                 SegInts &acc = s_ints[seg];
-                const unsigned long long nn64 = (unsigned long long)(sv.nn & 1023u) |
-                                                ((unsigned long long)((sv.nn >> 10) & 1023u) << 21) |
-                                                ((unsigned long long)((sv.nn >> 20) & 1023u) << 42);
-                const unsigned long long mm64 = (unsigned long long)(sv.mm & 1023u) |
-                                                ((unsigned long long)((sv.mm >> 10) & 1023u) << 21) |
-                                                ((unsigned long long)((sv.mm >> 20) & 1023u) << 42);
+                // three 21-bit fields per 64-bit word: n[0] | n[1] << 21 | n[2] << 42
+                const unsigned long long nn64 = (unsigned long long)sv.n[0] | ((unsigned long long)sv.n[1] << 21) |
+                                                ((unsigned long long)sv.n[2] << 42);
+                const unsigned long long mm64 = (unsigned long long)sv.m[0] | ((unsigned long long)sv.m[1] << 21) |
+                                                ((unsigned long long)sv.m[2] << 42);
                 atomicAdd(&acc.nn, nn64);
                 atomicAdd(&acc.mm, mm64);
                 atomicAdd(&acc.count, (unsigned long long)sv.count);

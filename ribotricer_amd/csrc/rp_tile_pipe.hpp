@@ -222,12 +222,10 @@ __device__ __forceinline__ void pipe_run(const SegSet &S, const int *s_counts, R
         }
         if (active) {  // integer sums: exact, order independent -> LDS atomics per segment
             SegInts &acc = s_ints[seg];
-            const unsigned long long nn64 = (unsigned long long)(sv.nn & 1023u) |
-                                            ((unsigned long long)((sv.nn >> 10) & 1023u) << 21) |
-                                            ((unsigned long long)((sv.nn >> 20) & 1023u) << 42);
-            const unsigned long long mm64 = (unsigned long long)(sv.mm & 1023u) |
-                                            ((unsigned long long)((sv.mm >> 10) & 1023u) << 21) |
-                                            ((unsigned long long)((sv.mm >> 20) & 1023u) << 42);
+            const unsigned long long nn64 = (unsigned long long)sv.n[0] | ((unsigned long long)sv.n[1] << 21) |
+                                            ((unsigned long long)sv.n[2] << 42);
+            const unsigned long long mm64 = (unsigned long long)sv.m[0] | ((unsigned long long)sv.m[1] << 21) |
+                                            ((unsigned long long)sv.m[2] << 42);
             atomicAdd(&acc.nn, nn64);
             atomicAdd(&acc.mm, mm64);
             atomicAdd(&acc.count, (unsigned long long)sv.count);
