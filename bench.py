@@ -109,13 +109,23 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        sys.exit("bench.py needs a HIP device (ribotricer_amd has no CPU path)")
+    local_dev = local_rank % n_dev  # one rank per GPU on the driver's node; wraps only in 1-GPU self-tests
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group(backend="nccl", device_id=dev)
+        # RCCL ("nccl") carries only the barrier and the max-over-ranks of the elapsed time;
+        # RP_BENCH_BACKEND=gloo lets the same control flow be exercised with ranks sharing a GPU
+        backend = os.environ.get("RP_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from ribotricer_amd import _lib
     from ribotricer_amd.engine import PhaseScoreEngine, make_filter
@@ -154,7 +164,7 @@ def main():
     elapsed = time.perf_counter() - t0
     dev_ms_per_step = ev0.elapsed_time(ev1) / args.steps
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
