@@ -656,22 +656,26 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_finalize(const int32_t *__r
     // too-close-to-call ORFs: queue them per workgroup; short ones are re-walked in float64
     // by one wave each, long ones (a single wave needs ~3 us per 1000 nt) by all four waves
     constexpr long long kBlockWalkLen = 2048;
-    __shared__ int s_list[kTileBlock];
+    __shared__ long long s_list_orf[kTileBlock], s_list_beg[kTileBlock], s_list_len[kTileBlock];
     __shared__ int s_n;
     __shared__ double s_part[kTileBlock / kWave][6];
     __shared__ int s_parti[kTileBlock / kWave][7];
     __shared__ long long s_partc[kTileBlock / kWave];
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    if (unsafe) s_list[atomicAdd(&s_n, 1)] = (int)(b - (long long)blockIdx.x * kTileBlock);
+    if (unsafe) {  // hand orf / start / length over: the re-walk then needs no dependent index loads
+        const int slot = atomicAdd(&s_n, 1);
+        s_list_orf[slot] = orf;
+        s_list_beg[slot] = beg;
+        s_list_len[slot] = len;
+    }
     __syncthreads();
     const int n_list = s_n;
     const int wave = threadIdx.x >> 6;
     for (int k = 0; k < n_list; ++k) {  // workgroup-uniform loop
-        const long long bb = (long long)blockIdx.x * kTileBlock + s_list[k];
-        const long long orf_s = ws.tile_first[bb + 1] - 1;
-        const long long beg_s = offsets[orf_s];
-        const long long len_s = (long long)offsets[orf_s + 1] - beg_s;
+        const long long orf_s = s_list_orf[k];
+        const long long beg_s = s_list_beg[k];
+        const long long len_s = s_list_len[k];
         const bool block_walk = len_s > kBlockWalkLen;
         if (!block_walk && (k & (kTileBlock / kWave - 1)) != wave) continue;
         WalkResult<double> w;

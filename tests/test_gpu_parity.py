@@ -162,6 +162,35 @@ def test_ragged_long_tail(eng, algo):
     assert_matches_oracle(res, counts, offsets)
 
 
+@pytest.mark.parametrize("algo", ["tile", "pipe"])
+@pytest.mark.parametrize("shift", [1, 2, 3])
+def test_misaligned_counts_pointer(eng, algo, shift):
+    """counts not 16-byte aligned (a view into a larger buffer): tiles live on the aligned grid."""
+    import torch
+
+    from ribotricer_amd.synth import synth_csr_host
+
+    counts, offsets = synth_csr_host(6000, seed=4242 + shift, cfg="cfg3")
+    base = torch.zeros(counts.size + shift, dtype=torch.int32, device="cuda:0")
+    view = base[shift:]
+    view.copy_(torch.from_numpy(counts))
+    assert (view.data_ptr() // 4) % 4 == shift % 4
+    res = eng.score(view, torch.from_numpy(offsets).to("cuda:0"), algo=algo)
+    torch.cuda.synchronize()
+    assert_matches_oracle(res.cpu_numpy(), counts, offsets)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_many_tiny_profiles_per_tile(eng, algo):
+    """More than 64 segments per tile (chunked segment tables), lengths 0..12."""
+    rng = np.random.default_rng(77)
+    lens = rng.integers(0, 13, size=40000)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    counts = rng.poisson(0.8, size=int(offsets[-1])).astype(np.int32)
+    res = run(eng, counts, offsets, algo)
+    assert_matches_oracle(res, counts, offsets)
+
+
 @pytest.mark.parametrize("algo", ALGOS)
 def test_large_counts(eng, algo):
     rng = np.random.default_rng(13)
