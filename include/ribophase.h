@@ -155,6 +155,26 @@ int rp_phase_score_f64_csr_dev(int device, const double *d_values, const int64_t
                                uint8_t *d_flags, void *hip_stream);
 
 /*
+ * Profile gather: builds the CSR counts array on the device from
+ * dense P-site coverage and the ORFs' exon intervals.  Replaces orf_coverage() for every
+ * ORF at once (detect_orfs.py:134-203): the positions of the intervals in ascending order,
+ * reversed for '-' strand ORFs (detect_orfs.py:201-202); positions outside d_coverage
+ * count 0 (the reference's missing-key case, detect_orfs.py:176-187).
+ *   d_coverage  int32[coverage_len]  all (strand, chrom) coverage arrays, concatenated
+ *   d_iv_start  int64[n_intervals]   index into d_coverage of each interval's first position
+ *   d_iv_len    int32[n_intervals]   interval lengths (end - start + 1, interval.py:60-62)
+ *   d_orf_iv    int64[n_orfs+1]      which intervals belong to which ORF (CSR, ascending)
+ *   d_reverse   uint8[n_orfs]        1 for '-' strand ORFs
+ *   d_offsets   int64[n_orfs+1]      output CSR offsets = prefix sum of the ORFs' lengths
+ *   d_counts    int32[offsets[n]]    output, ready for rp_phase_score_csr_dev
+ */
+int rp_gather_profiles_dev(int device, const int32_t *d_coverage, int64_t coverage_len,
+                           const int64_t *d_iv_start, const int32_t *d_iv_len,
+                           const int64_t *d_orf_iv, const uint8_t *d_reverse,
+                           const int64_t *d_offsets, int64_t n_orfs, int32_t *d_counts,
+                           void *hip_stream);
+
+/*
  * Synchronous input check (one pass over offsets and counts on the device, then a
  * host sync): RP_ERR_OFFSETS / RP_ERR_COUNTS as documented above.
  */

@@ -62,6 +62,7 @@ SYMBOLS = {
     "rp_phase_score_csr_dev_timed": (_int, _SCORE_ARGS + [ctypes.POINTER(ctypes.c_float * 4)]),
     "rp_phase_score_frames_dev": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "rp_phase_score_f64_csr_dev": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "rp_gather_profiles_dev": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "rp_validate_csr_dev": (_int, [_int, _vp, _vp, _i64, _i64, _vp]),
 }
 

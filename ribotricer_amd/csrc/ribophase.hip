@@ -336,6 +336,26 @@ int rp_phase_score_f64_csr_dev(int device, const double *d_values, const int64_t
     return RP_OK;
 }
 
+int rp_gather_profiles_dev(int device, const int32_t *d_coverage, int64_t coverage_len,
+                           const int64_t *d_iv_start, const int32_t *d_iv_len,
+                           const int64_t *d_orf_iv, const uint8_t *d_reverse,
+                           const int64_t *d_offsets, int64_t n_orfs, int32_t *d_counts,
+                           void *hip_stream)
+{
+    if (n_orfs < 0 || coverage_len < 0) return fail(RP_ERR_SIZE, "negative size");
+    if (n_orfs > 0 && (!d_orf_iv || !d_reverse || !d_offsets))
+        return fail(RP_ERR_NULL, "interval CSR, strand flags and offsets must be non-null");
+    int rc = select_device(device);
+    if (rc != RP_OK) return rc;
+    if (n_orfs == 0) return RP_OK;
+    const int grid = grid_for_waves(n_orfs, rp::kWaveBlock / rp::kWave);
+    hipLaunchKernelGGL(rp::k_gather_profiles, dim3(grid), dim3(rp::kWaveBlock), 0, (hipStream_t)hip_stream,
+                       d_coverage, (long long)coverage_len, d_iv_start, d_iv_len, d_orf_iv, d_reverse,
+                       d_offsets, (long long)n_orfs, d_counts);
+    RP_HIP(hipGetLastError());
+    return RP_OK;
+}
+
 int rp_validate_csr_dev(int device, const int32_t *d_counts, const int64_t *d_offsets,
                         int64_t n_orfs, int64_t total_nt, void *hip_stream)
 {

@@ -198,6 +198,37 @@ __global__ __launch_bounds__(kWaveBlock) void k_wave_score_f64in(const double *_
     }
 }
 
+// Profile gather (detect_orfs.py:134-203 for all ORFs): one wave per ORF copies its exon
+// intervals out of the dense coverage array, coalesced on both sides; '-' strand ORFs are
+// written back to front (detect_orfs.py:201-202).
+__global__ __launch_bounds__(kWaveBlock) void k_gather_profiles(
+    const int32_t *__restrict__ coverage, long long coverage_len, const int64_t *__restrict__ iv_start,
+    const int32_t *__restrict__ iv_len, const int64_t *__restrict__ orf_iv,
+    const uint8_t *__restrict__ reverse, const int64_t *__restrict__ offsets, long long n_orfs,
+    int32_t *__restrict__ counts)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const long long waves_total = (long long)gridDim.x * (kWaveBlock / kWave);
+    long long orf = (long long)blockIdx.x * (kWaveBlock / kWave) + (threadIdx.x >> 6);
+    for (; orf < n_orfs; orf += waves_total) {
+        const long long out0 = offsets[orf];
+        const long long len = (long long)offsets[orf + 1] - out0;
+        const bool rev = reverse[orf] != 0;
+        long long asc = 0;  // ascending position of the interval's first nucleotide in the ORF
+        for (long long k = orf_iv[orf]; k < (long long)orf_iv[orf + 1]; ++k) {
+            const long long src0 = iv_start[k];
+            const int n = iv_len[k];
+            for (int j = lane; j < n; j += kWave) {
+                const long long src = src0 + j;
+                const int v = (src >= 0 && src < coverage_len) ? coverage[src] : 0;
+                const long long a = asc + j;
+                if (a < len) counts[out0 + (rev ? len - 1 - a : a)] = v;
+            }
+            asc += n;
+        }
+    }
+}
+
 // Input validation: offsets[0] == 0, monotone, offsets[n] == total; 0 <= count <= RP_MAX_COUNT.
 // err[0] |= 1 for offsets, |= 2 for counts.
 __global__ void k_validate(const int32_t *__restrict__ counts, const int64_t *__restrict__ offsets,

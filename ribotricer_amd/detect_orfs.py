@@ -141,6 +141,16 @@ def pack_profiles(records, merged_alignments):
     return counts, offsets
 
 
+def gather_profiles(records, merged_alignments, device=None):
+    """Profiles of all records, gathered on the device (ribotricer_amd/gather.py):
+    ``(counts, offsets)`` as device tensors.  Same bytes as :func:`pack_profiles`."""
+    from .gather import build_dense_coverage, build_interval_table, gather_profiles_device
+
+    coverage, base = build_dense_coverage(merged_alignments, records)
+    table = build_interval_table(records, base)
+    return gather_profiles_device(coverage, table, device)
+
+
 def score_profiles(counts, offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
                    min_valid_codons_ratio, min_density_over_orf, device=None) -> dict:
     """One launch for the whole batch; host numpy arrays back (24 B + 2 B per ORF)."""
@@ -202,11 +212,14 @@ def export_orf_coverages(
 ) -> None:
     """Write ``{prefix}_translating_ORFs.tsv`` -- drop-in for detect_orfs.py:206-324."""
     records = read_index(ribotricer_index)
-    counts, offsets = pack_profiles(records, merged_alignments)
+    # profiles are gathered and scored on the GPU; they come back once for the profile column
+    d_counts, d_offsets = gather_profiles(records, merged_alignments)
     res = score_profiles(
-        counts, offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
+        d_counts, d_offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
         min_valid_codons_ratio, min_density_over_orf,
     )
+    counts = d_counts.cpu().numpy()
+    offsets = d_offsets.cpu().numpy()
     with open(f"{prefix}_translating_ORFs.tsv", "w") as output:
         output.write("\t".join(COLUMNS) + "\n")
         for row in format_rows(records, counts, offsets, res, report_all):

@@ -1,0 +1,119 @@
+"""Device-side profile gather.
+
+The reference fills each ORF's profile with one dict lookup per nucleotide
+(``orf_coverage``, ribotricer/detect_orfs.py:134-203).  Here the merged P-site
+alignments (``strand -> Counter{(chrom, pos): count}``, what ``merge_read_lengths``
+returns, detect_orfs.py:54-83) are laid out ONCE as dense int32 coverage arrays, one per
+(strand, chromosome), concatenated in HBM; the ORFs' exon intervals become a small
+interval table; ``rp_gather_profiles_dev`` then writes the CSR ``counts`` array for every
+ORF in one launch -- reversed for '-' strand ORFs -- ready for ``rp_phase_score_csr_dev``.
+
+Host work is O(reads + intervals) numpy, no per-nucleotide Python.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import NamedTuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import _as_device, _ptr, get_engine
+
+
+class IntervalTable(NamedTuple):
+    iv_start: np.ndarray  # int64 [n_intervals]  index into the dense coverage array
+    iv_len: np.ndarray  # int32 [n_intervals]
+    orf_iv: np.ndarray  # int64 [n_orfs + 1]
+    reverse: np.ndarray  # uint8 [n_orfs]       1 for '-' strand
+    offsets: np.ndarray  # int64 [n_orfs + 1]   CSR offsets of the profiles
+
+
+def build_dense_coverage(merged_alignments, records):
+    """Dense coverage for every (strand, chrom) that an ORF of ``records`` lives on.
+
+    Each array spans the union of the ORFs' extents on that (strand, chrom), so every
+    interval position has a slot (0 where no read maps: the missing-key case of
+    detect_orfs.py:176-187).  Returns ``(coverage int32[...], base)`` with
+    ``base[(strand, chrom)] = (index_of_position_lo, lo)``.
+    """
+    extent: dict = {}
+    for r in records:
+        key = (r.strand, r.chrom)
+        lo, hi = r.intervals[0][0], r.intervals[-1][1]
+        if key in extent:
+            e = extent[key]
+            extent[key] = (min(e[0], lo), max(e[1], hi))
+        else:
+            extent[key] = (lo, hi)
+    base = {}
+    total = 0
+    for key in sorted(extent):
+        lo, hi = extent[key]
+        base[key] = (total, lo)
+        total += hi - lo + 1
+    coverage = np.zeros(total, np.int32)
+    for strand, table in merged_alignments.items():
+        if not table:
+            continue
+        by_chrom: dict = {}
+        for (chrom, pos), count in table.items():
+            by_chrom.setdefault(chrom, []).append((pos, count))
+        for chrom, items in by_chrom.items():
+            key = (strand, chrom)
+            if key not in base:
+                continue
+            start, lo = base[key]
+            hi = extent[key][1]
+            arr = np.asarray(items, dtype=np.int64)
+            keep = (arr[:, 0] >= lo) & (arr[:, 0] <= hi)
+            arr = arr[keep]
+            np.add.at(coverage, start + (arr[:, 0] - lo), arr[:, 1].astype(np.int32))
+    return coverage, base
+
+
+def build_interval_table(records, base) -> IntervalTable:
+    n = len(records)
+    n_iv = sum(len(r.intervals) for r in records)
+    iv_start = np.empty(n_iv, np.int64)
+    iv_len = np.empty(n_iv, np.int32)
+    orf_iv = np.zeros(n + 1, np.int64)
+    reverse = np.zeros(n, np.uint8)
+    lengths = np.zeros(n, np.int64)
+    k = 0
+    for i, r in enumerate(records):
+        start0, lo = base[(r.strand, r.chrom)]
+        for s, e in r.intervals:  # ascending (orf.py:100)
+            iv_start[k] = start0 + (s - lo)
+            iv_len[k] = e - s + 1
+            lengths[i] += e - s + 1
+            k += 1
+        orf_iv[i + 1] = k
+        reverse[i] = 1 if r.strand == "-" else 0
+    offsets = np.zeros(n + 1, np.int64)
+    np.cumsum(lengths, out=offsets[1:])
+    return IntervalTable(iv_start, iv_len, orf_iv, reverse, offsets)
+
+
+def gather_profiles_device(coverage, table: IntervalTable, device=None):
+    """Run the gather on the GPU: ``(counts int32 device tensor, offsets int64 device tensor)``."""
+    eng = get_engine(device)
+    dev = eng.device
+    cov = _as_device(coverage, torch.int32, dev)
+    iv_start = _as_device(table.iv_start, torch.int64, dev)
+    iv_len = _as_device(table.iv_len, torch.int32, dev)
+    orf_iv = _as_device(table.orf_iv, torch.int64, dev)
+    reverse = _as_device(table.reverse, torch.uint8, dev)
+    offsets = _as_device(table.offsets, torch.int64, dev)
+    n = offsets.numel() - 1
+    counts = torch.empty(int(table.offsets[-1]), dtype=torch.int32, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(
+        _lib.load().rp_gather_profiles_dev(
+            dev.index, _ptr(cov), cov.numel(), _ptr(iv_start), _ptr(iv_len), _ptr(orf_iv), _ptr(reverse),
+            _ptr(offsets), n, _ptr(counts), stream,
+        )
+    )
+    return counts, offsets

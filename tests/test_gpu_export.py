@@ -49,3 +49,49 @@ def test_phasescore_mirror(g1, g5):
         assert abs(phase[i] - r["phase"]) <= 1e-9
         if not flags[i] & 1:
             assert valid[i] == r["valid"]
+
+
+def test_device_gather_equals_host_packer():
+    """rp_gather_profiles_dev vs the per-nucleotide host packer (the reference's orf_coverage
+    semantics, pinned by test_host_export_cpu) on the G6 fixture."""
+    import torch
+
+    from ribotricer_amd import detect_orfs as d
+
+    records = d.read_index(os.path.join(GOLDEN, "g6_index.tsv"))
+    align = load_alignments()
+    counts, offsets = d.pack_profiles(records, align)
+    dc, do = d.gather_profiles(records, align)
+    torch.cuda.synchronize()
+    assert np.array_equal(do.cpu().numpy(), offsets)
+    assert np.array_equal(dc.cpu().numpy(), counts)
+
+
+def test_device_gather_random_intervals():
+    import torch
+
+    from ribotricer_amd.gather import IntervalTable, gather_profiles_device
+
+    rng = np.random.default_rng(8)
+    cov = rng.poisson(0.6, size=200000).astype(np.int32)
+    n = 3000
+    n_iv = rng.integers(1, 6, size=n)
+    orf_iv = np.concatenate([[0], np.cumsum(n_iv)]).astype(np.int64)
+    iv_len = rng.integers(1, 400, size=int(orf_iv[-1])).astype(np.int32)
+    iv_start = rng.integers(-50, cov.size - 100, size=int(orf_iv[-1])).astype(np.int64)  # some hang off both ends
+    reverse = rng.integers(0, 2, size=n).astype(np.uint8)
+    lengths = np.add.reduceat(iv_len.astype(np.int64), orf_iv[:-1])
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    dc, _ = gather_profiles_device(cov, IntervalTable(iv_start, iv_len, orf_iv, reverse, offsets))
+    torch.cuda.synchronize()
+    got = dc.cpu().numpy()
+    for i in range(n):
+        parts = []
+        for k in range(orf_iv[i], orf_iv[i + 1]):
+            idx = iv_start[k] + np.arange(iv_len[k])
+            ok = (idx >= 0) & (idx < cov.size)
+            parts.append(np.where(ok, cov[np.clip(idx, 0, cov.size - 1)], 0))
+        want = np.concatenate(parts)
+        if reverse[i]:
+            want = want[::-1]
+        assert np.array_equal(got[offsets[i] : offsets[i + 1]], want), i

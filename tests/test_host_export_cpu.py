@@ -101,3 +101,22 @@ def test_formatted_rows_match_reference_tsv(packed, name):
     # (the closed form and scipy's FFT route differ in the last ulps, so only some phase
     #  scores print identically: a float64 repr is 17 digits)
     assert 0 <= exact_phase <= len(got)
+
+
+def test_dense_coverage_and_interval_table_reproduce_the_packer(packed):
+    """Host half of the device gather (gather.py): dense coverage + interval table, replayed
+    with numpy here, must give the same bytes as the per-nucleotide packer."""
+    from ribotricer_amd.gather import build_dense_coverage, build_interval_table
+
+    records, counts, offsets = packed
+    coverage, base = build_dense_coverage(load_alignments(), records)
+    table = build_interval_table(records, base)
+    assert np.array_equal(table.offsets, offsets)
+    assert table.orf_iv[-1] == sum(len(r.intervals) for r in records)
+    for i in range(len(records)):
+        parts = [coverage[s : s + n] for s, n in zip(table.iv_start[table.orf_iv[i] : table.orf_iv[i + 1]],
+                                                     table.iv_len[table.orf_iv[i] : table.orf_iv[i + 1]])]
+        prof = np.concatenate(parts)
+        if table.reverse[i]:
+            prof = prof[::-1]
+        assert np.array_equal(prof, counts[offsets[i] : offsets[i + 1]]), records[i].oid
