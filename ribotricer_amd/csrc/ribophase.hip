@@ -151,7 +151,7 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
         RP_HIP(hipGetLastError());
         if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));
         {
-            const int block = 256;
+            const int block = rp::kTileBlock;
             const int grid = (int)((plan.n_tiles + block - 1) / block);
             hipLaunchKernelGGL(rp::k_tile_finalize<rp::kPipeTile>, dim3(grid), dim3(block), 0, stream, d_counts,
                                d_offsets, (long long)n_orfs, plan, ws, out, fp);
@@ -182,7 +182,7 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));
     // 3. ORFs that straddle a tile boundary: combine partials
     {
-        const int block = 256;
+        const int block = rp::kTileBlock;
         const int grid = (int)((plan.n_tiles + block - 1) / block);
         hipLaunchKernelGGL(rp::k_tile_finalize<rp::kTile>, dim3(grid), dim3(block), 0, stream, d_counts,
                            d_offsets, (long long)n_orfs, plan, ws, out, fp);

@@ -200,7 +200,16 @@ __device__ __forceinline__ FrameScore frame_score(double p, double q, int n, int
     } else if (m == 0) {
         r.score = __builtin_nan("");
     } else {
-        r.score = __builtin_fma(p, p + q, q * q) / ((double)n * (double)m);  // IEEE division: exact ties stay exact
+        // x / (n m) through v_rcp_f64 + two Newton steps + one residual correction (~1 ulp;
+        // frames that tie exactly may now differ by 1e-16, which RP_TIE_RTOL absorbs) -- a
+        // third of the instructions of the IEEE division sequence, and this runs on one wave
+        const double x = __builtin_fma(p, p + q, q * q);
+        const double y = (double)n * (double)m;  // exact: n, m < 2^26
+        double inv = __builtin_amdgcn_rcp(y);
+        inv = __builtin_fma(__builtin_fma(-y, inv, 1.0), inv, inv);
+        inv = __builtin_fma(__builtin_fma(-y, inv, 1.0), inv, inv);
+        const double s0 = x * inv;
+        r.score = __builtin_fma(__builtin_fma(-s0, y, x), inv, s0);
     }
     return r;
 }
@@ -239,7 +248,7 @@ __device__ __forceinline__ void combine_frames(const FrameScore (&fr)[3], double
     for (int f = 0; f < 3; ++f) {
         if (f >= first_live && fr[f].n != v && fabs(fr[f].score - coh) <= tie_tol(coh)) fl |= RP_FLAG_TIE;
     }
-    phase = sqrt(coh);
+    phase = coh > 0.0 ? coh * rsqrt_f64(coh) : 0.0;  // sqrt to ~1 ulp (np.sqrt: statistics.py:115)
     valid = v;
     flags = fl;
 }

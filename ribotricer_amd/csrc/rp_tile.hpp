@@ -158,7 +158,7 @@ __device__ __forceinline__ void load_tile_to_lds(const int32_t *__restrict__ cou
         if (w >= 0) {
 #pragma unroll
             for (int row = 0; row < kTile / kRowPos; ++row) {
-                if (row % 3 == w)
+                if (row % (kTileBlock / kWave - 1) == w)
                     __builtin_amdgcn_global_load_lds((gptr_t)(src + row * kRowPos), (lptr_t)(s_counts + row * kRowPos), 16, 0, 0);
             }
         }
