@@ -2,23 +2,26 @@
 //
 // The CSR counts array is cut into fixed tiles of kTile positions on the 16-byte
 // aligned address grid, one workgroup per tile, so every workgroup streams the same
-// number of bytes with aligned dwordx4 loads regardless of how ragged the ORFs are
-// (20 short ORFs or a slice of one 100 k-nt ORF cost the same).  Inside a tile:
+// number of bytes regardless of how ragged the ORFs are (25 short ORFs or a slice of
+// one 100 k-nt ORF cost the same).  Inside a tile:
 //
-//   1. the tile (+ a 4-dword halo) is staged in LDS, each count read from HBM once;
-//   2. wave 0 lists the tile's segments -- the ORF that straddles in from the left
-//      ("head") and the ORFs that start inside -- and gives each segment
-//      ceil(T/kRun) lanes, T = codon triplets whose first position lies in the tile;
-//   3. every lane walks a contiguous run of <= kRun triplets of ONE segment out of
-//      LDS (odd dword stride between lanes -> bank-conflict free), one codon of each
-//      reading frame per step, fp32 unit vectors (one v_rsq_f32 per codon);
-//   4. a segmented wave scan (lanes of a segment are consecutive) folds lane
-//      partials into one record per (segment, wave);
-//   5. one thread per segment sums its records in float64 and either finishes the
-//      ORF (frame scores -> state machine -> status -> store) or, when the ORF
-//      straddles a tile boundary, writes a partial record for k_tile_finalize;
-//   6. ORFs whose fp32 frame decision is too close to call are re-walked in float64
-//      by a whole wave (rp_wave.hpp).
+//   1. waves 1-3 stage the tile (+ a 4-dword halo) in LDS with the LDS-DMA form of
+//      global_load (each count leaves HBM once); meanwhile wave 0 reads the tile index
+//      and the offsets of its 64 segment slots and builds the segment table: slot 0 is
+//      the ORF that straddles in from the left ("head"), the others the ORFs that start
+//      inside; each segment gets ceil(T/kRun) lanes, T = codon triplets whose first
+//      position lies in the tile;
+//   2. every lane walks a contiguous run of <= kRun triplets of ONE segment out of LDS
+//      (odd dword stride between lanes -> bank-conflict free), one codon of each reading
+//      frame per step, predicate-free fp32 arithmetic (one v_rsq_f32 per codon);
+//   3. integer sums go to per-segment LDS atomics (exact, order independent); the six
+//      float sums are folded by a segmented DPP scan inside each 16-lane row into one
+//      record per (segment, row) -- deterministic, no float atomics;
+//   4. one thread per segment sums its records in float64 and either finishes the ORF
+//      (frame scores -> state machine -> status -> store) or, when the ORF crosses a
+//      tile boundary, writes a partial record for k_tile_finalize;
+//   5. ORFs whose fp32 frame decision is too close to call are re-walked in float64 out
+//      of LDS by a whole wave (wave_walk, rp_wave.hpp).
 //
 // Ownership rule: a triplet (3 positions from an ORF-relative multiple of 3) belongs
 // to the tile that holds its FIRST position; its frame-1/2 codons may reach 4
@@ -32,7 +35,7 @@
 namespace rp {
 
 constexpr int kTileBlock = 256;
-constexpr int kTile = 7936;    // positions per tile (40 KiB of int32)
+constexpr int kTile = 7936;    // positions per tile (31 KiB of int32): 3 lane-run passes of 64 x 15 triplets
 constexpr int kRun = 15;        // triplets per lane run; odd => lane stride 45 dwords, conflict free
 constexpr int kSegChunk = 64;   // segments set up per round (one per lane of wave 0)
 constexpr int kHalo = 8;        // dwords staged past the tile end (4 needed, 2 chunks loaded)
