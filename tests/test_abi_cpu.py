@@ -83,3 +83,13 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "phase_oracle" not in text, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/ribophase.h must compile as C (no C++/HIP/torch types in the boundary)."""
+    import subprocess
+
+    src = tmp_path / "t.c"
+    src.write_text('#include "ribophase.h"\nint main(void){ rp_filter_params p; (void)p; return RP_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(REPO, "include"),
+                           "-c", str(src), "-o", str(tmp_path / "t.o")])
