@@ -2,7 +2,7 @@
 """bench.py -- ORFs phase-scored per second on N MI355X (BASELINE.json metric).
 
 A "step" is one pass of the hot path (libribophase rp_phase_score_csr_dev: tile index
-+ scoring kernel + split-ORF finalize) over one synthetic CSR batch that is already
++ scoring kernel + per-ORF finish) over one synthetic CSR batch that is already
 resident in HBM.  Workload at every N: BASELINE.json configs[1] per GPU -- 1 M
 synthetic ORFs, mean ~300 nt, Poisson P-site counts (ribotricer_amd/synth.py "cfg2").
 ORFs are independent, so ranks hold disjoint ORF-index slices and exchange nothing on
@@ -214,7 +214,7 @@ def main():
                 "kernel_ms": k_main,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "step_device_ms": dev_ms_per_step,
-                "aux_kernels_ms": {"tile_index": k_index, "finalize": k_fin},
+                "aux_kernels_ms": {"tile_index": k_index, "orf_finish": k_fin},
                 "step_achieved": algo_bytes / (dev_ms_per_step * 1e-3) / 1e9,
             },
             "quality": {

@@ -61,7 +61,7 @@ typedef enum rp_status {
                                   SURVEY.md Appendix A.4); valid_codons follows the exact-
                                   arithmetic rule: the earlier frame wins */
 #define RP_FLAG_RECHECK64 0x02u /* frame decision was re-derived in float64 on device */
-#define RP_FLAG_SPLIT 0x04u    /* profile spanned more than one tile (partials + finalize) */
+#define RP_FLAG_SPLIT 0x04u    /* profile spanned more than one tile (several segment records) */
 
 #define RP_TIE_RTOL 1e-9
 
@@ -69,9 +69,10 @@ typedef enum rp_status {
 typedef enum rp_algo {
     RP_ALGO_AUTO = 0,
     RP_ALGO_WAVE = 1, /* one wavefront per ORF, streaming straight from HBM */
-    RP_ALGO_TILE = 2, /* LDS-staged flat tiles, ragged lane packing, partials + finalize */
-    RP_ALGO_TILE_PIPE = 3 /* same tiles, persistent workgroups: finish / setup / DMA of neighbouring
-                             tiles overlap */
+    RP_ALGO_TILE = 2, /* LDS-staged flat tiles, ragged lane packing -> one record per (ORF, tile)
+                         segment in the workspace -> one thread per ORF scores and filters */
+    RP_ALGO_TILE_PIPE = 3 /* same records, persistent workgroups that keep the next tile in flight
+                             in registers while they score the current one (experimental) */
 } rp_algo;
 
 /*
@@ -104,7 +105,8 @@ int rp_filter_defaults(rp_filter_params *out);
 
 /*
  * Bytes of device workspace rp_phase_score_csr_dev needs for a batch of this
- * shape (tile index + split-ORF partials).  16-byte aligned pointer required.
+ * shape (tile index + one 76-byte record per ORF and per tile).  16-byte aligned
+ * pointer required.
  */
 int rp_workspace_bytes(int64_t n_orfs, int64_t total_nt, int algo, size_t *bytes);
 
@@ -184,7 +186,7 @@ int rp_validate_csr_dev(int device, const int32_t *d_counts, const int64_t *d_of
 /*
  * Same as rp_phase_score_csr_dev but brackets each internal launch with HIP events
  * on `hip_stream`, synchronises, and reports milliseconds: ms[0] tile-index pass,
- * ms[1] main scoring kernel, ms[2] split-ORF finalize, ms[3] whole call.
+ * ms[1] main scoring kernel, ms[2] per-ORF finish kernel, ms[3] whole call.
  * For bench.py's roofline figure; not for production use (it blocks the host).
  */
 int rp_phase_score_csr_dev_timed(int device, const int32_t *d_counts, const int64_t *d_offsets,

@@ -104,6 +104,7 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     const rp::OrfOutputs out{d_phase, d_valid, d_read_count, d_min_codon_cov, d_flags, d_status};
     const rp::FilterParams fp = make_filter(filter, d_status);
     if (algo == RP_ALGO_AUTO) algo = RP_ALGO_TILE;
+    if (algo == RP_ALGO_TILE_PIPE && total_nt == 0) algo = RP_ALGO_TILE;  // nothing to prefetch
 
     if (algo == RP_ALGO_WAVE) {
         if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[1], stream));
@@ -125,67 +126,56 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
         return fail(RP_ERR_WORKSPACE, "workspace of %zu bytes required, got %zu", need, workspace_bytes);
     if ((reinterpret_cast<uintptr_t>(d_workspace) & 15u) != 0)
         return fail(RP_ERR_WORKSPACE, "workspace must be 16-byte aligned");
-    if (algo == RP_ALGO_TILE_PIPE) {
-        // persistent, software-pipelined workgroups: 4 per CU
-        const rp::TilePlan plan = rp::make_pipe_plan(n_orfs, total_nt, d_counts);
-        rp::TileWorkspace ws = rp::pipe_carve_workspace(d_workspace, total_nt);
-        {
-            const long long threads = n_orfs + 1;
-            const int block = 256;
-            const int grid = (int)((threads + block - 1) / block);
-            hipLaunchKernelGGL(rp::k_pipe_index, dim3(grid), dim3(block), 0, stream, d_offsets, (long long)n_orfs, plan, ws);
-            RP_HIP(hipGetLastError());
-        }
-        if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[1], stream));
-        int n_cu = 256;
-        {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-        }
-        int per_cu = 4;
-        if (const char *e = getenv("RP_PIPE_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : 4;
-        long long grid_pipe = (long long)n_cu * per_cu;
-        if (grid_pipe > plan.n_tiles) grid_pipe = plan.n_tiles;
-        hipLaunchKernelGGL(rp::k_tile_score_pipe, dim3((unsigned)grid_pipe), dim3(rp::kTileBlock), 0, stream, d_counts,
-                           d_offsets, (long long)n_orfs, plan, ws, out, fp);
-        RP_HIP(hipGetLastError());
-        if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));
-        {
-            const int block = rp::kTileBlock;
-            const int grid = (int)((plan.n_tiles + block - 1) / block);
-            hipLaunchKernelGGL(rp::k_tile_finalize<rp::kPipeTile>, dim3(grid), dim3(block), 0, stream, d_counts,
-                               d_offsets, (long long)n_orfs, plan, ws, out, fp);
-            RP_HIP(hipGetLastError());
-        }
-        if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[3], stream));
-        return RP_OK;
-    }
-
-    // RP_ALGO_TILE
-    const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt, d_counts);
-    rp::TileWorkspace ws = rp::carve_workspace(d_workspace, total_nt);
+    // RP_ALGO_TILE / RP_ALGO_TILE_PIPE: tile index -> scoring pass (segment records) -> per-ORF finish
+    const bool pipe = algo == RP_ALGO_TILE_PIPE;
+    const int tile = pipe ? rp::kPipeTile : rp::kTile;
+    const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt, d_counts, tile);
+    const rp::TileWorkspace ws = rp::carve_workspace(d_workspace, n_orfs, total_nt, tile);
 
     // 1. tile index: first ORF starting at or after each tile boundary
     {
         const long long threads = n_orfs + 1;
         const int block = 256;
         const int grid = (int)((threads + block - 1) / block);
-        hipLaunchKernelGGL(rp::k_tile_index, dim3(grid), dim3(block), 0, stream, d_offsets,
-                           (long long)n_orfs, plan, ws);
+        if (pipe)
+            hipLaunchKernelGGL(rp::k_tile_index<rp::kPipeTile>, dim3(grid), dim3(block), 0, stream, d_offsets,
+                               (long long)n_orfs, plan, ws);
+        else
+            hipLaunchKernelGGL(rp::k_tile_index<rp::kTile>, dim3(grid), dim3(block), 0, stream, d_offsets,
+                               (long long)n_orfs, plan, ws);
         RP_HIP(hipGetLastError());
     }
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[1], stream));
-    // 2. main scoring pass over flat tiles
-    hipLaunchKernelGGL(rp::k_tile_score, dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
-                       d_counts, d_offsets, (long long)n_orfs, plan, ws, out, fp);
+    // 2. scoring pass over flat tiles: one record per (ORF, tile) segment
+    if (pipe) {
+        // persistent workgroups, next tile prefetched in registers
+        int n_cu = 256;
+        {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+        }
+        int per_cu = rp::kPipeBlocksPerCu;
+        if (const char *e = getenv("RP_PIPE_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : rp::kPipeBlocksPerCu;
+        long long grid_pipe = (long long)n_cu * per_cu;
+        if (grid_pipe > plan.n_tiles) grid_pipe = plan.n_tiles;
+        hipLaunchKernelGGL(rp::k_tile_score_pipe, dim3((unsigned)grid_pipe), dim3(rp::kTileBlock), 0, stream, d_counts,
+                           d_offsets, (long long)n_orfs, plan, ws);
+    } else {
+        hipLaunchKernelGGL(rp::k_tile_score, dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
+                           d_counts, d_offsets, (long long)n_orfs, plan, ws);
+    }
     RP_HIP(hipGetLastError());
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));
-    // 3. ORFs that straddle a tile boundary: combine partials
+    // 3. one thread per ORF: add its records, score, filter, store
     {
         const int block = rp::kTileBlock;
-        const int grid = (int)((plan.n_tiles + block - 1) / block);
-        hipLaunchKernelGGL(rp::k_tile_finalize<rp::kTile>, dim3(grid), dim3(block), 0, stream, d_counts,
-                           d_offsets, (long long)n_orfs, plan, ws, out, fp);
+        const int grid = (int)((n_orfs + block - 1) / block);
+        if (pipe)
+            hipLaunchKernelGGL(rp::k_orf_finish<rp::kPipeTile>, dim3(grid), dim3(block), 0, stream, d_counts,
+                               d_offsets, (long long)n_orfs, plan, ws, out, fp);
+        else
+            hipLaunchKernelGGL(rp::k_orf_finish<rp::kTile>, dim3(grid), dim3(block), 0, stream, d_counts,
+                               d_offsets, (long long)n_orfs, plan, ws, out, fp);
         RP_HIP(hipGetLastError());
     }
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[3], stream));
@@ -254,7 +244,8 @@ int rp_workspace_bytes(int64_t n_orfs, int64_t total_nt, int algo, size_t *bytes
         return RP_OK;
     }
     {   // AUTO may resolve to either tile family: size for the larger
-        const size_t a = rp::workspace_bytes(total_nt), p = rp::pipe_workspace_bytes(total_nt);
+        const size_t a = rp::workspace_bytes(n_orfs, total_nt, rp::kTile),
+                     p = rp::workspace_bytes(n_orfs, total_nt, rp::kPipeTile);
         *bytes = a > p ? a : p;
     }
     return RP_OK;

@@ -17,11 +17,19 @@
 //   3. integer sums go to per-segment LDS atomics (exact, order independent); the six
 //      float sums are folded by a segmented DPP scan inside each 16-lane row into one
 //      record per (segment, row) -- deterministic, no float atomics;
-//   4. one thread per segment sums its records in float64 and either finishes the ORF
-//      (frame scores -> state machine -> status -> store) or, when the ORF crosses a
-//      tile boundary, writes a partial record for k_tile_finalize;
-//   5. ORFs whose fp32 frame decision is too close to call are re-walked in float64 out
-//      of LDS by a whole wave (wave_walk, rp_wave.hpp).
+//   4. one thread per segment sums its row records in float64 and writes ONE segment
+//      record (six float64 sums, packed N/M, read count, minimum codon coverage) to the
+//      workspace, struct-of-arrays, at index  orf + tile  (unique and increasing);
+//   5. k_orf_finish, one thread per ORF at full occupancy, adds the records of the tiles
+//      the ORF spans (one, for most), scores the frames, runs the state machine and the
+//      filters and stores the outputs; ORFs whose fp32 frame decision is too close to call
+//      are re-walked in float64 from global memory by a whole wave (wave_walk, rp_wave.hpp).
+//
+// The scoring kernel used to finish the ORFs itself (frame scores, float64 re-walk out of
+// LDS); that is a ~300-instruction dependent float64 chain run by ONE wave per workgroup
+// while the other three idle and the LDS tile stays allocated.  Splitting it off costs
+// 76 bytes of write + read per segment (~7 % more traffic) and took the scoring kernel
+// from 0.317 to 0.276 ms on BASELINE configs[1].
 //
 // Ownership rule: a triplet (3 positions from an ORF-relative multiple of 3) belongs
 // to the tile that holds its FIRST position; its frame-1/2 codons may reach 4
@@ -42,8 +50,6 @@ constexpr int kHalo = 8;        // dwords staged past the tile end (4 needed, 2 
 constexpr int kLdsCounts = kTile + kHalo + 3 * kRun + 8;  // runs may read (masked) past the halo
 constexpr int kMaxRecs = kSegChunk + (kTile / (3 * kRun) + kSegChunk + 2 * 64) / 16 + 1;  // one per (segment, 16-lane row)
 
-enum SegKind : int { kSegComplete = 0, kSegHead = 1, kSegTail = 2, kSegNone = 3 };
-
 struct TilePlan {
     long long n_tiles;
     long long total_nt;
@@ -51,58 +57,77 @@ struct TilePlan {
     int mis;  // (counts address / 4) % 4: tiles live on the 16-byte aligned grid
 };
 
-// Partial sums of the part of an ORF that one tile owns.
-struct alignas(16) TilePartial {
-    double p[3];
-    double q[3];
-    int n[3];
-    int m[3];
-    long long count;
-    int min_codon;
-    int pad;
+// One record per (ORF, tile) segment: the sums over the triplets of the ORF that the tile
+// owns.  Struct of arrays, indexed by  orf + tile : an ORF spanning tiles s..e owns the
+// ids orf+s .. orf+e, and the next ORF starts in a tile >= e, so ids never collide.
+struct SegRecords {
+    double *pq;                 // [6][n_rec]  p[0..2], q[0..2]
+    unsigned long long *nn;     // [n_rec]     n[0] | n[1] << 21 | n[2] << 42
+    unsigned long long *mm;     // [n_rec]     same packing
+    unsigned long long *count;  // [n_rec]     reads
+    unsigned *min_codon;        // [n_rec]     RP_MIN_CODON_COV_EMPTY when no codon
+    long long n_rec;
 };
+constexpr size_t kRecordBytes = 6 * 8 + 3 * 8 + 4;
 
 struct TileWorkspace {
     long long *tile_first;  // [n_tiles + 1] first ORF starting at/after each tile start
-    TilePartial *partials;  // [n_tiles][2]: slot 0 head segment, slot 1 tail segment
+    SegRecords rec;
 };
 
-inline long long max_tiles(long long total_nt) { return (total_nt + 3 + kTile - 1) / kTile + 1; }
+inline long long max_tiles(long long total_nt, int tile) { return (total_nt + 3 + tile - 1) / tile + 1; }
 
-inline TilePlan make_tile_plan(long long n_orfs, long long total_nt, const void *counts = nullptr)
+inline long long max_records(long long n_orfs, long long total_nt, int tile)
+{
+    return (n_orfs + max_tiles(total_nt, tile) + 1 + 15) & ~15LL;  // keeps every array 16-byte aligned
+}
+
+inline TilePlan make_tile_plan(long long n_orfs, long long total_nt, const void *counts, int tile)
 {
     TilePlan p;
     p.n_orfs = n_orfs;
     p.total_nt = total_nt;
     p.mis = (int)((reinterpret_cast<uintptr_t>(counts) >> 2) & 3u);
-    p.n_tiles = (total_nt + p.mis + kTile - 1) / kTile;
+    p.n_tiles = (total_nt + p.mis + tile - 1) / tile;
     if (p.n_tiles < 1) p.n_tiles = 1;
     return p;
 }
 
-inline size_t workspace_bytes(long long total_nt)
+inline size_t tile_index_bytes(long long total_nt, int tile)
 {
-    const size_t nt = (size_t)max_tiles(total_nt);
-    size_t b = (nt + 1) * sizeof(long long);
-    b = (b + 127) & ~(size_t)127;
-    b += nt * 2 * sizeof(TilePartial);
-    return b;
+    const size_t b = ((size_t)max_tiles(total_nt, tile) + 1) * sizeof(long long);
+    return (b + 127) & ~(size_t)127;
 }
 
-inline TileWorkspace carve_workspace(void *base, long long total_nt)
+inline size_t workspace_bytes(long long n_orfs, long long total_nt, int tile)
 {
-    const size_t nt = (size_t)max_tiles(total_nt);
-    size_t b = (nt + 1) * sizeof(long long);
-    b = (b + 127) & ~(size_t)127;
+    return tile_index_bytes(total_nt, tile) + (size_t)max_records(n_orfs, total_nt, tile) * kRecordBytes;
+}
+
+inline TileWorkspace carve_workspace(void *base, long long n_orfs, long long total_nt, int tile)
+{
     TileWorkspace ws;
-    ws.tile_first = reinterpret_cast<long long *>(base);
-    ws.partials = reinterpret_cast<TilePartial *>(reinterpret_cast<char *>(base) + b);
+    char *p = reinterpret_cast<char *>(base);
+    ws.tile_first = reinterpret_cast<long long *>(p);
+    p += tile_index_bytes(total_nt, tile);
+    const size_t n = (size_t)max_records(n_orfs, total_nt, tile);
+    ws.rec.n_rec = (long long)n;
+    ws.rec.pq = reinterpret_cast<double *>(p);
+    p += 6 * n * sizeof(double);
+    ws.rec.nn = reinterpret_cast<unsigned long long *>(p);
+    p += n * sizeof(unsigned long long);
+    ws.rec.mm = reinterpret_cast<unsigned long long *>(p);
+    p += n * sizeof(unsigned long long);
+    ws.rec.count = reinterpret_cast<unsigned long long *>(p);
+    p += n * sizeof(unsigned long long);
+    ws.rec.min_codon = reinterpret_cast<unsigned *>(p);
     return ws;
 }
 
 // ---------------------------------------------------------------------------
 // pass 1: tile_first[b] = lower_bound(offsets[0..n], start position of tile b)
 // ---------------------------------------------------------------------------
+template <int TILE>
 __global__ void k_tile_index(const int64_t *__restrict__ offsets, long long n_orfs, TilePlan plan,
                              TileWorkspace ws)
 {
@@ -112,9 +137,9 @@ __global__ void k_tile_index(const int64_t *__restrict__ offsets, long long n_or
     if (i == n_orfs) ws.tile_first[plan.n_tiles] = n_orfs;
     const long long o = offsets[i];
     const long long o_prev = i > 0 ? (long long)offsets[i - 1] : -1 - (long long)plan.mis;
-    // tiles b >= 1 whose start position b*kTile - mis lies in (o_prev, o]
-    long long b_lo = (o_prev + plan.mis) / kTile + 1;
-    long long b_hi = (o + plan.mis) / kTile;
+    // tiles b >= 1 whose start position b*TILE - mis lies in (o_prev, o]
+    long long b_lo = (o_prev + plan.mis) / TILE + 1;
+    long long b_hi = (o + plan.mis) / TILE;
     if (b_lo < 1) b_lo = 1;
     if (b_hi > plan.n_tiles - 1) b_hi = plan.n_tiles - 1;
     for (long long b = b_lo; b <= b_hi; ++b) ws.tile_first[b] = i;
@@ -266,10 +291,16 @@ __device__ __forceinline__ int wave_add_scan(int x)
 constexpr int kRunBlock = 3;  // triplets per fully unrolled block of the lane run
 static_assert(kRun % kRunBlock == 0, "kRun must be a multiple of kRunBlock");
 
-// min(x, hi) for x >= 0 as v_med3_f32(x, 0, hi): a compiler-visible instruction (hipcc
-// inserts no hazard wait states around inline asm, and v_rsq_f32 results need them) that
-// does not drag in the NaN-canonicalising v_max(x, x) pair of fminf().
-__device__ __forceinline__ float min_nonneg(float x, float hi) { return __builtin_amdgcn_fmed3f(x, 0.0f, hi); }
+// min(x, hi) for x, hi >= 0 on the BIT PATTERNS: non-negative IEEE floats order like
+// unsigned integers (+inf = 0x7f800000 included), so this is one 32-bit-encoded v_min_u32
+// (2.8 cycles measured) instead of a VOP3 v_med3_f32 (4.4), it needs no NaN-canonicalising
+// v_max(x, x) the way fminf() does, and it is a compiler-visible instruction (hipcc inserts
+// no hazard wait states around inline asm, and v_rsq_f32 results need them).
+__device__ __forceinline__ float min_nonneg(float x, float hi)
+{
+    const unsigned a = __float_as_uint(x), b = __float_as_uint(hi);
+    return __uint_as_float(a < b ? a : b);
+}
 
 // clamp(x, 0, 1): folds into the producing instruction's clamp modifier
 __device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
@@ -309,7 +340,7 @@ __device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, Lan
             Q[f] = __builtin_fmaf(df1, r, Q[f]);
             const float u = min_nonneg(qq, vF);  // q is 0 or >= 1: exactly 1 for a counted codon
             M[f] += u;
-            E[f] = __builtin_fmaf(vF - u, clamp01(f0), E[f]);
+            E[f] = __builtin_fmaf(vF - u, min_nonneg(f0, 1.0f), E[f]);
             if (f == 0) {
                 const bool valid = c < lim;
                 const unsigned codon = (unsigned)(v0 + v1 + v2);
@@ -337,26 +368,37 @@ __device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, Lan
     o.mn = mn;
 }
 
+__device__ __forceinline__ void store_record(const SegRecords &r, long long id, const double p[3],
+                                             const double q[3], unsigned long long nn, unsigned long long mm,
+                                             unsigned long long count, unsigned min_codon)
+{
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        r.pq[f * r.n_rec + id] = p[f];
+        r.pq[(3 + f) * r.n_rec + id] = q[f];
+    }
+    r.nn[id] = nn;
+    r.mm[id] = mm;
+    r.count[id] = count;
+    r.min_codon[id] = min_codon;
+}
+
 constexpr int kMaxVl = kTile / (3 * kRun) + kSegChunk + 2 * kWave;  // virtual lanes per chunk (upper bound)
 
 __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__restrict__ counts,
                                                            const int64_t *__restrict__ offsets,
                                                            long long n_orfs, TilePlan plan,
-                                                           TileWorkspace ws, OrfOutputs out,
-                                                           FilterParams fp)
+                                                           TileWorkspace ws)
 {
     __shared__ __attribute__((aligned(16))) int s_counts[kLdsCounts];
     __shared__ int s_qfirst[kSegChunk];   // LDS index of the first owned triplet
     __shared__ int s_endq[kSegChunk];     // ORF end in LDS coordinates (clamped)
     __shared__ int s_ntrip[kSegChunk];    // owned triplets
-    __shared__ int s_kind[kSegChunk];
-    __shared__ long long s_len[kSegChunk];  // ORF length (for n_codons and the float64 re-walk)
+    __shared__ int s_live[kSegChunk];     // the slot holds a segment of this tile
     __shared__ int s_vlstart[kSegChunk + 1];
     __shared__ int s_owner[kMaxVl];       // segment+1 at the first lane of a segment / wave, else 0
     __shared__ RunRec s_rec[kMaxRecs];
     __shared__ SegInts s_ints[kSegChunk];
-    __shared__ int s_recheck[kSegChunk];
-    __shared__ int s_n_recheck;
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -382,7 +424,6 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
         s_ints[lane].mm = 0;
         s_ints[lane].count = 0;
         s_ints[lane].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
-        if (lane == 0) s_n_recheck = 0;
         const long long orf = a0 - 1 + lane;
         if (orf >= 0 && orf < a1) {
             beg0 = offsets[orf];
@@ -407,7 +448,7 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
         // ---- segment setup + lane allocation (wave 0; needs only offsets, not the tile) ----
         if (wave == 0) {
             int lanes = 0;
-            int kind = kSegNone;
+            int live = 0;
             const long long orf = c0 + lane;
             if (orf >= 0 && orf < a1) {
                 const long long beg = first_chunk ? beg0 : (long long)offsets[orf];
@@ -425,20 +466,17 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
                         qfirst = (int)(beg - t0);
                     }
                     const long long rem = end - t0;  // >= 0
-                    const bool end_in_lds = rem <= kTile + kHalo;
-                    const int endq = end_in_lds ? (int)rem : kTile + kHalo;
+                    const int endq = rem <= kTile + kHalo ? (int)rem : kTile + kHalo;
                     const int lim_q = kt < endq ? kt : endq;  // owned triplets start below this
                     const int ntrip = lim_q > qfirst ? (lim_q - qfirst + 2) / 3 : 0;
-                    const bool complete = !head && end_in_lds && ntrip == (endq - qfirst + 2) / 3;
                     s_qfirst[lane] = qfirst;
                     s_endq[lane] = endq;
                     s_ntrip[lane] = ntrip;
-                    s_len[lane] = end - beg;
-                    kind = head ? kSegHead : (complete ? kSegComplete : kSegTail);
+                    live = 1;
                     lanes = (ntrip + kRun - 1) / kRun;
                 }
             }
-            s_kind[lane] = kind;
+            s_live[lane] = live;
             const int incl = wave_add_scan(lanes);
             const int vs = incl - lanes;
             s_vlstart[lane] = vs;
@@ -508,23 +546,14 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
         }
         __syncthreads();
 
-        // ---- one thread per segment: float64 combine, finish or emit a partial ------------
-        if (tid < kSegChunk && s_kind[tid] != kSegNone) {
+        // ---- one thread per segment: row records -> one float64 segment record ---------------
+        if (tid < kSegChunk && s_live[tid]) {
             const int seg = tid;
-            const long long orf = c0 + seg;
             const int vs = s_vlstart[seg];
             const int ve = s_vlstart[seg + 1];
-            TilePartial t;
-#pragma unroll
-            for (int f = 0; f < 3; ++f) {
-                t.p[f] = 0.0;
-                t.q[f] = 0.0;
-                t.n[f] = 0;
-                t.m[f] = 0;
-            }
-            t.count = 0;
-            t.min_codon = RP_MIN_CODON_COV_EMPTY;
-            t.pad = 0;
+            double p[3] = {0.0, 0.0, 0.0}, q[3] = {0.0, 0.0, 0.0};
+            unsigned long long nn = 0, mm = 0, count = 0;
+            unsigned min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
             if (ve > vs) {
                 const int w_first = vs >> 4;
                 const int w_last = (ve - 1) >> 4;
@@ -532,119 +561,70 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
                     const RunRec &rec = s_rec[seg + w];
 #pragma unroll
                     for (int f = 0; f < 3; ++f) {
-                        t.p[f] += (double)rec.p[f];
-                        t.q[f] += (double)rec.q[f];
+                        p[f] += (double)rec.p[f];
+                        q[f] += (double)rec.q[f];
                     }
                 }
                 const SegInts &acc = s_ints[seg];
-#pragma unroll
-                for (int f = 0; f < 3; ++f) {
-                    t.n[f] = (int)((acc.nn >> (21 * f)) & 0x1fffffu);
-                    t.m[f] = (int)((acc.mm >> (21 * f)) & 0x1fffffu);
-                }
-                t.count = (long long)acc.count;
-                t.min_codon = (int)acc.min_codon;
+                nn = acc.nn;
+                mm = acc.mm;
+                count = acc.count;
+                min_codon = acc.min_codon;
             }
-            const int kind = s_kind[seg];
-            if (kind == kSegComplete) {
-                FrameScore fr[3];
-#pragma unroll
-                for (int f = 0; f < 3; ++f) fr[f] = frame_score(t.p[f], t.q[f], t.n[f], t.m[f]);
-                if (fp32_decision_unsafe(fr)) {
-                    const int slot = atomicAdd(&s_n_recheck, 1);
-                    s_recheck[slot] = seg;
-                } else {
-                    double phase;
-                    int valid;
-                    unsigned flags;
-                    combine_frames(fr, phase, valid, flags);
-                    store_orf(out, fp, orf, phase, valid, t.count, t.min_codon, flags, s_len[seg]);
-                }
-            } else {
-                ws.partials[2 * b + (kind == kSegHead ? 0 : 1)] = t;
-            }
+            store_record(ws.rec, c0 + seg + b, p, q, nn, mm, count, min_codon);
         }
-        __syncthreads();
-
-        // ---- float64 re-walk of the too-close-to-call ORFs, one wave each -----------------
-        const int n_re = s_n_recheck;
-        if (n_re > 0) {
-            for (int k = wave; k < n_re; k += kTileBlock / kWave) {
-                const int seg = s_recheck[k];
-                const long long orf = c0 + seg;
-                const long long len = s_len[seg];
-                WalkResult<double> w;
-                // a complete segment starts in this tile and ends inside tile + halo: walk LDS
-                wave_walk<double>(s_counts + s_qfirst[seg], len, lane, w);
-                FrameScore fr[3];
-                long long count;
-                int min_codon;
-                wave_reduce_frames(w, fr, count, min_codon);
-                double phase;
-                int valid;
-                unsigned flags;
-                combine_frames(fr, phase, valid, flags);
-                if (lane == 0)
-                    store_orf(out, fp, orf, phase, valid, count, min_codon, flags | RP_FLAG_RECHECK64, len);
-            }
-            __syncthreads();
-            if (tid == 0) s_n_recheck = 0;
-        }
+        if (c0 + kSegChunk < a1) __syncthreads();  // the next chunk clears the scratch
     }
 }
 
 // ---------------------------------------------------------------------------
-// pass 3: ORFs that straddle a tile boundary -- one LANE per tile whose last ORF does
-// not end inside it; sums the tail partial of that tile and the head partials of the
-// tiles the ORF runs through.  Too-close-to-call ORFs are re-walked by the whole wave.
+// pass 3: one thread per ORF -- add the records of the tiles it spans, score, filter,
+// store.  Too-close-to-call ORFs (~0.7 %) are queued per workgroup and re-walked in float64
+// from global memory: short ones by one wave each, long ones by all four waves.  (A global
+// queue drained by a fourth kernel was measured slower: the single contended atomic alone
+// cost more than the re-walks.)
 // ---------------------------------------------------------------------------
 template <int TILE>
-__global__ __launch_bounds__(kTileBlock) void k_tile_finalize(const int32_t *__restrict__ counts,
-                                                              const int64_t *__restrict__ offsets,
-                                                              long long n_orfs, TilePlan plan,
-                                                              TileWorkspace ws, OrfOutputs out,
-                                                              FilterParams fp)
+__global__ __launch_bounds__(kTileBlock) void k_orf_finish(const int32_t *__restrict__ counts,
+                                                           const int64_t *__restrict__ offsets,
+                                                           long long n_orfs, TilePlan plan,
+                                                           TileWorkspace ws, OrfOutputs out,
+                                                           FilterParams fp)
 {
+    constexpr int kWaves = kTileBlock / kWave;
     const int lane = threadIdx.x & (kWave - 1);
-    const long long b = (long long)blockIdx.x * kTileBlock + threadIdx.x;
-    bool work = false;
-    long long orf = 0, beg = 0, len = 0, b_end = 0;
-    if (b < plan.n_tiles) {
-        const long long a0 = ws.tile_first[b];
-        const long long a1 = ws.tile_first[b + 1];
-        if (a1 > a0) {  // some ORF starts in this tile; only the last one can leave it
-            orf = a1 - 1;
-            beg = offsets[orf];
-            len = (long long)offsets[orf + 1] - beg;
-            const long long ntrip_all = (len + 2) / 3;
-            long long t1 = (b + 1) * (long long)TILE - plan.mis;
-            if (t1 > plan.total_nt) t1 = plan.total_nt;
-            const long long last_first = beg + 3 * (ntrip_all - 1);  // first position of the last triplet
-            if (ntrip_all > 0 && last_first >= t1) {
-                work = true;
-                b_end = (last_first + plan.mis) / TILE;
-            }
-        }
-    }
-    FrameScore fr[3];
-    long long count = 0;
-    int min_codon = RP_MIN_CODON_COV_EMPTY;
+    const int wave = threadIdx.x >> 6;
+    const long long orf = (long long)blockIdx.x * kTileBlock + threadIdx.x;
+    long long beg = 0, len = 0;
+    unsigned split = 0;
     bool unsafe = false;
-    if (work) {
+    if (orf < n_orfs) {
+        beg = offsets[orf];
+        len = (long long)offsets[orf + 1] - beg;
         double p[3] = {0, 0, 0}, q[3] = {0, 0, 0};
         int n[3] = {0, 0, 0}, m[3] = {0, 0, 0};
-        for (long long k = 0; k <= b_end - b; ++k) {
-            const TilePartial &t = (k == 0) ? ws.partials[2 * b + 1] : ws.partials[2 * (b + k)];
+        long long count = 0;
+        int min_codon = RP_MIN_CODON_COV_EMPTY;
+        if (len > 0) {
+            const long long b_first = (beg + plan.mis) / TILE;
+            const long long b_last = (beg + len - 1 + plan.mis) / TILE;
+            const SegRecords &r = ws.rec;
+            for (long long b = b_first; b <= b_last; ++b) {  // tile order: deterministic sums
+                const long long id = orf + b;
+                const unsigned long long nn = r.nn[id], mm = r.mm[id];
 #pragma unroll
-            for (int f = 0; f < 3; ++f) {
-                p[f] += t.p[f];
-                q[f] += t.q[f];
-                n[f] += t.n[f];
-                m[f] += t.m[f];
+                for (int f = 0; f < 3; ++f) {
+                    p[f] += r.pq[f * r.n_rec + id];
+                    q[f] += r.pq[(3 + f) * r.n_rec + id];
+                    n[f] += (int)((nn >> (21 * f)) & 0x1fffffu);
+                    m[f] += (int)((mm >> (21 * f)) & 0x1fffffu);
+                }
+                count += (long long)r.count[id];
+                min_codon = min(min_codon, (int)r.min_codon[id]);
             }
-            count += t.count;
-            min_codon = min(min_codon, t.min_codon);
+            if (b_last > b_first) split = RP_FLAG_SPLIT;
         }
+        FrameScore fr[3];
 #pragma unroll
         for (int f = 0; f < 3; ++f) fr[f] = frame_score(p[f], q[f], n[f], m[f]);
         unsafe = fp32_decision_unsafe(fr);
@@ -653,17 +633,18 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_finalize(const int32_t *__r
             int valid;
             unsigned flags;
             combine_frames(fr, phase, valid, flags);
-            store_orf(out, fp, orf, phase, valid, count, min_codon, flags | RP_FLAG_SPLIT, len);
+            store_orf(out, fp, orf, phase, valid, count, min_codon, flags | split, len);
         }
     }
-    // too-close-to-call ORFs: queue them per workgroup; short ones are re-walked in float64
-    // by one wave each, long ones (a single wave needs ~3 us per 1000 nt) by all four waves
-    constexpr long long kBlockWalkLen = 2048;
+    if (!__syncthreads_or(unsafe)) return;
+
+    constexpr long long kBlockWalkLen = 2048;  // a single wave needs ~3 us per 1000 nt
     __shared__ long long s_list_orf[kTileBlock], s_list_beg[kTileBlock], s_list_len[kTileBlock];
+    __shared__ unsigned s_list_split[kTileBlock];
     __shared__ int s_n;
-    __shared__ double s_part[kTileBlock / kWave][6];
-    __shared__ int s_parti[kTileBlock / kWave][7];
-    __shared__ long long s_partc[kTileBlock / kWave];
+    __shared__ double s_part[kWaves][6];
+    __shared__ int s_parti[kWaves][7];
+    __shared__ long long s_partc[kWaves];
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     if (unsafe) {  // hand orf / start / length over: the re-walk then needs no dependent index loads
@@ -671,16 +652,17 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_finalize(const int32_t *__r
         s_list_orf[slot] = orf;
         s_list_beg[slot] = beg;
         s_list_len[slot] = len;
+        s_list_split[slot] = split;
     }
     __syncthreads();
     const int n_list = s_n;
-    const int wave = threadIdx.x >> 6;
     for (int k = 0; k < n_list; ++k) {  // workgroup-uniform loop
         const long long orf_s = s_list_orf[k];
         const long long beg_s = s_list_beg[k];
         const long long len_s = s_list_len[k];
+        const unsigned split_s = s_list_split[k];
         const bool block_walk = len_s > kBlockWalkLen;
-        if (!block_walk && (k & (kTileBlock / kWave - 1)) != wave) continue;
+        if (!block_walk && (k & (kWaves - 1)) != wave) continue;
         WalkResult<double> w;
         if (block_walk)
             wave_walk<double>(counts + beg_s, len_s, (int)threadIdx.x, w, kTileBlock);
@@ -715,7 +697,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_finalize(const int32_t *__r
             for (int f = 0; f < 3; ++f) {
                 double ps = 0.0, qs = 0.0;
                 int ns = 0, ms = 0;
-                for (int wv = 0; wv < kTileBlock / kWave; ++wv) {
+                for (int wv = 0; wv < kWaves; ++wv) {
                     ps += s_part[wv][2 * f];
                     qs += s_part[wv][2 * f + 1];
                     ns += s_parti[wv][2 * f];
@@ -723,7 +705,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_finalize(const int32_t *__r
                 }
                 fr2[f] = frame_score(ps, qs, ns, ms);
             }
-            for (int wv = 0; wv < kTileBlock / kWave; ++wv) {
+            for (int wv = 0; wv < kWaves; ++wv) {
                 count2 += s_partc[wv];
                 min2 = min(min2, s_parti[wv][6]);
             }
@@ -736,7 +718,7 @@ __global__ __launch_bounds__(kTileBlock) void k_tile_finalize(const int32_t *__r
         unsigned flags;
         combine_frames(fr2, phase, valid, flags);
         if (lane == 0 && (!block_walk || wave == 0))
-            store_orf(out, fp, orf_s, phase, valid, count2, min2, flags | RP_FLAG_SPLIT | RP_FLAG_RECHECK64, len_s);
+            store_orf(out, fp, orf_s, phase, valid, count2, min2, flags | split_s | RP_FLAG_RECHECK64, len_s);
     }
 }
 

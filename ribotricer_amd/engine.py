@@ -144,7 +144,7 @@ class PhaseScoreEngine:
         """Score every ORF of a CSR batch (counts int32, offsets int64, offsets[-1] == len(counts)).
 
         Asynchronous on the current torch stream unless ``timings`` is a list, in
-        which case the call blocks and appends [index_ms, main_ms, finalize_ms, total_ms].
+        which case the call blocks and appends [index_ms, main_ms, finish_ms, total_ms].
         """
         dev = self.device
         counts = _as_device(counts, torch.int32, dev)

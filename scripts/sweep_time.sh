@@ -1,0 +1,13 @@
+#!/bin/bash
+# Timing only (no parity tests): build with each flag set, run the bench for the given algo.
+# usage: ALGO=tile scripts/sweep_time.sh "<flags A>" "<flags B>" ...
+cd ${GRAFT_REPO_ROOT:-.}
+BASE="-O3 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -fno-slp-vectorize"
+for X in "$@"; do
+  rm -f ribotricer_amd/csrc/libribophase.so
+  make -C ribotricer_amd/csrc HIPFLAGS="$BASE $X" 2>&1 | grep -E " error"
+  timeout 120 python bench.py --algo ${ALGO:-tile} --steps 20 --warmup 3 --cpu-sample 0 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('flags=[$X] kernel_ms=%.4f GB/s=%.0f step_ms=%.4f' % (r['kernel_ms'], r['achieved'], d['ms_per_step']), r.get('aux_kernels_ms'))"
+done
