@@ -184,6 +184,39 @@ int rp_validate_csr_dev(int device, const int32_t *d_counts, const int64_t *d_of
                         int64_t n_orfs, int64_t total_nt, void *hip_stream);
 
 /*
+ * ---- host side: TSV row rendering ------------------------------
+ *
+ * rp_format_rows_host replaces the per-ORF `formatter.format(...)` of
+ * detect_orfs.py:301-324 for a whole batch: plain host memory in, text out, no GPU
+ * involved.  Every rendering is byte-identical to CPython's ('{}'.format of a float is
+ * repr(): shortest round-trip digits, fixed notation for 1e-4 <= |x| < 1e16; of a list of
+ * ints "[a, b, c]").  Column order, detect_orfs.py:304-323:
+ *   head_i  status  phase_score  read_count  length  valid_codons  valid_codons_ratio
+ *   read_density  tail_i  profile
+ * where head_i = "ORF_ID\tORF_type" and tail_i = "transcript_id\t...\tstart_codon" are
+ * the caller's bytes (index columns, orf.py:122-182), valid_codons_ratio =
+ * valid / max(1, length // 3) (detect_orfs.py:281-285) and read_density likewise (:287).
+ * Rows of ORFs with status[i] == 0 are skipped unless report_all (detect_orfs.py:301-303).
+ *
+ * Streaming: rows of ORFs first, first+1, ... are written while they fit in out[0..cap);
+ * *next = first ORF not written (n_orfs when finished), *out_len = bytes written.  If the
+ * first row to be written does not fit on its own: RP_ERR_SIZE, *next = its ORF (skipped
+ * rows before it are consumed), *out_len = bytes it needs.  Thread-safe (no shared state): callers may format disjoint ORF ranges
+ * concurrently into separate buffers.
+ */
+int rp_format_rows_host(const int32_t *counts, const int64_t *offsets, int64_t n_orfs,
+                        const double *phase, const int32_t *valid, const int64_t *read_count,
+                        const uint8_t *status, const char *head, const int64_t *head_off,
+                        const char *tail, const int64_t *tail_off, int report_all, int64_t first,
+                        char *out, size_t out_cap, int64_t *next, size_t *out_len);
+
+/* repr(float) of CPython 3 into buf (>= 32 bytes, not NUL-terminated); returns the length. */
+int rp_format_double_repr(double value, char *buf);
+
+/* str(list_of_int) of CPython 3 ("[a, b, c]") into out (>= 2 + 13*n bytes); returns the length. */
+size_t rp_format_int_list(const int32_t *values, int64_t n, char *out);
+
+/*
  * Same as rp_phase_score_csr_dev but brackets each internal launch with HIP events
  * on `hip_stream`, synchronises, and reports milliseconds: ms[0] tile-index pass,
  * ms[1] main scoring kernel, ms[2] per-ORF finish kernel, ms[3] whole call.

@@ -64,6 +64,11 @@ SYMBOLS = {
     "rp_phase_score_f64_csr_dev": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "rp_gather_profiles_dev": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "rp_validate_csr_dev": (_int, [_int, _vp, _vp, _i64, _i64, _vp]),
+    # host side (no GPU): TSV row rendering
+    "rp_format_rows_host": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp,
+                                   ctypes.c_size_t, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_size_t)]),
+    "rp_format_double_repr": (_int, [ctypes.c_double, _vp]),
+    "rp_format_int_list": (ctypes.c_size_t, [_vp, _i64, _vp]),
 }
 
 _lib = None

@@ -14,6 +14,7 @@
 #include "rp_device.hpp"
 #include "rp_tile.hpp"
 #include "rp_tile_pipe.hpp"
+#include "rp_format.hpp"
 #include "rp_wave.hpp"
 
 namespace {
@@ -345,6 +346,39 @@ int rp_gather_profiles_dev(int device, const int32_t *d_coverage, int64_t covera
                        d_offsets, (long long)n_orfs, d_counts);
     RP_HIP(hipGetLastError());
     return RP_OK;
+}
+
+int rp_format_rows_host(const int32_t *counts, const int64_t *offsets, int64_t n_orfs,
+                        const double *phase, const int32_t *valid, const int64_t *read_count,
+                        const uint8_t *status, const char *head, const int64_t *head_off,
+                        const char *tail, const int64_t *tail_off, int report_all, int64_t first,
+                        char *out, size_t out_cap, int64_t *next, size_t *out_len)
+{
+    if (!next || !out_len) return fail(RP_ERR_NULL, "next / out_len is null");
+    *next = first;
+    *out_len = 0;
+    if (n_orfs < 0 || first < 0 || first > n_orfs) return fail(RP_ERR_SIZE, "n_orfs=%lld first=%lld", (long long)n_orfs, (long long)first);
+    if (first == n_orfs) return RP_OK;
+    if (!offsets || !phase || !valid || !read_count || !status || !head_off || !tail_off || !out)
+        return fail(RP_ERR_NULL, "format_rows: null array");
+    if (!counts && offsets[n_orfs] > 0) return fail(RP_ERR_NULL, "counts is null but offsets[n] > 0");
+    const rpfmt::RowInputs in{counts, offsets, phase, valid, read_count, status, head, head_off, tail, tail_off};
+    size_t len = 0, need = 0;
+    const long long nx = rpfmt::format_rows(in, n_orfs, report_all != 0, first, out, out_cap, &len, &need);
+    *next = nx;
+    *out_len = len;
+    if (need > 0) {
+        *out_len = need;
+        return fail(RP_ERR_SIZE, "row of ORF %lld needs %zu bytes, buffer has %zu", nx, need, out_cap);
+    }
+    return RP_OK;
+}
+
+int rp_format_double_repr(double value, char *buf) { return buf ? rpfmt::double_repr(value, buf) : 0; }
+
+size_t rp_format_int_list(const int32_t *values, int64_t n, char *out)
+{
+    return (out && (values || n <= 0)) ? rpfmt::int_list_str(values, n, out) : 0;
 }
 
 int rp_validate_csr_dev(int device, const int32_t *d_counts, const int64_t *d_offsets,

@@ -166,7 +166,10 @@ def score_profiles(counts, offsets, phase_score_cutoff, min_valid_codons, min_re
 
 
 def format_rows(records, counts, offsets, res, report_all: bool):
-    """Yield the TSV rows of detect_orfs.py:301-324 (same ``str.format('{}')`` renderings)."""
+    """Yield the TSV rows of detect_orfs.py:301-324 (same ``str.format('{}')`` renderings).
+
+    Pure-Python rendering, kept as the readable statement of the row format and as the
+    cross-check of the native renderer (``format_rows_native``) that the export path uses."""
     lengths = np.diff(offsets)
     n_codons = np.maximum(1, lengths // 3)  # detect_orfs.py:281
     formatter = "{}\t" * (len(COLUMNS) - 1) + "{}\n"
@@ -199,6 +202,17 @@ def format_rows(records, counts, offsets, res, report_all: bool):
         )
 
 
+def format_rows_native(records, counts, offsets, res, report_all: bool, chunk_bytes: int = 64 << 20):
+    """Yield the same bytes as ``format_rows`` in large chunks, rendered by the library
+    (``rp_format_rows_host``: SURVEY.md 8(f) f2; detect_orfs.py:301-324)."""
+    from . import tsv
+
+    yield from tsv.format_rows_native(
+        counts, offsets, res["phase"], res["valid"], res["read_count"], res["status"],
+        tsv.record_tables(records), report_all, chunk_bytes=chunk_bytes,
+    )
+
+
 def export_orf_coverages(
     ribotricer_index: str,
     merged_alignments,
@@ -220,7 +234,7 @@ def export_orf_coverages(
     )
     counts = d_counts.cpu().numpy()
     offsets = d_offsets.cpu().numpy()
-    with open(f"{prefix}_translating_ORFs.tsv", "w") as output:
-        output.write("\t".join(COLUMNS) + "\n")
-        for row in format_rows(records, counts, offsets, res, report_all):
-            output.write(row)
+    with open(f"{prefix}_translating_ORFs.tsv", "wb") as output:
+        output.write(("\t".join(COLUMNS) + "\n").encode("utf-8"))
+        for chunk in format_rows_native(records, counts, offsets, res, report_all):
+            output.write(chunk)

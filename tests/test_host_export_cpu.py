@@ -120,3 +120,80 @@ def test_dense_coverage_and_interval_table_reproduce_the_packer(packed):
         if table.reverse[i]:
             prof = prof[::-1]
         assert np.array_equal(prof, counts[offsets[i] : offsets[i + 1]]), records[i].oid
+
+
+def oracle_results(counts, offsets, **thr):
+    o = c_oracle.phase_score_csr(counts, offsets)
+    status = reference_status(
+        o.phase, o.valid, o.read_count, o.min_codon_cov, np.diff(offsets),
+        cutoff=thr.get("cutoff", 0.428571428571), min_valid=thr.get("min_valid", 5), min_reads=0, min_ratio=0,
+        min_density=0.0,
+    )
+    return dict(phase=o.phase, valid=o.valid, read_count=o.read_count, min_codon_cov=o.min_codon_cov, flags=o.flags, status=status)
+
+
+@pytest.mark.parametrize("report_all", [False, True])
+@pytest.mark.parametrize("chunk_bytes", [1 << 20, 700, 64])  # 64 B: every row needs the grow-and-retry path
+def test_native_rows_equal_python_rows(packed, report_all, chunk_bytes):
+    """rp_format_rows_host (8(f) f2) renders byte-for-byte what '{}'.format renders."""
+    records, counts, offsets = packed
+    res = oracle_results(counts, offsets)
+    want = "".join(d.format_rows(records, counts, offsets, res, report_all)).encode("utf-8")
+    got = b"".join(d.format_rows_native(records, counts, offsets, res, report_all, chunk_bytes=chunk_bytes))
+    assert got == want
+    assert got.count(b"\n") == (len(records) if report_all else int(res["status"].sum()))
+
+
+def test_native_rows_match_reference_tsv_bytes(packed):
+    """Against the reference's own file: every column that does not carry the last ulps of
+    the phase score is byte-identical."""
+    records, counts, offsets = packed
+    res = oracle_results(counts, offsets)
+    body = b"".join(d.format_rows_native(records, counts, offsets, res, True)).decode("utf-8")
+    got = [r.split("\t") for r in body.rstrip("\n").split("\n")]
+    _, expect = read_tsv("g6_expected_report_all.tsv")
+    tie = {rec.oid for rec, f in zip(records, res["flags"]) if f & 1}
+    assert len(got) == len(expect)
+    for g, e in zip(got, expect):
+        assert g[:2] == e[:2] and g[4:6] == e[4:6] and g[8:] == e[8:]
+        if g[0] not in tie:
+            assert g[6:8] == e[6:8]
+
+
+def test_native_number_renderings_equal_cpython():
+    import random
+    import struct
+
+    from ribotricer_amd import tsv
+
+    rng = random.Random(20260213)
+    specials = [0.0, -0.0, 0.5, 1.0, 1e16, 1e15, 9999999999999998.0, 1e-4, 1e-5, 0.1 + 0.2, 1 / 3, 5e-324,
+                1.7976931348623157e308, 1e22, 123456.0, float("inf"), float("-inf"), float("nan"), -2.5e-7]
+    values = specials + [struct.unpack("<d", struct.pack("<Q", rng.getrandbits(64)))[0] for _ in range(20000)]
+    values += [rng.randint(0, 10 ** rng.randint(0, 9)) / rng.randint(1, 10 ** rng.randint(0, 6)) for _ in range(20000)]
+    for v in values:
+        assert tsv.double_repr(v) == repr(v)
+    for n in (0, 1, 2, 17):
+        arr = np.array([rng.choice([0, 1, 9, 10, 123, 2**24 - 1, -7, 2**31 - 1, -(2**31)]) for _ in range(n)], np.int32)
+        assert tsv.int_list_str(arr) == str(arr.tolist())
+
+
+def test_native_rows_ragged_and_empty():
+    """Empty batch, empty profiles, None start codon, non-ASCII names."""
+    from ribotricer_amd import tsv
+
+    counts = np.array([3, 0, 1, 7, 7, 7, 12], np.int32)
+    offsets = np.array([0, 0, 3, 3, 7], np.int64)
+    res = dict(phase=np.array([0.0, 1.0, 0.0, 1 / 3]), valid=np.array([0, 1, 0, 1], np.int32),
+               read_count=np.array([0, 4, 0, 33], np.int64), status=np.array([0, 1, 0, 1], np.uint8))
+    tables = (*tsv.string_table(["a\tx", "b\ty", "c\tz", "d\u00e9\tw"]), *tsv.string_table(["t1", "t2\tNone", "", "t4"]))
+    body = b"".join(tsv.format_rows_native(counts, offsets, res["phase"], res["valid"], res["read_count"], res["status"], tables, True))
+    rows = body.decode("utf-8").split("\n")
+    assert rows[0] == "a\tx\tnontranslating\t0.0\t0\t0\t0\t0.0\t0.0\tt1\t[]"
+    assert rows[1] == "b\ty\ttranslating\t1.0\t4\t3\t1\t1.0\t4.0\tt2\tNone\t[3, 0, 1]"
+    assert rows[3] == "d\u00e9\tw\ttranslating\t0.3333333333333333\t33\t4\t1\t1.0\t33.0\tt4\t[7, 7, 7, 12]"
+    only = b"".join(tsv.format_rows_native(counts, offsets, res["phase"], res["valid"], res["read_count"], res["status"], tables, False))
+    assert only.count(b"\n") == 2
+    e = np.zeros(0)
+    none = list(tsv.format_rows_native(np.zeros(0, np.int32), np.zeros(1, np.int64), e, e, e, e, (*tsv.string_table([]), *tsv.string_table([])), True))
+    assert none == []
