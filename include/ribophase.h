@@ -52,7 +52,9 @@ typedef enum rp_status {
     RP_ERR_WORKSPACE = -5, /* workspace missing, misaligned or too small */
     RP_ERR_DEVICE = -6,    /* no such device / no HIP device available */
     RP_ERR_COUNTS = -7,    /* a count is negative or exceeds RP_MAX_COUNT */
-    RP_ERR_ARG = -8        /* invalid enum / option value */
+    RP_ERR_ARG = -8,       /* invalid enum / option value */
+    RP_ERR_INDEX_COLUMNS = -9, /* index line without exactly 11 tab-separated fields (orf.py:143-152) */
+    RP_ERR_INDEX_COORD = -10   /* malformed "start-end,..." coordinate field */
 } rp_status;
 
 /* bits of the per-ORF flags byte */
@@ -209,6 +211,50 @@ int rp_format_rows_host(const int32_t *counts, const int64_t *offsets, int64_t n
                         const uint8_t *status, const char *head, const int64_t *head_off,
                         const char *tail, const int64_t *tail_off, int report_all, int64_t first,
                         char *out, size_t out_cap, int64_t *next, size_t *out_len);
+
+/*
+ * ---- host side: index parser -----------------------------------
+ *
+ * rp_index_parse_host reads the text of a `{prefix}_candidate_orfs.tsv` index
+ * (prepare_orfs.py:370-404) in one pass with the line semantics of ORF.from_string /
+ * ORF.__init__ (orf.py:88-182): 11 tab-separated fields or RP_ERR_INDEX_COLUMNS (the
+ * reference exits there), "s-e,s-e" coordinates sorted by start, ORF_ID recomputed as
+ * tid_start_end_length, start_codon = first three characters of field 9 or None.  It
+ * replaces parse_ribotricer_index (detect_orfs.py:86-131) and the per-line
+ * ORF.from_string calls of the export loop (detect_orfs.py:273-278).
+ *
+ * The result is an opaque object; rp_index_view_host lends out its arrays (valid until
+ * rp_index_free):
+ *   per ORF       orf_iv[n+1], length[n], group[n] (index of its (strand, chrom)), reverse[n]
+ *   per interval  iv_start[], iv_end[]   1-based closed, ascending inside each ORF
+ *   per group     group_names/off ("strand\tchrom"), group_lo/hi = extent of its ORFs
+ *   string tables head ("ORF_ID\tORF_type") and tail ("transcript_id ... start_codon")
+ *                 exactly as rp_format_rows_host takes them
+ * On a malformed line *error_line (may be NULL) receives its 1-based line number.
+ */
+typedef struct rp_index rp_index;
+
+typedef struct rp_index_view {
+    int64_t n_orfs, n_intervals, n_groups;
+    const int64_t *orf_iv;
+    const int64_t *length;
+    const int32_t *group;
+    const uint8_t *reverse;
+    const int64_t *iv_start;
+    const int64_t *iv_end;
+    const char *group_names;
+    const int64_t *group_off;
+    const int64_t *group_lo;
+    const int64_t *group_hi;
+    const char *head;
+    const int64_t *head_off;
+    const char *tail;
+    const int64_t *tail_off;
+} rp_index_view;
+
+int rp_index_parse_host(const char *text, size_t len, int skip_header, rp_index **out, int64_t *error_line);
+int rp_index_view_host(const rp_index *index, rp_index_view *view);
+void rp_index_free(rp_index *index);
 
 /* repr(float) of CPython 3 into buf (>= 32 bytes, not NUL-terminated); returns the length. */
 int rp_format_double_repr(double value, char *buf);

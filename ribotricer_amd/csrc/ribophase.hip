@@ -14,7 +14,9 @@
 #include "rp_device.hpp"
 #include "rp_tile.hpp"
 #include "rp_tile_pipe.hpp"
+#include <new>
 #include "rp_format.hpp"
+#include "rp_index.hpp"
 #include "rp_wave.hpp"
 
 namespace {
@@ -203,6 +205,8 @@ const char *rp_status_string(int status)
         case RP_ERR_DEVICE: return "no such HIP device";
         case RP_ERR_COUNTS: return "count out of range";
         case RP_ERR_ARG: return "invalid argument";
+        case RP_ERR_INDEX_COLUMNS: return "index line: unexpected number of columns";
+        case RP_ERR_INDEX_COORD: return "index line: malformed coordinate";
         default: return "unknown status";
     }
 }
@@ -373,6 +377,63 @@ int rp_format_rows_host(const int32_t *counts, const int64_t *offsets, int64_t n
     }
     return RP_OK;
 }
+
+struct rp_index {
+    rpidx::Index ix;
+};
+
+int rp_index_parse_host(const char *text, size_t len, int skip_header, rp_index **out, int64_t *error_line)
+{
+    if (!out) return fail(RP_ERR_NULL, "out is null");
+    *out = nullptr;
+    if (error_line) *error_line = 0;
+    if (!text && len > 0) return fail(RP_ERR_NULL, "text is null but len > 0");
+    rp_index *h = new (std::nothrow) rp_index;
+    if (!h) return fail(RP_ERR_SIZE, "out of memory");
+    int rc = rpidx::kOk;
+    try {
+        rc = rpidx::parse(text, len, skip_header != 0, h->ix);
+    } catch (const std::bad_alloc &) {
+        delete h;
+        return fail(RP_ERR_SIZE, "out of memory while parsing the index");
+    }
+    if (rc != rpidx::kOk) {
+        const long long line = h->ix.error_line;
+        delete h;
+        if (error_line) *error_line = line;
+        if (rc == rpidx::kColumns)
+            return fail(RP_ERR_INDEX_COLUMNS, "line %lld: unexpected number of columns found for index file", line);
+        return fail(RP_ERR_INDEX_COORD, "line %lld: malformed coordinate field", line);
+    }
+    *out = h;
+    return RP_OK;
+}
+
+int rp_index_view_host(const rp_index *index, rp_index_view *view)
+{
+    if (!index || !view) return fail(RP_ERR_NULL, "index / view is null");
+    const rpidx::Index &ix = index->ix;
+    view->n_orfs = (int64_t)ix.length.size();
+    view->n_intervals = (int64_t)ix.iv_start.size();
+    view->n_groups = (int64_t)ix.group_lo.size();
+    view->orf_iv = ix.orf_iv.data();
+    view->length = ix.length.data();
+    view->group = ix.group.data();
+    view->reverse = ix.reverse.data();
+    view->iv_start = ix.iv_start.data();
+    view->iv_end = ix.iv_end.data();
+    view->group_names = ix.group_names.data();
+    view->group_off = ix.group_off.data();
+    view->group_lo = ix.group_lo.data();
+    view->group_hi = ix.group_hi.data();
+    view->head = ix.head.data();
+    view->head_off = ix.head_off.data();
+    view->tail = ix.tail.data();
+    view->tail_off = ix.tail_off.data();
+    return RP_OK;
+}
+
+void rp_index_free(rp_index *index) { delete index; }
 
 int rp_format_double_repr(double value, char *buf) { return buf ? rpfmt::double_repr(value, buf) : 0; }
 

@@ -151,6 +151,15 @@ def gather_profiles(records, merged_alignments, device=None):
     return gather_profiles_device(coverage, table, device)
 
 
+def gather_profiles_indexed(index, merged_alignments, device=None):
+    """Same for a natively parsed index (``ribotricer_amd.index.NativeIndex``): the interval
+    table comes from the parser's arrays, no per-ORF Python."""
+    from .gather import build_dense_coverage_from_extents, gather_profiles_device, interval_table_from_index
+
+    coverage, base = build_dense_coverage_from_extents(merged_alignments, index.extents)
+    return gather_profiles_device(coverage, interval_table_from_index(index, base), device)
+
+
 def score_profiles(counts, offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
                    min_valid_codons_ratio, min_density_over_orf, device=None) -> dict:
     """One launch for the whole batch; host numpy arrays back (24 B + 2 B per ORF)."""
@@ -224,10 +233,16 @@ def export_orf_coverages(
     min_density_over_orf: float = MINIMUM_DENSITY_OVER_ORF,
     report_all: bool = False,
 ) -> None:
-    """Write ``{prefix}_translating_ORFs.tsv`` -- drop-in for detect_orfs.py:206-324."""
-    records = read_index(ribotricer_index)
+    """Write ``{prefix}_translating_ORFs.tsv`` -- drop-in for detect_orfs.py:206-324.
+
+    index text -> ``rp_index_parse_host`` (f3) -> interval table -> ``rp_gather_profiles_dev``
+    (f1) -> ``rp_phase_score_csr_dev`` -> ``rp_format_rows_host`` (f2): no per-ORF Python."""
+    from . import tsv
+    from .index import NativeIndex
+
+    index = NativeIndex.from_file(ribotricer_index)
     # profiles are gathered and scored on the GPU; they come back once for the profile column
-    d_counts, d_offsets = gather_profiles(records, merged_alignments)
+    d_counts, d_offsets = gather_profiles_indexed(index, merged_alignments)
     res = score_profiles(
         d_counts, d_offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
         min_valid_codons_ratio, min_density_over_orf,
@@ -236,5 +251,7 @@ def export_orf_coverages(
     offsets = d_offsets.cpu().numpy()
     with open(f"{prefix}_translating_ORFs.tsv", "wb") as output:
         output.write(("\t".join(COLUMNS) + "\n").encode("utf-8"))
-        for chunk in format_rows_native(records, counts, offsets, res, report_all):
+        for chunk in tsv.format_rows_native(
+            counts, offsets, res["phase"], res["valid"], res["read_count"], res["status"], index.tables, report_all
+        ):
             output.write(chunk)

@@ -48,6 +48,12 @@ def build_dense_coverage(merged_alignments, records):
             extent[key] = (min(e[0], lo), max(e[1], hi))
         else:
             extent[key] = (lo, hi)
+    return build_dense_coverage_from_extents(merged_alignments, extent)
+
+
+def build_dense_coverage_from_extents(merged_alignments, extent: dict):
+    """Same, from ``extent[(strand, chrom)] = (lo, hi)`` (what the native index parser
+    reports per group)."""
     base = {}
     total = 0
     for key in sorted(extent):
@@ -95,6 +101,20 @@ def build_interval_table(records, base) -> IntervalTable:
     offsets = np.zeros(n + 1, np.int64)
     np.cumsum(lengths, out=offsets[1:])
     return IntervalTable(iv_start, iv_len, orf_iv, reverse, offsets)
+
+
+def interval_table_from_index(index, base) -> IntervalTable:
+    """IntervalTable of a natively parsed index (``ribotricer_amd.index.NativeIndex``),
+    vectorised: no per-ORF Python."""
+    keys = index.group_keys
+    g_start = np.array([base[k][0] for k in keys], np.int64)
+    g_lo = np.array([base[k][1] for k in keys], np.int64)
+    per_iv_group = np.repeat(index.group, np.diff(index.orf_iv))
+    iv_start = g_start[per_iv_group] + (index.iv_start - g_lo[per_iv_group])
+    iv_len = (index.iv_end - index.iv_start + 1).astype(np.int32)
+    offsets = np.zeros(index.n_orfs + 1, np.int64)
+    np.cumsum(index.length, out=offsets[1:])
+    return IntervalTable(iv_start, iv_len, index.orf_iv.copy(), index.reverse.copy(), offsets)
 
 
 def gather_profiles_device(coverage, table: IntervalTable, device=None):

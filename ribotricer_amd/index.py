@@ -1,0 +1,110 @@
+"""Native ribotricer index parser: ``rp_index_parse_host``.
+
+One C++ pass over ``{prefix}_candidate_orfs.tsv`` replaces ``parse_ribotricer_index``
+(``ribotricer/detect_orfs.py:86-131``) and the per-line ``ORF.from_string`` calls of the
+export loop (``detect_orfs.py:273-278``, ``orf.py:122-182``).  The result carries the
+interval table for the device gather, the (strand, chrom) extents for the dense coverage
+layout and the two string tables the native TSV writer prints.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import sys
+
+import numpy as np
+
+from . import _lib
+
+RP_ERR_INDEX_COLUMNS = -9
+
+
+class _View(ctypes.Structure):  # rp_index_view
+    _fields_ = [(n, ctypes.c_int64) for n in ("n_orfs", "n_intervals", "n_groups")] + [
+        (n, ctypes.c_void_p)
+        for n in ("orf_iv", "length", "group", "reverse", "iv_start", "iv_end", "group_names", "group_off",
+                  "group_lo", "group_hi", "head", "head_off", "tail", "tail_off")
+    ]
+
+
+def _array(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype)
+    buf = (ctypes.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+def _bytes(ptr, n):
+    return ctypes.string_at(ptr, n) if n else b""
+
+
+class NativeIndex:
+    """Arrays of a parsed index (host numpy copies; the C++ object is freed at once)."""
+
+    def __init__(self, text: bytes, skip_header: bool = True):
+        lib = _lib.load()
+        handle = ctypes.c_void_p()
+        bad_line = ctypes.c_int64(0)
+        rc = lib.rp_index_parse_host(text, len(text), int(skip_header), ctypes.byref(handle), ctypes.byref(bad_line))
+        if rc == RP_ERR_INDEX_COLUMNS:  # what ORF.from_string does (orf.py:143-152)
+            sys.exit(
+                "{}\n{}".format(
+                    "Error: unexpected number of columns found for index file",
+                    "please run ribotricer prepare-orfs to regenerate",
+                )
+            )
+        _lib.check(rc)
+        try:
+            v = _View()
+            _lib.check(lib.rp_index_view_host(handle, ctypes.byref(v)))
+            n, m, g = v.n_orfs, v.n_intervals, v.n_groups
+            self.n_orfs = int(n)
+            self.orf_iv = _array(v.orf_iv, n + 1, np.int64)
+            self.length = _array(v.length, n, np.int64)
+            self.group = _array(v.group, n, np.int32)
+            self.reverse = _array(v.reverse, n, np.uint8)
+            self.iv_start = _array(v.iv_start, m, np.int64)
+            self.iv_end = _array(v.iv_end, m, np.int64)
+            group_off = _array(v.group_off, g + 1, np.int64)
+            names = _bytes(v.group_names, int(group_off[-1]))
+            self.group_keys = [
+                tuple(names[group_off[k] : group_off[k + 1]].decode("utf-8").split("\t", 1)) for k in range(g)
+            ]  # (strand, chrom)
+            self.group_lo = _array(v.group_lo, g, np.int64)
+            self.group_hi = _array(v.group_hi, g, np.int64)
+            self.head_off = _array(v.head_off, n + 1, np.int64)
+            self.head = _bytes(v.head, int(self.head_off[-1]))
+            self.tail_off = _array(v.tail_off, n + 1, np.int64)
+            self.tail = _bytes(v.tail, int(self.tail_off[-1]))
+        finally:
+            lib.rp_index_free(handle)
+
+    @classmethod
+    def from_file(cls, path: str) -> "NativeIndex":
+        with open(path, "rb") as fh:
+            return cls(fh.read(), skip_header=True)  # header line skipped: detect_orfs.py:273
+
+    @property
+    def tables(self):
+        """(head, head_off, tail, tail_off) as ``tsv.format_rows_native`` takes them."""
+        return self.head, self.head_off, self.tail, self.tail_off
+
+    @property
+    def extents(self) -> dict:
+        """``{(strand, chrom): (lo, hi)}`` over the ORFs of each group."""
+        return {k: (int(lo), int(hi)) for k, lo, hi in zip(self.group_keys, self.group_lo, self.group_hi)}
+
+    def records(self):
+        """Materialise ``detect_orfs.IndexRecord`` rows (tests / small inputs only)."""
+        from .detect_orfs import IndexRecord
+
+        out = []
+        for i in range(self.n_orfs):
+            oid, category = self.head[self.head_off[i] : self.head_off[i + 1]].decode("utf-8").split("\t")
+            t = self.tail[self.tail_off[i] : self.tail_off[i + 1]].decode("utf-8").split("\t")
+            ivs = tuple(
+                (int(s), int(e))
+                for s, e in zip(self.iv_start[self.orf_iv[i] : self.orf_iv[i + 1]], self.iv_end[self.orf_iv[i] : self.orf_iv[i + 1]])
+            )
+            out.append(IndexRecord(oid, category, t[0], t[1], t[2], t[3], t[4], t[5], t[6], None if t[7] == "None" else t[7], ivs))
+        return out

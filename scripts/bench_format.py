@@ -22,6 +22,7 @@ Rec = namedtuple("Rec", "oid category tid ttype gid gname gtype chrom strand sta
 records = [Rec(f"ENST{i:011d}_{i*7}_{i*7+300}_300", "annotated", f"ENST{i:011d}", "protein_coding", f"ENSG{i:011d}",
                f"GENE{i}", "protein_coding", "chr1", "+", "ATG") for i in range(n)]
 
+tsv.double_repr(0.5)  # loads the library
 t = time.perf_counter()
 tables = tsv.record_tables(records)
 t_tab = time.perf_counter() - t

@@ -197,3 +197,53 @@ def test_native_rows_ragged_and_empty():
     e = np.zeros(0)
     none = list(tsv.format_rows_native(np.zeros(0, np.int32), np.zeros(1, np.int64), e, e, e, e, (*tsv.string_table([]), *tsv.string_table([])), True))
     assert none == []
+
+
+# ---- native index parser ----------------------------------------------
+
+def test_native_index_equals_python_parser(packed):
+    from ribotricer_amd.gather import build_dense_coverage, build_dense_coverage_from_extents, build_interval_table, interval_table_from_index
+    from ribotricer_amd.index import NativeIndex
+
+    records, counts, offsets = packed
+    ni = NativeIndex.from_file(os.path.join(GOLDEN, "g6_index.tsv"))
+    assert ni.records() == records
+    # string tables are what the python rows print around the numbers
+    from ribotricer_amd import tsv
+
+    assert ni.tables[0] == tsv.record_tables(records)[0] and ni.tables[2] == tsv.record_tables(records)[2]
+    assert np.array_equal(ni.tables[1], tsv.record_tables(records)[1])
+    # and the interval table equals the per-record one
+    align = load_alignments()
+    cov_a, base_a = build_dense_coverage(align, records)
+    cov_b, base_b = build_dense_coverage_from_extents(align, ni.extents)
+    assert base_a == base_b and np.array_equal(cov_a, cov_b)
+    ta, tb = build_interval_table(records, base_a), interval_table_from_index(ni, base_b)
+    for x, y in zip(ta, tb):
+        assert np.array_equal(x, y)
+    assert np.array_equal(tb.offsets, offsets)
+
+
+def test_native_index_line_semantics():
+    from ribotricer_amd.index import NativeIndex
+
+    hdr = b"h\n"
+    line = "id\tannotated\ttx1\tprotein_coding\tg1\tGENE\tprotein_coding\tchr\u00e9\t-\tAT\t 30-40,+5-9 ,10-12\r\n"
+    ni = NativeIndex(hdr + line.encode("utf-8") + line.replace("AT", "ATGC").replace("\r\n", "").encode("utf-8"))
+    assert ni.n_orfs == 2
+    r0, r1 = ni.records()
+    assert r0 == d.parse_index_line(line) and r1 == d.parse_index_line(line.replace("AT", "ATGC").replace("\r\n", ""))
+    assert r0.intervals == ((5, 9), (10, 12), (30, 40)) and r0.oid == "tx1_5_40_19" and r0.start_codon is None
+    assert r1.start_codon == "ATG" and ni.reverse.tolist() == [1, 1] and ni.group_keys == [("-", "chr\u00e9")]
+    assert NativeIndex(b"only a header\n").n_orfs == 0 and NativeIndex(b"").n_orfs == 0
+    with pytest.raises(SystemExit) as e:  # orf.py:143-152
+        NativeIndex(hdr + b"a\tb\tc\n")
+    assert "unexpected number of columns" in str(e.value)
+    with pytest.raises(SystemExit):
+        NativeIndex(hdr + line.encode("utf-8") + b"\n")  # blank line: 1 field
+    from ribotricer_amd._lib import RibophaseError
+
+    for bad in ("1-2-3", "1", "a-2", "1-", ""):
+        with pytest.raises(RibophaseError) as e2:
+            NativeIndex(hdr + line.replace(" 30-40,+5-9 ,10-12", bad).encode("utf-8"))
+        assert e2.value.status == -10
