@@ -253,9 +253,13 @@ __device__ __forceinline__ void combine_frames(const FrameScore (&fr)[3], double
     flags = fl;
 }
 
-// Can the frame decision made on fp32-accumulated scores be trusted?  It cannot when
-// two live frames with different N (or a live frame and the initial best of 0 with a
-// different fallback N) are closer than the fp32 error margin.
+// Can the frame decision made on fp32-accumulated scores be trusted?  The outcome of the
+// state machine depends only on the largest live score and on which frame reaches it
+// first (the initial best is 0 with the fallback N), so only the CONTENDERS matter: the
+// frames -- and the initial 0 -- within the fp32 error margin of that maximum.  If they
+// all carry the same N the choice between them cannot change valid_codons; if two of them
+// differ in N the ORF is re-walked in float64.  (Close pairs further down the ranking are
+// common in sparse profiles and irrelevant.)
 __device__ __forceinline__ bool fp32_decision_unsafe(const FrameScore (&fr)[3])
 {
     int first_live = 0;
@@ -264,21 +268,22 @@ __device__ __forceinline__ bool fp32_decision_unsafe(const FrameScore (&fr)[3])
         if (fr[f].n == 0) first_live = f + 1;
     if (first_live >= 3) return false;
     const int n_fallback = first_live == 0 ? fr[0].n : (first_live == 1 ? fr[1].n : fr[2].n);
+    double smax = 0.0;
+#pragma unroll
+    for (int f = 0; f < 3; ++f)
+        if (f >= first_live) smax = fmax(smax, fr[f].score);  // fmax ignores a NaN score
+    const double thr = smax - kRecheckMargin * fmax(1.0, smax);
+    int n_ref = 0.0 >= thr ? n_fallback : -1;
     bool unsafe = false;
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
-        if (f < first_live) continue;
-        const double sf = fr[f].score;
-        if (fr[f].n != n_fallback && fabs(sf) <= kRecheckMargin) unsafe = true;
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            if (g <= f || g < first_live) continue;
-            const double sg = fr[g].score;
-            const double scale = fmax(1.0, fmax(fabs(sf), fabs(sg)));
-            if (fr[f].n != fr[g].n && fabs(sf - sg) <= kRecheckMargin * scale) unsafe = true;
-        }
+        if (f < first_live || !(fr[f].score >= thr)) continue;  // NaN frames are decided by integers
+        if (n_ref < 0)
+            n_ref = fr[f].n;
+        else if (fr[f].n != n_ref)
+            unsafe = true;
     }
-    return unsafe;  // comparisons with NaN are false: NaN frames are decided by integers
+    return unsafe;
 }
 
 // detect_orfs.py:281,285-299
