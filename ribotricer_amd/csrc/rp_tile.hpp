@@ -234,23 +234,49 @@ struct LaneSums {
 // source carries the same segment key (keys are >= 1) fold the source's running value
 // into their own.  Masking with all-ones / zero bits instead of a select keeps it at
 // (fetch, and, add) per value.
-template <int CTRL>
+// One step of the segmented scan: x += m * x[lane - K] inside the 16-lane row for the six
+// float sums (lanes without a source read 0), as six v_fmac_f32 with a DPP source.  hipcc
+// keeps a separate v_mov_b32_dpp in front of every fma, hence the asm; it is ONE block so
+// that the six stay together: a DPP read needs 2 wait states after the VALU write of its
+// source, which the leading s_nop gives the first and the five others give each following
+// step (the compiler inserts no wait states around inline asm).
+#define RP_SCAN_STEP(ctrl)                                                                          \
+    asm volatile("s_nop 1\n\t"                                                                      \
+                 "v_fmac_f32_dpp %0, %0, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
+                 "v_fmac_f32_dpp %1, %1, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
+                 "v_fmac_f32_dpp %2, %2, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
+                 "v_fmac_f32_dpp %3, %3, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
+                 "v_fmac_f32_dpp %4, %4, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
+                 "v_fmac_f32_dpp %5, %5, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1"         \
+                 : "+v"(v.p[0]), "+v"(v.p[1]), "+v"(v.p[2]), "+v"(v.q[0]), "+v"(v.q[1]), "+v"(v.q[2]) \
+                 : "v"(m))
+
+template <int K>
 __device__ __forceinline__ void seg_scan_step(LaneSums &v, int key)
 {
-    const int bits = (dpp_row<CTRL>(key) == key) ? -1 : 0;
+    static_assert(K == 1 || K == 2 || K == 4 || K == 8, "row_shr distance");
+    constexpr int ctrl = K == 1 ? kDppRowShr1 : K == 2 ? kDppRowShr2 : K == 4 ? kDppRowShr4 : kDppRowShr8;
+    const float m = (dpp_row<ctrl>(key) == key) ? 1.0f : 0.0f;  // 1 inside the segment, 0 across its start
+#ifdef RP_SCAN_PLAIN  // the same step in plain C++ (A/B reference: +40 VALU instructions per pass)
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
-        v.p[f] += __int_as_float(dpp_row<CTRL>(__float_as_int(v.p[f])) & bits);
-        v.q[f] += __int_as_float(dpp_row<CTRL>(__float_as_int(v.q[f])) & bits);
+        v.p[f] = __builtin_fmaf(__int_as_float(dpp_row<ctrl>(__float_as_int(v.p[f]))), m, v.p[f]);
+        v.q[f] = __builtin_fmaf(__int_as_float(dpp_row<ctrl>(__float_as_int(v.q[f]))), m, v.q[f]);
     }
+    return;
+#endif
+    if constexpr (K == 1) RP_SCAN_STEP("row_shr:1");
+    if constexpr (K == 2) RP_SCAN_STEP("row_shr:2");
+    if constexpr (K == 4) RP_SCAN_STEP("row_shr:4");
+    if constexpr (K == 8) RP_SCAN_STEP("row_shr:8");
 }
 
 __device__ __forceinline__ void seg_scan_rows(LaneSums &v, int key)
 {
-    seg_scan_step<kDppRowShr1>(v, key);
-    seg_scan_step<kDppRowShr2>(v, key);
-    seg_scan_step<kDppRowShr4>(v, key);
-    seg_scan_step<kDppRowShr8>(v, key);
+    seg_scan_step<1>(v, key);
+    seg_scan_step<2>(v, key);
+    seg_scan_step<4>(v, key);
+    seg_scan_step<8>(v, key);
 }
 
 template <int CTRL, int ROW_MASK>
