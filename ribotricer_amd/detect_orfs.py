@@ -154,9 +154,9 @@ def gather_profiles(records, merged_alignments, device=None):
 def gather_profiles_indexed(index, merged_alignments, device=None):
     """Same for a natively parsed index (``ribotricer_amd.index.NativeIndex``): the interval
     table comes from the parser's arrays, no per-ORF Python."""
-    from .gather import build_dense_coverage_from_extents, gather_profiles_device, interval_table_from_index
+    from .gather import build_dense_coverage_device, gather_profiles_device, interval_table_from_index
 
-    coverage, base = build_dense_coverage_from_extents(merged_alignments, index.extents)
+    coverage, base = build_dense_coverage_device(merged_alignments, index.extents, device)
     return gather_profiles_device(coverage, interval_table_from_index(index, base), device)
 
 

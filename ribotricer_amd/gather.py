@@ -14,6 +14,7 @@ Host work is O(reads + intervals) numpy, no per-nucleotide Python.
 from __future__ import annotations
 
 import ctypes
+from operator import itemgetter
 from typing import NamedTuple
 
 import numpy as np
@@ -51,33 +52,82 @@ def build_dense_coverage(merged_alignments, records):
     return build_dense_coverage_from_extents(merged_alignments, extent)
 
 
-def build_dense_coverage_from_extents(merged_alignments, extent: dict):
-    """Same, from ``extent[(strand, chrom)] = (lo, hi)`` (what the native index parser
-    reports per group)."""
+def coverage_layout(extent: dict):
+    """``base[(strand, chrom)] = (index_of_position_lo, lo)`` and the total length of the
+    concatenated dense coverage, groups in sorted key order."""
     base = {}
     total = 0
     for key in sorted(extent):
         lo, hi = extent[key]
         base[key] = (total, lo)
         total += hi - lo + 1
-    coverage = np.zeros(total, np.int32)
+    return base, total
+
+
+def coverage_entries(merged_alignments, extent: dict, base: dict):
+    """The non-zero entries of the dense coverage as ``(index int64[], count int32[])``:
+    one per (strand, chrom, pos) key that falls inside a group's extent.  O(reads) numpy."""
+    all_idx, all_cnt = [], []
     for strand, table in merged_alignments.items():
         if not table:
             continue
-        by_chrom: dict = {}
-        for (chrom, pos), count in table.items():
-            by_chrom.setdefault(chrom, []).append((pos, count))
-        for chrom, items in by_chrom.items():
+        # the Counter's keys are (chrom, pos) tuples: split them at C speed, then numpy
+        keys = list(table.keys())
+        pos = np.fromiter(map(itemgetter(1), keys), np.int64, len(keys))
+        cnt = np.fromiter(table.values(), np.int64, len(keys))
+        names, code = _factorize(list(map(itemgetter(0), keys)))
+        start = np.full(len(names), -1, np.int64)
+        lo = np.zeros(len(names), np.int64)
+        hi = np.full(len(names), -1, np.int64)
+        for k, chrom in enumerate(names):
             key = (strand, chrom)
-            if key not in base:
-                continue
-            start, lo = base[key]
-            hi = extent[key][1]
-            arr = np.asarray(items, dtype=np.int64)
-            keep = (arr[:, 0] >= lo) & (arr[:, 0] <= hi)
-            arr = arr[keep]
-            np.add.at(coverage, start + (arr[:, 0] - lo), arr[:, 1].astype(np.int32))
+            if key in base:
+                start[k], lo[k] = base[key]
+                hi[k] = extent[key][1]
+        keep = (start[code] >= 0) & (pos >= lo[code]) & (pos <= hi[code])
+        code, pos, cnt = code[keep], pos[keep], cnt[keep]
+        all_idx.append(start[code] + (pos - lo[code]))
+        all_cnt.append(cnt.astype(np.int32))
+    if not all_idx:
+        return np.zeros(0, np.int64), np.zeros(0, np.int32)
+    return np.concatenate(all_idx), np.concatenate(all_cnt)
+
+
+def build_dense_coverage_from_extents(merged_alignments, extent: dict):
+    """Same as :func:`build_dense_coverage`, from ``extent[(strand, chrom)] = (lo, hi)`` (what
+    the native index parser reports per group).  Host array; the export path uses
+    :func:`build_dense_coverage_device` instead."""
+    base, total = coverage_layout(extent)
+    coverage = np.zeros(total, np.int32)
+    idx, cnt = coverage_entries(merged_alignments, extent, base)
+    coverage[idx] = cnt  # (strand, chrom, pos) keys are unique, so a plain scatter is enough
     return coverage, base
+
+
+def build_dense_coverage_device(merged_alignments, extent: dict, device=None):
+    """Dense coverage laid out directly in HBM: only the non-zero entries (12 bytes per
+    distinct P-site position) cross PCIe and are scattered into a zero-filled device
+    array -- for a human-sized index the dense array is tens of GB, mostly zeros."""
+    dev = get_engine(device).device
+    base, total = coverage_layout(extent)
+    idx, cnt = coverage_entries(merged_alignments, extent, base)
+    coverage = torch.zeros(total, dtype=torch.int32, device=dev)
+    if idx.size:
+        coverage[torch.from_numpy(idx).to(dev)] = torch.from_numpy(cnt).to(dev)
+    return coverage, base
+
+
+def _factorize(values):
+    """(unique values in order of first appearance, int codes) -- hash based."""
+    try:
+        import pandas as pd
+
+        code, names = pd.factorize(np.asarray(values, dtype=object))
+        return list(names), code.astype(np.int64)
+    except ImportError:  # pragma: no cover - pandas ships with the image
+        seen: dict = {}
+        code = np.fromiter((seen.setdefault(v, len(seen)) for v in values), np.int64, len(values))
+        return list(seen), code
 
 
 def build_interval_table(records, base) -> IntervalTable:

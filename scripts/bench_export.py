@@ -1,0 +1,86 @@
+"""End-to-end timing of the drop-in export path on a synthetic index (run on the GPU box):
+index text -> rp_index_parse_host (f3) -> dense coverage -> rp_gather_profiles_dev (f1)
+-> rp_phase_score_csr_dev -> D2H -> rp_format_rows_host (f2) -> file.
+usage: python scripts/bench_export.py [n_orfs] [reads_per_orf]"""
+import json
+import os
+import sys
+import tempfile
+import time
+from collections import Counter, defaultdict
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ribotricer_amd import detect_orfs as d  # noqa: E402
+from ribotricer_amd import tsv  # noqa: E402
+from ribotricer_amd.gather import build_dense_coverage_device, gather_profiles_device, interval_table_from_index  # noqa: E402
+from ribotricer_amd.index import NativeIndex  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
+reads_per_orf = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
+rng = np.random.default_rng(7)
+chroms = [f"chr{k}" for k in range(1, 23)]
+lines = ["ORF_ID\tORF_type\ttranscript_id\ttranscript_type\tgene_id\tgene_name\tgene_type\tchrom\tstrand\tstart_codon\tcoordinate\n"]
+cursor = {(s, c): 1000 for s in "+-" for c in chroms}
+spans = []
+for i in range(n):
+    c, s = chroms[i % 22], "+-"[(i // 22) % 2]
+    pos = cursor[(s, c)]
+    k = int(rng.integers(1, 5))
+    per = max(10, int(rng.lognormal(np.log(240), 0.7)) // k // 3 * 3 // 1)
+    ivs = []
+    for _ in range(k):
+        ivs.append((pos, pos + per - 1))
+        pos += per + int(rng.integers(80, 400))
+    cursor[(s, c)] = pos + 50
+    spans.append((s, c, ivs))
+    lines.append(f"x\tannotated\tENST{i:011d}\tprotein_coding\tENSG{i//3:011d}\tGENE{i//3}\tprotein_coding\t{c}\t{s}\tATG\t{','.join(f'{a}-{b}' for a, b in ivs)}\n")
+text = "".join(lines).encode()
+align = defaultdict(Counter)
+n_reads = int(n * reads_per_orf)
+pick = rng.integers(0, n, n_reads)
+for j in pick:
+    s, c, ivs = spans[j]
+    a, b = ivs[int(rng.integers(0, len(ivs)))]
+    align[s][(c, int(rng.integers(a, b + 1)))] += 1
+tmp = tempfile.mkdtemp()
+index_path = os.path.join(tmp, "candidate_orfs.tsv")
+open(index_path, "wb").write(text)
+NativeIndex(b"")
+torch.zeros(1, device="cuda")
+
+T = {}
+def lap(name, t0):
+    torch.cuda.synchronize()
+    T[name] = time.perf_counter() - t0
+    return time.perf_counter()
+
+t = time.perf_counter()
+index = NativeIndex.from_file(index_path); t = lap("parse_index_f3", t)
+coverage, base = build_dense_coverage_device(align, index.extents); t = lap("counter_to_device_coverage", t)
+table = interval_table_from_index(index, base); t = lap("interval_table_numpy", t)
+d_counts, d_offsets = gather_profiles_device(coverage, table); t = lap("table_h2d_plus_gather_f1", t)
+res = d.score_profiles(d_counts, d_offsets, 0.428571428571, 5, 0, 0, 0.0); t = lap("score_plus_d2h_outputs", t)
+counts, offsets = d_counts.cpu().numpy(), d_offsets.cpu().numpy(); t = lap("d2h_profiles", t)
+out_path = os.path.join(tmp, "out.tsv")
+with open(out_path, "wb") as fh:
+    fh.write(("\t".join(d.COLUMNS) + "\n").encode())
+    for chunk in tsv.format_rows_native(counts, offsets, res["phase"], res["valid"], res["read_count"], res["status"], index.tables, True):
+        fh.write(chunk)
+t = lap("format_f2_plus_write", t)
+size = os.path.getsize(out_path)
+total = sum(T.values())
+# the whole thing once more through the public entry point (report_all=False, the CLI default)
+t0 = time.perf_counter()
+d.export_orf_coverages(index_path, align, os.path.join(tmp, "x"))
+t_export = time.perf_counter() - t0
+print(json.dumps({
+    "n_orfs": n, "total_nt": int(offsets[-1]), "reads": n_reads, "tsv_bytes_report_all": size,
+    "seconds": {k: round(v, 4) for k, v in T.items()}, "total_s": round(total, 3), "orfs_per_s_report_all": round(n / total),
+    "export_orf_coverages_default_s": round(t_export, 3), "translating": int(res["status"].sum()),
+}))
+for f in os.listdir(tmp):
+    os.remove(os.path.join(tmp, f))
+os.rmdir(tmp)
