@@ -73,7 +73,7 @@ __device__ __forceinline__ void codon_add(FrameAcc<float> &acc, int a, int b, in
 // fp64: q is an exact integer-valued double, r = rsqrt(q) after one Newton step is good
 // to ~1 ulp.  Frames that tie in exact arithmetic may then differ by ~1e-16 relative,
 // which the RP_TIE_RTOL rule of combine_frames absorbs (a correctly rounded sqrt + two
-// divisions cost 4x more and made the float64 re-walks the slowest part of finalize).
+// divisions cost 4x more and made the float64 re-walks the slowest part of the finish kernel).
 __device__ __forceinline__ double rsqrt_f64(double q)
 {
     double r = __builtin_amdgcn_rsq(q);          // v_rsq_f64, ~2^-26 relative

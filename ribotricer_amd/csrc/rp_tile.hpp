@@ -331,8 +331,9 @@ __device__ __forceinline__ float min_nonneg(float x, float hi)
 // clamp(x, 0, 1): folds into the producing instruction's clamp modifier
 __device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 
-// The lane run, predicate-free: every test is folded into fp32 arithmetic so the loop is
-// 16 VALU instructions per codon with no v_cmp / v_cndmask / scalar mask traffic:
+// The lane run, predicate-free: every test is folded into arithmetic so the float part of
+// the loop is 15 VALU instructions per codon with no v_cmp / v_cndmask / scalar mask traffic
+// (the masked integer count / minimum of frame 0 adds 2 per codon):
 //   vF  = clamp(lim - c, 0, 1)          1 while codon c is a real codon of this run
 //   r   = min(rsq(q), vF)               1/sqrt(q);  a == b == c gives rsq(0) = inf -> 1, and
 //                                       its d0 = d1 = 0 make the products below exactly 0

@@ -5,7 +5,7 @@
 // (statistics.py:67-91 walks the three frames one after the other; here they
 // share one read of the profile).  Used as
 //   * the simple scoring path (RP_ALGO_WAVE),
-//   * the float64 recheck / split-ORF finalize path of the tile kernels,
+//   * the float64 re-walk of too-close-to-call ORFs in k_orf_finish (rp_tile.hpp),
 //   * the per-frame diagnostics and float64-profile entry points.
 #pragma once
 

@@ -9,6 +9,8 @@ Replaces the per-ORF ``formatter.format(...)`` of the reference's output loop
 from __future__ import annotations
 
 import ctypes
+import os
+import threading
 from typing import Iterator, Sequence
 
 import numpy as np
@@ -16,6 +18,7 @@ import numpy as np
 from . import _lib
 
 RP_ERR_SIZE = -2
+_tls = threading.local()
 
 
 def double_repr(value: float) -> str:
@@ -52,40 +55,19 @@ def record_tables(records):
     return head, head_off, tail, tail_off
 
 
-def format_rows_native(
-    counts: np.ndarray,
-    offsets: np.ndarray,
-    phase: np.ndarray,
-    valid: np.ndarray,
-    read_count: np.ndarray,
-    status: np.ndarray,
-    tables,
-    report_all: bool,
-    first: int = 0,
-    last: int | None = None,
-    chunk_bytes: int = 64 << 20,
-) -> Iterator[bytes]:
-    """Yield the TSV body of ORFs [first, last) in chunks of at most ``chunk_bytes``
-    (a single longer row gets a buffer of its own)."""
+def _format_range(arrays, tables_c, report_all, first, last, chunk_bytes) -> list:
+    """Rows of ORFs [first, last) as a list of byte chunks (one C call per chunk)."""
     lib = _lib.load()
-    counts = np.ascontiguousarray(counts, dtype=np.int32)
-    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
-    phase = np.ascontiguousarray(phase, dtype=np.float64)
-    valid = np.ascontiguousarray(valid, dtype=np.int32)
-    read_count = np.ascontiguousarray(read_count, dtype=np.int64)
-    status = np.ascontiguousarray(status, dtype=np.uint8)
-    head, head_off, tail, tail_off = tables
-    n = offsets.size - 1
-    last = n if last is None else last
-    if not (phase.size == valid.size == read_count.size == status.size == n == head_off.size - 1 == tail_off.size - 1):
-        raise ValueError("per-ORF arrays and string tables must all have n_orfs entries")
-    head_buf = ctypes.create_string_buffer(head, len(head)) if head else ctypes.create_string_buffer(1)
-    tail_buf = ctypes.create_string_buffer(tail, len(tail)) if tail else ctypes.create_string_buffer(1)
+    counts, offsets, phase, valid, read_count, status = arrays
+    head_buf, head_off, tail_buf, tail_off = tables_c
     cap = chunk_bytes
-    out = ctypes.create_string_buffer(cap)
+    out = getattr(_tls, "out", None)  # one reusable buffer per thread: first touch is the costly part
+    if out is None or len(out) != cap:
+        out = _tls.out = ctypes.create_string_buffer(cap)
     nxt = ctypes.c_int64(first)
     ln = ctypes.c_size_t(0)
     cur = first
+    chunks = []
     while cur < last:
         rc = lib.rp_format_rows_host(
             counts.ctypes.data, offsets.ctypes.data, last, phase.ctypes.data, valid.ctypes.data,
@@ -100,5 +82,65 @@ def format_rows_native(
             continue
         _lib.check(rc)
         if ln.value:
-            yield out.raw[: ln.value]
+            chunks.append(out.raw[: ln.value])
         cur = nxt.value
+    return chunks
+
+
+def format_rows_native(
+    counts: np.ndarray,
+    offsets: np.ndarray,
+    phase: np.ndarray,
+    valid: np.ndarray,
+    read_count: np.ndarray,
+    status: np.ndarray,
+    tables,
+    report_all: bool,
+    first: int = 0,
+    last: int | None = None,
+    chunk_bytes: int = 64 << 20,
+    threads: int | None = None,
+) -> Iterator[bytes]:
+    """Yield the TSV body of ORFs [first, last), in order, in chunks of at most
+    ``chunk_bytes`` (a single longer row gets a buffer of its own).
+
+    ``threads`` > 1 renders disjoint ORF ranges concurrently (the C call holds no shared
+    state and ctypes drops the GIL); default: up to 8, one for small batches."""
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    phase = np.ascontiguousarray(phase, dtype=np.float64)
+    valid = np.ascontiguousarray(valid, dtype=np.int32)
+    read_count = np.ascontiguousarray(read_count, dtype=np.int64)
+    status = np.ascontiguousarray(status, dtype=np.uint8)
+    head, head_off, tail, tail_off = tables
+    n = offsets.size - 1
+    last = n if last is None else last
+    if not (phase.size == valid.size == read_count.size == status.size == n == head_off.size - 1 == tail_off.size - 1):
+        raise ValueError("per-ORF arrays and string tables must all have n_orfs entries")
+    head_buf = ctypes.create_string_buffer(head, len(head)) if head else ctypes.create_string_buffer(1)
+    tail_buf = ctypes.create_string_buffer(tail, len(tail)) if tail else ctypes.create_string_buffer(1)
+    arrays = (counts, offsets, phase, valid, read_count, status)
+    tables_c = (head_buf, np.ascontiguousarray(head_off, dtype=np.int64), tail_buf, np.ascontiguousarray(tail_off, dtype=np.int64))
+    total_nt = int(offsets[last] - offsets[first]) if last > first else 0
+    if threads is None:
+        threads = min(8, os.cpu_count() or 1) if total_nt > (4 << 20) else 1
+    if threads <= 1 or last - first < 2:
+        yield from _format_range(arrays, tables_c, report_all, first, last, chunk_bytes)
+        return
+    # ranges of about chunk_bytes / 4 nucleotides (a row is ~3.2 bytes of text per nt), cut on
+    # the prefix sum of lengths; a sliding window of futures keeps the output ordered and bounded
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+
+    chunk_bytes = max(1 << 20, chunk_bytes // threads)  # per-thread buffer
+    per_range = max(1, min(chunk_bytes // 4, -(-total_nt // threads)))
+    cuts = np.searchsorted(offsets[first : last + 1], offsets[first] + np.arange(per_range, total_nt, per_range)) + first
+    bounds = np.unique(np.concatenate(([first], cuts, [last])))
+    window: deque = deque()
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            window.append(pool.submit(_format_range, arrays, tables_c, report_all, int(a), int(b), chunk_bytes))
+            if len(window) >= 2 * threads:
+                yield from window.popleft().result()
+        while window:
+            yield from window.popleft().result()
