@@ -247,3 +247,18 @@ def test_native_index_line_semantics():
         with pytest.raises(RibophaseError) as e2:
             NativeIndex(hdr + line.replace(" 30-40,+5-9 ,10-12", bad).encode("utf-8"))
         assert e2.value.status == -10
+
+
+@pytest.mark.parametrize("threads", [2, 5])
+def test_native_rows_threaded_equal_serial(packed, threads):
+    from ribotricer_amd import tsv
+
+    records, counts, offsets = packed
+    res = oracle_results(counts, offsets)
+    tables = tsv.record_tables(records)
+    args = (counts, offsets, res["phase"], res["valid"], res["read_count"], res["status"], tables)
+    serial = b"".join(tsv.format_rows_native(*args, True, threads=1))
+    for chunk_bytes in (1 << 20, 4096):
+        assert b"".join(tsv.format_rows_native(*args, True, threads=threads, chunk_bytes=chunk_bytes)) == serial
+    part = b"".join(tsv.format_rows_native(*args, False, first=17, last=140, threads=threads, chunk_bytes=2048))
+    assert part == b"".join(tsv.format_rows_native(*args, False, first=17, last=140, threads=1))
