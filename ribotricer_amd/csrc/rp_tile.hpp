@@ -181,19 +181,25 @@ __device__ __forceinline__ void load_tile_to_lds(const int32_t *__restrict__ cou
         const int lane = tid & (kWave - 1);
         const int32_t *src = counts + t0 + 4 * lane;
         // rows dealt round-robin to waves 1-3: issuing stalls a wave until the memory pipe has
-        // taken its requests, and wave 0 builds the segment table meanwhile
-        const int w = (tid >> 6) - 1;
+        // taken its requests, and wave 0 builds the segment table meanwhile.  The wave index is
+        // made scalar so that the row loop is straight-line code (row = w, w+3, ...; M0 and the
+        // global offset are SALU arithmetic) instead of one exec-mask branch per row.
+        constexpr int kIssuers = kTileBlock / kWave - 1;
+        constexpr int kRows = kTile / kRowPos;
+        constexpr int kEven = kRows / kIssuers;  // rows every issuing wave takes
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6) - 1;
         if (w >= 0) {
 #pragma unroll
-            for (int row = 0; row < kTile / kRowPos; ++row) {
-                if (row % (kTileBlock / kWave - 1) == w)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(src + row * kRowPos), (lptr_t)(s_counts + row * kRowPos), 16, 0, 0);
+            for (int k = 0; k < kEven; ++k) {
+                const int row = w + kIssuers * k;  // < kRows for every issuing wave
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + row * kRowPos), (lptr_t)(s_counts + row * kRowPos), 16, 0, 0);
             }
-        }
-        if (tid >= kWave && tid < kWave + 2) {  // halo: 2 chunks past the tile
-            const int h = tid - kWave;
-            const int4 v = *reinterpret_cast<const int4 *>(counts + t0 + kTile + 4 * h);
-            *reinterpret_cast<int4 *>(s_counts + kTile + 4 * h) = v;
+#pragma unroll
+            for (int row = kEven * kIssuers; row < kRows; ++row)  // the left-over rows, one per wave
+                if (w == row - kEven * kIssuers)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src + row * kRowPos), (lptr_t)(s_counts + row * kRowPos), 16, 0, 0);
+            if (w == kIssuers - 1 && lane < kHalo / 4)  // halo: 2 chunks past the tile
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + kTile), (lptr_t)(s_counts + kTile), 16, 0, 0);
         }
         // NOTE: no wait here -- the caller waits (vmcnt only tracks the DMA) after it has
         // issued its own independent loads
