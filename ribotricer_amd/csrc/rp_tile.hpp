@@ -18,7 +18,7 @@
 //      float sums are folded by a segmented DPP scan inside each 16-lane row into one
 //      record per (segment, row) -- deterministic, no float atomics;
 //   4. one thread per segment sums its row records in float64 and writes ONE segment
-//      record (six float64 sums, packed N/M, read count, minimum codon coverage) to the
+//      record (six sums, packed N/M, read count, minimum codon coverage) to the
 //      workspace, struct-of-arrays, at index  orf + tile  (unique and increasing);
 //   5. k_orf_finish, one thread per ORF at full occupancy, adds the records of the tiles
 //      the ORF spans (one, for most), scores the frames, runs the state machine and the
@@ -28,7 +28,7 @@
 // The scoring kernel used to finish the ORFs itself (frame scores, float64 re-walk out of
 // LDS); that is a ~300-instruction dependent float64 chain run by ONE wave per workgroup
 // while the other three idle and the LDS tile stays allocated.  Splitting it off costs
-// 76 bytes of write + read per segment (~7 % more traffic) and took the scoring kernel
+// 52 bytes of write + read per segment (~5 % more traffic) and took the scoring kernel
 // from 0.317 to 0.276 ms on BASELINE configs[1].
 //
 // Ownership rule: a triplet (3 positions from an ORF-relative multiple of 3) belongs
@@ -61,14 +61,19 @@ struct TilePlan {
 // owns.  Struct of arrays, indexed by  orf + tile : an ORF spanning tiles s..e owns the
 // ids orf+s .. orf+e, and the next ORF starts in a tile >= e, so ids never collide.
 struct SegRecords {
-    double *pq;                 // [6][n_rec]  p[0..2], q[0..2]
+#ifdef RP_REC_F64
+    typedef double pq_t;
+#else
+    typedef float pq_t;  // the float64 sum of <= 11 fp32 row records, rounded once: +-6e-8 relative
+#endif
+    pq_t *pq;                   // [6][n_rec]  p[0..2], q[0..2]
     unsigned long long *nn;     // [n_rec]     n[0] | n[1] << 21 | n[2] << 42
     unsigned long long *mm;     // [n_rec]     same packing
     unsigned long long *count;  // [n_rec]     reads
     unsigned *min_codon;        // [n_rec]     RP_MIN_CODON_COV_EMPTY when no codon
     long long n_rec;
 };
-constexpr size_t kRecordBytes = 6 * 8 + 3 * 8 + 4;
+constexpr size_t kRecordBytes = 6 * sizeof(SegRecords::pq_t) + 3 * 8 + 4;
 
 struct TileWorkspace {
     long long *tile_first;  // [n_tiles + 1] first ORF starting at/after each tile start
@@ -112,8 +117,8 @@ inline TileWorkspace carve_workspace(void *base, long long n_orfs, long long tot
     p += tile_index_bytes(total_nt, tile);
     const size_t n = (size_t)max_records(n_orfs, total_nt, tile);
     ws.rec.n_rec = (long long)n;
-    ws.rec.pq = reinterpret_cast<double *>(p);
-    p += 6 * n * sizeof(double);
+    ws.rec.pq = reinterpret_cast<SegRecords::pq_t *>(p);
+    p += 6 * n * sizeof(SegRecords::pq_t);
     ws.rec.nn = reinterpret_cast<unsigned long long *>(p);
     p += n * sizeof(unsigned long long);
     ws.rec.mm = reinterpret_cast<unsigned long long *>(p);
@@ -407,8 +412,8 @@ __device__ __forceinline__ void store_record(const SegRecords &r, long long id, 
 {
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
-        r.pq[f * r.n_rec + id] = p[f];
-        r.pq[(3 + f) * r.n_rec + id] = q[f];
+        r.pq[f * r.n_rec + id] = (SegRecords::pq_t)p[f];
+        r.pq[(3 + f) * r.n_rec + id] = (SegRecords::pq_t)q[f];
     }
     r.nn[id] = nn;
     r.mm[id] = mm;
@@ -647,8 +652,8 @@ __global__ __launch_bounds__(kTileBlock) void k_orf_finish(const int32_t *__rest
                 const unsigned long long nn = r.nn[id], mm = r.mm[id];
 #pragma unroll
                 for (int f = 0; f < 3; ++f) {
-                    p[f] += r.pq[f * r.n_rec + id];
-                    q[f] += r.pq[(3 + f) * r.n_rec + id];
+                    p[f] += (double)r.pq[f * r.n_rec + id];
+                    q[f] += (double)r.pq[(3 + f) * r.n_rec + id];
                     n[f] += (int)((nn >> (21 * f)) & 0x1fffffu);
                     m[f] += (int)((mm >> (21 * f)) & 0x1fffffu);
                 }
