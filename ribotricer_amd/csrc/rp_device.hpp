@@ -25,10 +25,19 @@ namespace rp {
 
 constexpr int kWave = 64;
 
-// absolute/relative margin under which an fp32 frame comparison is not trusted and
-// the ORF is re-derived in float64 (fp32 score error is <= ~3e-6 for the longest
-// per-lane sums we allow in fp32; see DESIGN.md "Precision").
+// Margins under which an fp32 frame comparison is not trusted and the ORF is re-derived in
+// float64.
+//  * kRecheckMargin, relative to max(1, score): the wave-per-ORF path, whose per-lane fp32
+//    sums grow with the ORF (error <= ~3e-6 for the longest we allow in fp32).
+//  * the tile path keeps every fp32 sum short (<= 45 terms per lane, <= 16 lanes per row,
+//    float64 above): with gamma ~ 61 * 2^-24 the error of P, Q is <= gamma * M, hence the
+//    error of score = |sum u|^2 / (N M) is <= 2 gamma |sum u| / N = 2 gamma sqrt(score M / N)
+//    <= 7.4e-6 * sqrt(score) in the worst case (typically 30x less).  Margin:
+//    kTileMargin * sqrt(score) + kTileMarginAbs; the absolute part covers the second-order
+//    term gamma^2 M / N and stays above the tie tolerance (RP_TIE_RTOL).
 constexpr double kRecheckMargin = 1e-5;
+constexpr double kTileMargin = 1e-5;
+constexpr double kTileMarginAbs = 1e-8;
 
 // ---------------------------------------------------------------------------
 // per-codon accumulation
@@ -260,7 +269,7 @@ __device__ __forceinline__ void combine_frames(const FrameScore (&fr)[3], double
 // all carry the same N the choice between them cannot change valid_codons; if two of them
 // differ in N the ORF is re-walked in float64.  (Close pairs further down the ranking are
 // common in sparse profiles and irrelevant.)
-__device__ __forceinline__ bool fp32_decision_unsafe(const FrameScore (&fr)[3])
+__device__ __forceinline__ bool fp32_decision_unsafe(const FrameScore (&fr)[3], bool tile_sums = false)
 {
     int first_live = 0;
 #pragma unroll
@@ -272,7 +281,9 @@ __device__ __forceinline__ bool fp32_decision_unsafe(const FrameScore (&fr)[3])
 #pragma unroll
     for (int f = 0; f < 3; ++f)
         if (f >= first_live) smax = fmax(smax, fr[f].score);  // fmax ignores a NaN score
-    const double thr = smax - kRecheckMargin * fmax(1.0, smax);
+    const double margin = tile_sums ? kTileMargin * (smax > 0.0 ? smax * rsqrt_f64(smax) : 0.0) + kTileMarginAbs
+                                    : kRecheckMargin * fmax(1.0, smax);
+    const double thr = smax - margin;
     int n_ref = 0.0 >= thr ? n_fallback : -1;
     bool unsafe = false;
 #pragma unroll

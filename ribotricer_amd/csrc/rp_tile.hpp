@@ -665,7 +665,7 @@ __global__ __launch_bounds__(kTileBlock) void k_orf_finish(const int32_t *__rest
         FrameScore fr[3];
 #pragma unroll
         for (int f = 0; f < 3; ++f) fr[f] = frame_score(p[f], q[f], n[f], m[f]);
-        unsafe = fp32_decision_unsafe(fr);
+        unsafe = fp32_decision_unsafe(fr, /*tile_sums=*/true);
         if (!unsafe) {
             double phase;
             int valid;
