@@ -16,6 +16,27 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $W/pmc3 -o pmc3 -- python3 ben
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $W/pmc4 -o pmc4 -- python3 bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 > $OUT/pmc4_bench.log 2>&1
 find $W -name "*.csv" | while read f; do echo "$f $(wc -c < $f)"; done
 cp $(find $W/stats -name "*kernel_stats.csv") $OUT/kernel_stats.csv 2>/dev/null
+# rocprofv3's stats give mean/min/max; add the median and the mean of the timed region (the
+# last 20 + 20 launches: bench.py times 20 steps, then 20 more with per-kernel events) per kernel
+python3 - "$W" "$OUT" <<'PY'
+import csv, glob, sys, statistics
+W, OUT = sys.argv[1], sys.argv[2]
+rows = {}
+for f in glob.glob(f"{W}/stats/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = r.get("Kernel_Name", "?")
+        if "rp::" not in name:
+            continue
+        rows.setdefault(name[:70], []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+with open(f"{OUT}/kernel_durations.csv", "w") as fh:
+    fh.write("kernel,calls,mean_ns,median_ns,min_ns,max_ns,mean_last40_ns\n")
+    for name, v in sorted(rows.items()):
+        v.sort()
+        d = [x[1] for x in v]
+        last = d[-40:]
+        fh.write(f"\"{name}\",{len(d)},{statistics.mean(d):.0f},{statistics.median(d):.0f},{min(d)},{max(d)},{statistics.mean(last):.0f}\n")
+print(open(f"{OUT}/kernel_durations.csv").read())
+PY
 # per-kernel mean of every counter (counter_collection csv is one row per dispatch x counter)
 python3 - "$W" "$OUT" <<'PY'
 import csv, glob, sys, collections
