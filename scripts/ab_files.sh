@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of two versions of the tile headers kept under scripts/_ab/ (*.A = reference, *.B = candidate):
+# A/B of two versions of the tile headers: put them under scripts/_ab/ as rp_tile.hpp.A / .B and
+# rp_tile_pipe.hpp.A / .B (A = reference, e.g. from `git show HEAD:...`, B = candidate):
 # parity tests + two bench runs each, alternating, on one box.
 cd ${GRAFT_REPO_ROOT:-.}
 for V in A B A B; do
