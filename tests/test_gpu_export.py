@@ -95,3 +95,33 @@ def test_device_gather_random_intervals():
         if reverse[i]:
             want = want[::-1]
         assert np.array_equal(got[offsets[i] : offsets[i + 1]], want), i
+
+
+def test_export_edge_indexes(tmp_path):
+    """Header-only index, alignments on a strand / chromosome no ORF uses, an ORF with no
+    reads at all: same files as the reference's loop would write."""
+    from collections import Counter, defaultdict
+
+    from ribotricer_amd.detect_orfs import COLUMNS, export_orf_coverages
+
+    header = "\t".join(["ORF_ID", "ORF_type", "transcript_id", "transcript_type", "gene_id", "gene_name", "gene_type",
+                        "chrom", "strand", "start_codon", "coordinate"]) + "\n"
+    empty = tmp_path / "empty_candidate_orfs.tsv"
+    empty.write_text(header)
+    align = defaultdict(Counter)
+    align["+"][("chr1", 100)] = 3
+    export_orf_coverages(str(empty), align, str(tmp_path / "e"))
+    assert (tmp_path / "e_translating_ORFs.tsv").read_text() == "\t".join(COLUMNS) + "\n"
+
+    one = tmp_path / "one_candidate_orfs.tsv"
+    one.write_text(header + "x\tannotated\ttx\tpc\tg\tn\tpc\tchr2\t-\tATG\t10-18,30-38\n")
+    align["-"][("chr2", 12)] = 5
+    align["-"][("chr2", 500)] = 7     # outside every ORF
+    align["+"][("chr2", 12)] = 9      # other strand
+    export_orf_coverages(str(one), align, str(tmp_path / "o"), report_all=True)
+    rows = (tmp_path / "o_translating_ORFs.tsv").read_text().splitlines()
+    assert len(rows) == 2
+    f = rows[1].split("\t")
+    assert f[0] == "tx_10_38_18" and f[2] == "nontranslating" and f[4:6] == ["5", "18"]
+    # '-' strand: the profile is reversed (detect_orfs.py:201-202); position 12 is the 3rd of 10-18
+    assert f[17] == str([0] * 9 + [0, 0, 0, 0, 0, 0, 5, 0, 0])
