@@ -1,0 +1,68 @@
+"""Seeded fuzz of the tile paths against the C oracle: batch shapes built around the tile
+size (ORFs that end exactly on, one before and one after a tile boundary, runs of empty
+ORFs on a boundary, ORFs spanning several tiles, many tiny ORFs per tile), random pointer
+misalignment, counts up to RP_MAX_COUNT, lengths that are not multiples of 3."""
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_matches_oracle
+
+pytestmark = pytest.mark.gpu
+
+TILES = {"tile": 7936, "pipe": 10240}
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from ribotricer_amd.engine import PhaseScoreEngine
+
+    return PhaseScoreEngine("cuda:0")
+
+
+def lengths_for(seed: int, tile: int) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    kind = seed % 6
+    if kind == 0:  # boundary hugging: cumulative ends at tile*k + {-2..2}
+        ends = np.sort(np.unique(np.concatenate([tile * np.arange(1, 9) + d for d in (-2, -1, 0, 1, 2)])))
+        lens = np.diff(np.concatenate([[0], ends]))
+    elif kind == 1:  # empty ORFs piled on boundaries and at both ends
+        body = rng.integers(1, 900, 60)
+        lens = np.concatenate([[0, 0], body[:20], [tile - int(body[:20].sum()) % tile], [0] * 5, body[20:], [0, 0, 0]])
+    elif kind == 2:  # several multi-tile ORFs in a row, then short ones
+        lens = np.concatenate([rng.integers(tile, 4 * tile, 4), rng.integers(1, 50, 300), [3 * tile + 1]])
+    elif kind == 3:  # > 64 and > 128 segments per tile
+        lens = rng.integers(1, 40, 3000)
+    elif kind == 4:  # one ORF exactly one tile, one exactly two, neighbours of 1 and 2 nt
+        lens = np.array([1, tile, 2, 2 * tile, 1, 1, tile - 1, tile + 1, 3, 5])
+    else:  # plain ragged
+        lens = np.clip(np.rint(rng.lognormal(np.log(240), 1.0, 400)), 0, 40000).astype(np.int64)
+    return np.asarray(lens, np.int64)
+
+
+@pytest.mark.parametrize("algo", ["tile", "pipe"])
+@pytest.mark.parametrize("seed", range(18))
+def test_fuzz_against_oracle(eng, algo, seed):
+    rng = np.random.default_rng(1000 + seed)
+    lens = lengths_for(seed, TILES[algo])
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    total = int(offsets[-1])
+    lam = rng.choice([0.02, 0.3, 3.0], size=lens.size)
+    counts = rng.poisson(np.repeat(lam, lens)).astype(np.int32)
+    if seed % 4 == 1 and total:  # a few huge counts (exact in fp32 up to 2^24 - 1)
+        counts[rng.integers(0, total, 20)] = 2**24 - 1
+        counts[rng.integers(0, total, 20)] = 2**24 - 2
+    mis = seed % 4  # start the device array 0..3 ints off a 16-byte boundary
+    dev = torch.zeros(total + 8, dtype=torch.int32, device="cuda:0")
+    view = dev[mis : mis + total]
+    view.copy_(torch.from_numpy(counts))
+    r = eng.score(view, torch.from_numpy(offsets).cuda(), algo=algo)
+    torch.cuda.synchronize()
+    res = r.cpu_numpy()
+    assert_matches_oracle(res, counts, offsets)
+    split = (res["flags"] & 4) != 0
+    tile = TILES[algo]
+    starts, ends = offsets[:-1] + mis, offsets[1:] + mis
+    expect_split = (lens > 0) & ((ends - 1) // tile > starts // tile)
+    assert np.array_equal(split, expect_split)
