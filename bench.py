@@ -179,7 +179,8 @@ def main():
     if rank == 0:
         algo_bytes = 4 * total_nt + 8 * (n_orfs + 1) + 24 * n_orfs
         achieved = algo_bytes / (k_main * 1e-3) / 1e9
-        resolved = "tile" if algo == "auto" else algo  # RP_ALGO_AUTO -> RP_ALGO_TILE (ribophase.hip)
+        # RP_ALGO_AUTO -> RP_ALGO_TILE from 2 Mi nucleotides up (ribophase.hip), RP_ALGO_WAVE below
+        resolved = ("tile" if total_nt >= (2 << 20) else "wave") if algo == "auto" else algo
         traffic = measured_traffic(args, n_orfs, resolved)
         flags = out.flags
         result = {

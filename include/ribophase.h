@@ -69,7 +69,7 @@ typedef enum rp_status {
 
 /* kernel family selector */
 typedef enum rp_algo {
-    RP_ALGO_AUTO = 0,
+    RP_ALGO_AUTO = 0, /* RP_ALGO_TILE, or RP_ALGO_WAVE for batches under 2 Mi nucleotides */
     RP_ALGO_WAVE = 1, /* one wavefront per ORF, streaming straight from HBM */
     RP_ALGO_TILE = 2, /* LDS-staged flat tiles, ragged lane packing -> one record per (ORF, tile)
                          segment in the workspace -> one thread per ORF scores and filters */

@@ -22,6 +22,7 @@
 namespace {
 
 thread_local char g_err[512] = "";
+constexpr long long kAutoWaveNt = 2LL << 20;  // RP_ALGO_AUTO switches to the wave kernel below this
 
 int fail(int code, const char *fmt, ...)
 {
@@ -106,7 +107,9 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     }
     const rp::OrfOutputs out{d_phase, d_valid, d_read_count, d_min_codon_cov, d_flags, d_status};
     const rp::FilterParams fp = make_filter(filter, d_status);
-    if (algo == RP_ALGO_AUTO) algo = RP_ALGO_TILE;
+    // AUTO: the flat-tile path, except for batches so small that its three launches cost more
+    // than the single wave-per-ORF launch (measured crossover ~3 M nt; scripts/bench_small.py)
+    if (algo == RP_ALGO_AUTO) algo = total_nt < kAutoWaveNt ? RP_ALGO_WAVE : RP_ALGO_TILE;
     if (algo == RP_ALGO_TILE_PIPE && total_nt == 0) algo = RP_ALGO_TILE;  // nothing to prefetch
 
     if (algo == RP_ALGO_WAVE) {
