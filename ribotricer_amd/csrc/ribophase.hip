@@ -347,7 +347,8 @@ int rp_gather_profiles_dev(int device, const int32_t *d_coverage, int64_t covera
     int rc = select_device(device);
     if (rc != RP_OK) return rc;
     if (n_orfs == 0) return RP_OK;
-    const int grid = grid_for_waves(n_orfs, rp::kWaveBlock / rp::kWave);
+    // one wave per batch of 64 ORFs
+    const int grid = grid_for_waves((n_orfs + rp::kWave - 1) / rp::kWave, rp::kWaveBlock / rp::kWave);
     hipLaunchKernelGGL(rp::k_gather_profiles, dim3(grid), dim3(rp::kWaveBlock), 0, (hipStream_t)hip_stream,
                        d_coverage, (long long)coverage_len, d_iv_start, d_iv_len, d_orf_iv, d_reverse,
                        d_offsets, (long long)n_orfs, d_counts);

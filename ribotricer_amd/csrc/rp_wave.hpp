@@ -198,9 +198,54 @@ __global__ __launch_bounds__(kWaveBlock) void k_wave_score_f64in(const double *_
     }
 }
 
-// Profile gather (detect_orfs.py:134-203 for all ORFs): one wave per ORF copies its exon
-// intervals out of the dense coverage array, coalesced on both sides; '-' strand ORFs are
-// written back to front (detect_orfs.py:201-202).
+// Profile gather (detect_orfs.py:134-203 for all ORFs): the exon intervals of every ORF are
+// copied out of the dense coverage array into the CSR counts array, coalesced on both
+// sides; '-' strand ORFs are written back to front (detect_orfs.py:201-202).
+//
+// A wave takes a batch of 64 consecutive ORFs.  The per-ORF metadata (offsets, interval
+// range, strand) is loaded lane-parallel, one coalesced load per array for the whole batch,
+// and handed out with v_readlane; the interval descriptors of ORF j + 1 are fetched (lane t
+// = interval t) while ORF j is being copied.  An ORF is copied kGatherUnroll * 64 nucleotides
+// per round: a wave-uniform walk over its (few) descriptors tells every lane where each of
+// its positions comes from, all loads are issued, then all stores.  That leaves no dependent
+// global load in front of the copies except the descriptor load, which the prefetch hides.
+// Measured on 1 M ORFs of ~300 nt (2.4 GB moved): 0.73 ms = 3.3 TB/s; the first version (one
+// wave per ORF, metadata re-loaded at every step, one element per lane in flight) 1.32 ms.
+// Two flatter variants (intervals of several ORFs copied together) were slower.
+constexpr int kGatherUnroll = 8;  // independent loads in flight per lane: 512 nt per round
+
+// inclusive add-scan over the wave on the DPP network
+__device__ __forceinline__ int wave_add_scan_i32(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    return x;
+}
+
+__device__ __forceinline__ long long readlane64(long long v, int l)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)v, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), l);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// One interval, one element per lane and step (used for the rare ORFs with > 64 exons).
+__device__ __forceinline__ void gather_copy(const int32_t *__restrict__ coverage, long long coverage_len,
+                                            long long src0, int n, long long asc, long long out0, long long len,
+                                            bool rev, int32_t *__restrict__ counts, int lane)
+{
+    for (int i = lane; i < n; i += kWave) {
+        const long long src = src0 + i;
+        const int v = (src >= 0 && src < coverage_len) ? coverage[src] : 0;
+        const long long a = asc + i;
+        if (a < len) counts[out0 + (rev ? len - 1 - a : a)] = v;
+    }
+}
+
 __global__ __launch_bounds__(kWaveBlock) void k_gather_profiles(
     const int32_t *__restrict__ coverage, long long coverage_len, const int64_t *__restrict__ iv_start,
     const int32_t *__restrict__ iv_len, const int64_t *__restrict__ orf_iv,
@@ -209,22 +254,97 @@ __global__ __launch_bounds__(kWaveBlock) void k_gather_profiles(
 {
     const int lane = threadIdx.x & (kWave - 1);
     const long long waves_total = (long long)gridDim.x * (kWaveBlock / kWave);
-    long long orf = (long long)blockIdx.x * (kWaveBlock / kWave) + (threadIdx.x >> 6);
-    for (; orf < n_orfs; orf += waves_total) {
-        const long long out0 = offsets[orf];
-        const long long len = (long long)offsets[orf + 1] - out0;
-        const bool rev = reverse[orf] != 0;
-        long long asc = 0;  // ascending position of the interval's first nucleotide in the ORF
-        for (long long k = orf_iv[orf]; k < (long long)orf_iv[orf + 1]; ++k) {
-            const long long src0 = iv_start[k];
-            const int n = iv_len[k];
-            for (int j = lane; j < n; j += kWave) {
-                const long long src = src0 + j;
-                const int v = (src >= 0 && src < coverage_len) ? coverage[src] : 0;
-                const long long a = asc + j;
-                if (a < len) counts[out0 + (rev ? len - 1 - a : a)] = v;
+    const long long n_batches = (n_orfs + kWave - 1) / kWave;
+    long long batch = (long long)blockIdx.x * (kWaveBlock / kWave) + (threadIdx.x >> 6);
+    for (; batch < n_batches; batch += waves_total) {
+        const long long base = batch * kWave;
+        const long long orf = base + lane;
+        long long out0 = 0, len = 0, k0 = 0;
+        int nk = 0, rev = 0;
+        if (orf < n_orfs) {
+            out0 = offsets[orf];
+            len = (long long)offsets[orf + 1] - out0;
+            k0 = orf_iv[orf];
+            nk = (int)((long long)orf_iv[orf + 1] - k0);
+            rev = reverse[orf];
+        }
+        const int n_valid = (int)(n_orfs - base < kWave ? n_orfs - base : kWave);
+        // descriptors of the batch's first ORF, lane t = its interval t
+        long long s_cur = 0;
+        int n_cur = 0;
+        {
+            const long long k0_0 = readlane64(k0, 0);
+            const int nk_0 = __builtin_amdgcn_readlane(nk, 0);
+            if (lane < nk_0) {
+                s_cur = iv_start[k0_0 + lane];
+                n_cur = iv_len[k0_0 + lane];
             }
-            asc += n;
+        }
+        for (int j = 0; j < n_valid; ++j) {  // wave-uniform
+            const long long out0_j = readlane64(out0, j);
+            const long long len_j = readlane64(len, j);
+            const long long k0_j = readlane64(k0, j);
+            const int nk_j = __builtin_amdgcn_readlane(nk, j);
+            const bool rev_j = __builtin_amdgcn_readlane(rev, j) != 0;
+            // prefetch the next ORF's descriptors
+            long long s_nxt = 0;
+            int n_nxt = 0;
+            if (j + 1 < n_valid) {
+                const long long k0_n = readlane64(k0, j + 1);
+                const int nk_n = __builtin_amdgcn_readlane(nk, j + 1);
+                if (lane < nk_n) {
+                    s_nxt = iv_start[k0_n + lane];
+                    n_nxt = iv_len[k0_n + lane];
+                }
+            }
+            // ascending position of each interval's first nucleotide inside the ORF
+            const int incl = wave_add_scan_i32(n_cur);
+            const int asc_lane = incl - n_cur;
+            const int first = nk_j < kWave ? nk_j : kWave;
+            const int covered = __builtin_amdgcn_readlane(incl, kWave - 1);  // nt in the first 64 intervals
+            const int todo = (int)(covered < len_j ? covered : len_j);
+            int32_t *const dst = counts + out0_j;
+            for (int a0 = 0; a0 < todo; a0 += kGatherUnroll * kWave) {
+                int val[kGatherUnroll];
+#pragma unroll
+                for (int u = 0; u < kGatherUnroll; ++u) val[u] = 0;
+                for (int t = 0; t < first; ++t) {  // wave-uniform walk over the descriptors
+                    const int st = __builtin_amdgcn_readlane(asc_lane, t);
+                    const int nn = __builtin_amdgcn_readlane(n_cur, t);
+                    if (st + nn <= a0 || st >= a0 + kGatherUnroll * kWave) continue;
+                    const long long s0 = readlane64(s_cur, t);
+                    const int32_t *const src = coverage + (s0 - st);  // src[a] is the count at ORF position a
+                    if (s0 >= 0 && s0 + nn <= coverage_len) {          // whole interval inside the array
+#pragma unroll
+                        for (int u = 0; u < kGatherUnroll; ++u) {
+                            const int a = a0 + u * kWave + lane;
+                            if (a >= st && a < st + nn) val[u] = src[a];
+                        }
+                    } else {  // hangs off an end: those positions read as 0
+#pragma unroll
+                        for (int u = 0; u < kGatherUnroll; ++u) {
+                            const int a = a0 + u * kWave + lane;
+                            const long long g = s0 + (a - st);
+                            if (a >= st && a < st + nn && g >= 0 && g < coverage_len) val[u] = coverage[g];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kGatherUnroll; ++u) {  // every load above is in flight by now
+                    const int a = a0 + u * kWave + lane;
+                    if (a < todo) dst[rev_j ? (int)len_j - 1 - a : a] = val[u];
+                }
+            }
+            if (nk_j > kWave) {  // more than 64 exons: the rest straight from memory
+                long long asc = covered;
+                for (long long k = k0_j + kWave; k < k0_j + nk_j; ++k) {
+                    const int n = iv_len[k];
+                    gather_copy(coverage, coverage_len, iv_start[k], n, asc, out0_j, len_j, rev_j, counts, lane);
+                    asc += n;
+                }
+            }
+            s_cur = s_nxt;
+            n_cur = n_nxt;
         }
     }
 }

@@ -76,6 +76,7 @@ def test_device_gather_random_intervals():
     cov = rng.poisson(0.6, size=200000).astype(np.int32)
     n = 3000
     n_iv = rng.integers(1, 6, size=n)
+    n_iv[[5, 6, 7, 64, 2999]] = [150, 64, 65, 130, 70]  # around and beyond the 64 descriptors a wave holds
     orf_iv = np.concatenate([[0], np.cumsum(n_iv)]).astype(np.int64)
     iv_len = rng.integers(1, 400, size=int(orf_iv[-1])).astype(np.int32)
     iv_start = rng.integers(-50, cov.size - 100, size=int(orf_iv[-1])).astype(np.int64)  # some hang off both ends
