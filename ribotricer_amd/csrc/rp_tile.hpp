@@ -43,7 +43,10 @@
 namespace rp {
 
 constexpr int kTileBlock = 256;
-constexpr int kTile = 7936;    // positions per tile (31 KiB of int32): 3 lane-run passes of 64 x 15 triplets
+#ifndef RP_TILE
+#define RP_TILE 7936
+#endif
+constexpr int kTile = RP_TILE;  // positions per tile (31 KiB of int32): 3 lane-run passes of 64 x 15 triplets
 constexpr int kRun = 15;        // triplets per lane run; odd => lane stride 45 dwords, conflict free
 constexpr int kSegChunk = 64;   // segments set up per round (one per lane of wave 0)
 constexpr int kHalo = 8;        // dwords staged past the tile end (4 needed, 2 chunks loaded)
