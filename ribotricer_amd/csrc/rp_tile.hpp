@@ -329,7 +329,10 @@ __device__ __forceinline__ int wave_add_scan(int x)
 // dwords.  `lim` = number of leading codon starts that are real codons of this lane's ORF
 // and owned by this run.  Predicates are evaluated once per POSITION (is the count zero?
 // does it equal its successor?) and combined per codon on the scalar unit.
-constexpr int kRunBlock = 3;  // triplets per fully unrolled block of the lane run
+#ifndef RP_KRUNBLOCK
+#define RP_KRUNBLOCK 3
+#endif
+constexpr int kRunBlock = RP_KRUNBLOCK;  // triplets per fully unrolled block of the lane run
 static_assert(kRun % kRunBlock == 0, "kRun must be a multiple of kRunBlock");
 
 // min(x, hi) for x, hi >= 0 on the BIT PATTERNS: non-negative IEEE floats order like
