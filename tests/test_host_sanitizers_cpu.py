@@ -1,0 +1,27 @@
+"""The host-side C++ of the library (index parser, TSV renderer) under AddressSanitizer and
+UBSan: GPU sanitizers are not available on the pool, so the CPU build is where memory errors
+in this code would show."""
+
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_host_code_is_clean_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "san_host")
+    build = subprocess.run(
+        ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+         "-I", os.path.join(REPO, "ribotricer_amd", "csrc"), os.path.join(REPO, "tests", "tools", "san_host.cpp"), "-o", exe],
+        capture_output=True, text=True,
+    )
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe, os.path.join(GOLDEN, "g6_index.tsv")], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "parse rc=0 n=220" in run.stdout and "ok total=" in run.stdout
