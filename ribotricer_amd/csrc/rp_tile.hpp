@@ -245,10 +245,6 @@ struct LaneSums {
     unsigned mn;
 };
 
-// One step of the segmented inclusive scan inside each 16-lane row: lanes whose DPP
-// source carries the same segment key (keys are >= 1) fold the source's running value
-// into their own.  Masking with all-ones / zero bits instead of a select keeps it at
-// (fetch, and, add) per value.
 // One step of the segmented scan: x += m * x[lane - K] inside the 16-lane row for the six
 // float sums (lanes without a source read 0), as six v_fmac_f32 with a DPP source.  hipcc
 // keeps a separate v_mov_b32_dpp in front of every fma, hence the asm; it is ONE block so
