@@ -19,8 +19,7 @@
 //      record per (segment, row) -- deterministic, no float atomics;
 //   4. one thread per segment sums its row records in float64 and writes ONE segment
 //      record (six sums, packed N/M, read count, minimum codon coverage) to the
-//      workspace, struct-of-arrays, at index  orf  for the tile the ORF starts in and at
-//      head_base + tile  for a tile it continues in;
+//      workspace, struct-of-arrays, at index  orf + tile  (unique and increasing);
 //   5. k_orf_finish, one thread per ORF at full occupancy, adds the records of the tiles
 //      the ORF spans (one, for most), scores the frames, runs the state machine and the
 //      filters and stores the outputs; ORFs whose fp32 frame decision is too close to call
