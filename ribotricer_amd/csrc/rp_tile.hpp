@@ -62,10 +62,8 @@ struct TilePlan {
 };
 
 // One record per (ORF, tile) segment: the sums over the triplets of the ORF that the tile
-// owns.  Struct of arrays in two areas: the segment of the tile an ORF STARTS in lives at
-// index  orf  (so the finish kernel can fetch it without knowing the ORF's position), the
-// segment an ORF continues with in a later tile b -- a tile has at most one such "head"
-// segment -- at index  head_base + b.
+// owns.  Struct of arrays, indexed by  orf + tile : an ORF spanning tiles s..e owns the
+// ids orf+s .. orf+e, and the next ORF starts in a tile >= e, so ids never collide.
 struct SegRecords {
 #ifdef RP_REC_F64
     typedef double pq_t;
@@ -78,7 +76,6 @@ struct SegRecords {
     unsigned long long *count;  // [n_rec]     reads
     unsigned *min_codon;        // [n_rec]     RP_MIN_CODON_COV_EMPTY when no codon
     long long n_rec;
-    long long head_base;        // first index of the per-tile head records
 };
 constexpr size_t kRecordBytes = 6 * sizeof(SegRecords::pq_t) + 3 * 8 + 4;
 
@@ -91,7 +88,7 @@ inline long long max_tiles(long long total_nt, int tile) { return (total_nt + 3 
 
 inline long long max_records(long long n_orfs, long long total_nt, int tile)
 {
-    return ((n_orfs + 15) & ~15LL) + ((max_tiles(total_nt, tile) + 1 + 15) & ~15LL);  // 16-byte aligned arrays
+    return (n_orfs + max_tiles(total_nt, tile) + 1 + 15) & ~15LL;  // keeps every array 16-byte aligned
 }
 
 inline TilePlan make_tile_plan(long long n_orfs, long long total_nt, const void *counts, int tile)
@@ -124,7 +121,6 @@ inline TileWorkspace carve_workspace(void *base, long long n_orfs, long long tot
     p += tile_index_bytes(total_nt, tile);
     const size_t n = (size_t)max_records(n_orfs, total_nt, tile);
     ws.rec.n_rec = (long long)n;
-    ws.rec.head_base = (n_orfs + 15) & ~15LL;
     ws.rec.pq = reinterpret_cast<SegRecords::pq_t *>(p);
     p += 6 * n * sizeof(SegRecords::pq_t);
     ws.rec.nn = reinterpret_cast<unsigned long long *>(p);
@@ -622,8 +618,7 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
                 count += codon;
                 min_codon = min(min_codon, codon);
             }
-            const long long orf = c0 + seg;
-            store_record(ws.rec, orf < a0 ? ws.rec.head_base + b : orf, p, q, nn, mm, count, min_codon);
+            store_record(ws.rec, c0 + seg + b, p, q, nn, mm, count, min_codon);
         }
         if (c0 + kSegChunk < a1) __syncthreads();  // the next chunk clears the scratch
     }
@@ -651,28 +646,18 @@ __global__ __launch_bounds__(kTileBlock) void k_orf_finish(const int32_t *__rest
     unsigned split = 0;
     bool unsafe = false;
     if (orf < n_orfs) {
-        const SegRecords &r = ws.rec;
-        // the record of the tile the ORF starts in sits at index orf: these loads do not wait
-        // for the offsets
-        double p[3], q[3];
-        int n[3], m[3];
-        const unsigned long long nn0 = r.nn[orf], mm0 = r.mm[orf];
-#pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            p[f] = (double)r.pq[f * r.n_rec + orf];
-            q[f] = (double)r.pq[(3 + f) * r.n_rec + orf];
-            n[f] = (int)((nn0 >> (16 * f)) & 0xffffu);
-            m[f] = (int)((mm0 >> (16 * f)) & 0xffffu);
-        }
-        long long count = (long long)r.count[orf];
-        int min_codon = (int)r.min_codon[orf];
         beg = offsets[orf];
         len = (long long)offsets[orf + 1] - beg;
+        double p[3] = {0, 0, 0}, q[3] = {0, 0, 0};
+        int n[3] = {0, 0, 0}, m[3] = {0, 0, 0};
+        long long count = 0;
+        int min_codon = RP_MIN_CODON_COV_EMPTY;
         if (len > 0) {
             const long long b_first = (beg + plan.mis) / TILE;
             const long long b_last = (beg + len - 1 + plan.mis) / TILE;
-            for (long long b = b_first + 1; b <= b_last; ++b) {  // later tiles, in order: deterministic sums
-                const long long id = r.head_base + b;
+            const SegRecords &r = ws.rec;
+            for (long long b = b_first; b <= b_last; ++b) {  // tile order: deterministic sums
+                const long long id = orf + b;
                 const unsigned long long nn = r.nn[id], mm = r.mm[id];
 #pragma unroll
                 for (int f = 0; f < 3; ++f) {

@@ -227,9 +227,8 @@ __device__ __forceinline__ void pipe_run(const SegSet &S, const int *s_counts, R
 // Finish one chunk by ONE wave: one lane per slot sums its row records in float64 and
 // writes the segment record (k_orf_finish scores the ORFs afterwards).
 __device__ __forceinline__ void pipe_finish(const SegSet &S, RunRec *s_rec, SegInts *s_ints, long long b,
-                                            long long a0, const TileWorkspace &ws, int lane)
+                                            const TileWorkspace &ws, int lane)
 {
-    const bool is_head = S.first_orf + lane < a0;
     if (S.live[lane]) {
         const int vs = S.vlstart[lane];
         const int ve = S.vlstart[lane + 1];
@@ -253,8 +252,7 @@ __device__ __forceinline__ void pipe_finish(const SegSet &S, RunRec *s_rec, SegI
             count = acc.count;
             min_codon = acc.min_codon;
         }
-        // slot 0 of a tile's first chunk is the head (the ORF that started in an earlier tile)
-        store_record(ws.rec, is_head ? ws.rec.head_base + b : S.first_orf + lane, p, q, nn, mm, count, min_codon);
+        store_record(ws.rec, S.first_orf + lane + b, p, q, nn, mm, count, min_codon);
     }
     // the integer accumulators belong to the next chunk from here on
     s_ints[lane].nn = 0;
@@ -330,7 +328,7 @@ __global__ __launch_bounds__(kTileBlock, kPipeBlocksPerCu) void k_tile_score_pip
         //      offsets are plain global loads, which wait for the prefetch ahead of them.
         if (s_seg[cur].more) {
             long long c0 = s_seg[cur].first_orf + kSegChunk;
-            if (wave == 0) pipe_finish(s_seg[cur], s_rec, s_ints, b, a0, ws, lane);
+            if (wave == 0) pipe_finish(s_seg[cur], s_rec, s_ints, b, ws, lane);
             lds_barrier();
             for (;;) {
                 if (wave == 0) {
@@ -347,7 +345,7 @@ __global__ __launch_bounds__(kTileBlock, kPipeBlocksPerCu) void k_tile_score_pip
                 lds_barrier();
                 const int more = s_seg[cur].more;
                 if (!more) break;  // the last chunk is finished by the common code below
-                if (wave == 0) pipe_finish(s_seg[cur], s_rec, s_ints, b, a0, ws, lane);
+                if (wave == 0) pipe_finish(s_seg[cur], s_rec, s_ints, b, ws, lane);
                 c0 += kSegChunk;
                 lds_barrier();
             }
@@ -355,7 +353,7 @@ __global__ __launch_bounds__(kTileBlock, kPipeBlocksPerCu) void k_tile_score_pip
 
         // ---- finish(b) | segment table of tile b + G, bounds of tile b + 2G ---------------------
 #if !defined(RP_PIPE_EXP) || RP_PIPE_EXP >= 3
-        if (wave == 0) pipe_finish(s_seg[cur], s_rec, s_ints, b, a0, ws, lane);
+        if (wave == 0) pipe_finish(s_seg[cur], s_rec, s_ints, b, ws, lane);
 #else
         if (tid == 0 && s_counts[tid] == 0x7fffffff) ws.rec.nn[b] = 1;  // keep the tile live
 #endif
