@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--orfs", type=int, default=1_000_000, help="ORFs per GPU")
     ap.add_argument("--cfg", default="cfg2", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--algo", default="auto", choices=["auto", "wave", "tile", "pipe"])
