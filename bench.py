@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- ORFs phase-scored per second on N MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path (libribophase rp_phase_score_csr_dev: tile index
-+ scoring kernel + per-ORF finish) over one synthetic CSR batch that is already
-resident in HBM.  Workload at every N: BASELINE.json configs[1] per GPU -- 1 M
-synthetic ORFs, mean ~300 nt, Poisson P-site counts (ribotricer_amd/synth.py "cfg2").
-ORFs are independent, so ranks hold disjoint ORF-index slices and exchange nothing on
-the data path ("scaling": "weak"; the only collectives are the barrier and the
-max-over-ranks of the elapsed time).
+Workload (BASELINE.json): ONE seeded synthetic candidate-ORF set of 11 M ORFs with the
+GENCODE-like length law of ribotricer_amd/synth.py "cfg3" (3.97 G nt, 16 GB of int32
+P-site counts, resident in HBM):
+    N = 1   configs[2]  the whole set on one MI355X
+    N > 1   configs[3]  the SAME set cut into N nt-balanced ORF-index slices
+                        (ribotricer_amd/sharding.py), one slice per GPU, no collective on
+                        the data path -> "scaling": "strong".  After the timed steps rank 0
+                        scores the whole set on its own GPU and checks that the
+                        concatenation of the ranks' results equals it.
+A "step" is one pass of the hot path over the rank's slice: libribophase
+rp_phase_score_csr_plan_dev = scoring kernel (rp::k_tile_score) + per-ORF finish kernel.
+The tile plan (tile index + offsets validation, rp_plan_create_dev) depends on the index
+only and is built once before the steps, the way `detect-orfs` reuses one index for every
+sample; its time is reported as `plan_build_ms`.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (algorithmic bytes
 B = 4*sum(L) + 8*(n+1) + 24*n per launch over its HIP-event duration, vs the 8 TB/s
-HBM peak); `cpu_baseline` is the literal scipy restatement of the reference's
-phasescore (oracle/phasescore_literal.py, 1 core) on a bounded sample of the same batch.
+HBM peak); `cpu_baseline` is the literal scipy restatement of the reference's phasescore
+(oracle/phasescore_literal.py) on all host cores, on a bounded sample of the same set.
 """
 
 from __future__ import annotations
@@ -32,44 +39,55 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 CFG_NAMES = {"cfg2": "BASELINE configs[1]", "cfg3": "BASELINE configs[2]", "cfg5": "BASELINE configs[4]"}
+DEFAULT_ORFS = {"cfg2": 1_000_000, "cfg3": 11_000_000, "cfg5": 20_000_000}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--orfs", type=int, default=1_000_000, help="ORFs per GPU")
-    ap.add_argument("--cfg", default="cfg2", choices=["cfg2", "cfg3", "cfg5"])
-    ap.add_argument("--algo", default="auto", choices=["auto", "wave", "tile", "pipe"])
-    ap.add_argument("--cpu-sample", type=int, default=30000, help="ORFs for the CPU baseline (0 = skip)")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--cfg", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--orfs", type=int, default=0, help="ORFs of the whole set (default: the config's size)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: one set sharded over the GPUs (configs[3]); weak: --orfs ORFs on every GPU")
+    ap.add_argument("--algo", default="auto", choices=["auto", "wave", "tile"])
+    ap.add_argument("--no-plan", action="store_true", help="rebuild the tile index inside every step")
+    ap.add_argument("--cpu-sample", type=int, default=3000, help="ORFs per core for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="cores for the CPU baseline (default: all, at most 64)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the concat == whole check at N > 1")
     ap.add_argument("--seed", type=int, default=20260213)
     return ap.parse_args()
 
 
-def cpu_baseline(counts_host, offsets_host, n_sample):
+def cpu_baseline(pool, counts_host, offsets_host, per_core):
     """Reference-equivalent CPU path on a bounded sample: pure-Python triplet loop +
-    scipy.signal.coherence per frame (oracle/phasescore_literal.py), single core."""
+    scipy.signal.coherence per frame (oracle/phasescore_literal.py), all cores via a
+    process pool and one core alone; plus the best-effort C closed form (OpenMP)."""
     import numpy as np
 
     from oracle import c_oracle
     from oracle.phasescore_literal import phasescore_literal
 
-    n = min(n_sample, offsets_host.size - 1)
-    profiles = [counts_host[offsets_host[i] : offsets_host[i + 1]].tolist() for i in range(n)]
+    n_done, wall, n_workers = pool.run(counts_host, offsets_host, per_core)
+    base = {
+        "value": n_done / wall,
+        "unit": "ORFs/s",
+        "cores": n_workers,
+        "kind": "port",
+        "sample": f"first {n_done} ORFs of the set ({int(offsets_host[n_done])} nt), {n_done // n_workers} per process, "
+        f"oracle/phasescore_literal.py (python triplet loop + scipy.signal.coherence) on {n_workers} processes "
+        f"of a {os.cpu_count()}-core host, {wall:.1f} s wall",
+    }
+    n1 = min(per_core, offsets_host.size - 1)
+    profiles = [counts_host[offsets_host[i] : offsets_host[i + 1]].tolist() for i in range(n1)]
     t0 = time.perf_counter()
     for p in profiles:
         phasescore_literal(p)
     dt = time.perf_counter() - t0
-    out = {
-        "value": n / dt,
-        "unit": "ORFs/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"first {n} ORFs of the rank-0 batch ({int(offsets_host[n])} nt), "
-        f"oracle/phasescore_literal.py (python loop + scipy.signal.coherence), {dt:.1f} s",
-    }
+    one = {"value": n1 / dt, "unit": "ORFs/s", "cores": 1, "kind": "port",
+           "sample": f"first {n1} ORFs, same code on one core, {dt:.1f} s"}
     # best-effort CPU: C closed form on all host cores over a larger sample
     cores = os.cpu_count() or 1
     n_c = min(200_000, offsets_host.size - 1)
@@ -81,34 +99,43 @@ def cpu_baseline(counts_host, offsets_host, n_sample):
     dt_c = time.perf_counter() - t0
     extra = {"value": n_c / dt_c, "unit": "ORFs/s", "cores": cores, "kind": "port",
              "sample": f"first {n_c} ORFs, oracle/phase_oracle.c closed form + OpenMP, {dt_c:.2f} s"}
-    return out, extra
+    return base, one, extra
 
 
-def measured_traffic(args, n_orfs, algo):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/traffic.json: FETCH_SIZE and WRITE_SIZE in KiB, separate --pmc runs of this
-    very command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 wide
-    streaming reads).  None when no profile matches the workload being run."""
+def measured_traffic(cfg, n_orfs, algo, seed):
+    """HBM bytes per launch of the dominant kernel, REPLAYED from the committed rocprofv3
+    PMC passes of this very command (profiles/traffic.json: FETCH_SIZE and WRITE_SIZE in KiB
+    from separate --pmc runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
+    wide streaming reads).  Counters cannot be read from inside the run, so this is None
+    unless a profile of exactly this workload is on file."""
     path = os.path.join(REPO, "profiles", "traffic.json")
     if not os.path.exists(path):
-        return None
+        return None, None
     with open(path) as fh:
         for rec in json.load(fh):
-            if rec["cfg"] == args.cfg and rec["orfs_per_gpu"] == n_orfs and rec["algo"] == algo and rec["seed"] == args.seed:
-                return int((2 * rec["fetch_size_kib"] + rec["write_size_kib"]) * 1024)
-    return None
+            if rec["cfg"] == cfg and rec["orfs_per_gpu"] == n_orfs and rec["algo"] == algo and rec["seed"] == seed:
+                return int((2 * rec["fetch_size_kib"] + rec["write_size_kib"]) * 1024), rec.get("source", "profiles/traffic.json")
+    return None, None
 
 
 def main():
     args = parse_args()
-    import torch
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+
+    # CPU-baseline workers first: they must exist before this process initialises the GPU
+    pool = None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        from oracle.cpu_pool import CpuPool
+
+        pool = CpuPool(args.cpu_cores if args.cpu_cores > 0 else min(os.cpu_count() or 1, 64))
+
+    import numpy as np
+    import torch
+
     n_dev = torch.cuda.device_count()
     if n_dev == 0:
         sys.exit("bench.py needs a HIP device (ribotricer_amd has no CPU path)")
@@ -116,10 +143,12 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
 
-        # RCCL ("nccl") carries only the barrier and the max-over-ranks of the elapsed time;
+        # RCCL ("nccl") carries only the barrier, the max-over-ranks of the elapsed time and, after
+        # the timed region, the result hand-over for the concat == whole check;
         # RP_BENCH_BACKEND=gloo lets the same control flow be exercised with ranks sharing a GPU
         backend = os.environ.get("RP_BENCH_BACKEND", "nccl")
         if backend == "nccl":
@@ -129,18 +158,39 @@ def main():
 
     from ribotricer_amd import _lib
     from ribotricer_amd.engine import PhaseScoreEngine, make_filter
-    from ribotricer_amd.synth import synth_csr_device
+    from ribotricer_amd.sharding import slice_bounds
+    from ribotricer_amd.synth import offsets_from_lengths, orf_lengths, synth_csr_device
 
-    # each rank owns a disjoint slice of the ORF index: its own seeded batch
-    counts, offsets = synth_csr_device(args.orfs, seed=args.seed + 1000 * rank, cfg=args.cfg, device=dev)
+    n_set = args.orfs if args.orfs > 0 else DEFAULT_ORFS[args.cfg]
+    strong = args.scaling == "strong"
+    if strong:
+        # every rank derives the same index (lengths come from numpy: identical everywhere) and
+        # materialises only its own nt-balanced slice of the one seeded set
+        offsets_set = offsets_from_lengths(orf_lengths(n_set, args.seed, args.cfg))
+        bounds = slice_bounds(offsets_set, world)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        counts, offsets = synth_csr_device(n_set, seed=args.seed, cfg=args.cfg, device=dev, orf_range=(lo, hi))
+        n_job = n_set
+    else:
+        lo, hi = 0, n_set
+        counts, offsets = synth_csr_device(n_set, seed=args.seed + 1000 * rank, cfg=args.cfg, device=dev)
+        n_job = n_set * world
     n_orfs = offsets.numel() - 1
     total_nt = counts.numel()
     eng = PhaseScoreEngine(dev)
     thresholds = make_filter()
     algo = args.algo
+    resolved = ("tile" if total_nt >= (2 << 20) else "wave") if algo == "auto" else algo
+    plan = None
+    plan_ms = 0.0
+    if resolved == "tile" and not args.no_plan and n_orfs > 0:
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        plan = eng.plan_for(offsets, total_nt, (counts.data_ptr() // 4) % 4)  # validates the offsets, syncs
+        plan_ms = 1e3 * (time.perf_counter() - t0)
 
     def step():
-        return eng.score(counts, offsets, thresholds=thresholds, algo=algo, reuse_outputs=True)
+        return eng.score(counts, offsets, thresholds=thresholds, algo=algo, reuse_outputs=True, plan=plan)
 
     def barrier():
         if dist is not None:
@@ -162,47 +212,100 @@ def main():
     barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    dev_ms_per_step = ev0.elapsed_time(ev1) / args.steps
+    dev_ms_per_step = ev0.elapsed_time(ev1) / max(1, args.steps)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # per-kernel HIP-event timing (events recorded inside the library, on the same stream)
     timings: list = []
     for _ in range(max(5, min(args.steps, 20))):
-        eng.score(counts, offsets, thresholds=thresholds, algo=algo, reuse_outputs=True, timings=timings)
+        eng.score(counts, offsets, thresholds=thresholds, algo=algo, reuse_outputs=True, plan=plan, timings=timings)
     k_index = sum(t[0] for t in timings) / len(timings)
     k_main = sum(t[1] for t in timings) / len(timings)
     k_fin = sum(t[2] for t in timings) / len(timings)
+    per_rank = {"rank": rank, "orfs": n_orfs, "nt": total_nt, "kernel_ms": k_main, "finish_ms": k_fin,
+                "step_device_ms": dev_ms_per_step}
+    ranks = [per_rank]
+    if dist is not None:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, per_rank)
+
+    # ---- N > 1: the concatenation of the ranks' results must equal the one-GPU result ----------
+    verify = None
+    if dist is not None and strong and not args.no_verify:
+        keys = ("phase", "valid", "read_count", "min_codon_cov", "flags", "status")
+        mine = {k: getattr(out, k) for k in keys}
+        to_wire = (lambda x: x) if backend == "nccl" else (lambda x: x.cpu())
+        if rank == 0:
+            counts_all, offsets_all = synth_csr_device(n_set, seed=args.seed, cfg=args.cfg, device=dev)
+            whole = eng.score(counts_all, offsets_all, thresholds=thresholds, algo=algo, plan=None)
+            torch.cuda.synchronize(dev)
+            verify = {"ok": True, "max_abs_dphase": 0.0, "orfs_checked": 0,
+                      "read_count_checksum": int(whole.read_count.sum())}
+            for r in range(world):
+                a, b = int(bounds[r]), int(bounds[r + 1])
+                for k in keys:
+                    ref = getattr(whole, k)[a:b]
+                    if r == 0:
+                        got = mine[k]
+                    else:
+                        got = torch.empty(b - a, dtype=ref.dtype, device=dev if backend == "nccl" else "cpu")
+                        dist.recv(got, src=r)
+                        got = got.to(dev)
+                    if k == "phase":
+                        d = float((got - ref).abs().max()) if b > a else 0.0
+                        verify["max_abs_dphase"] = max(verify["max_abs_dphase"], d)
+                        verify["ok"] &= d <= 1e-6
+                    elif k == "flags":  # the split / recheck bits depend on where the tiles fall
+                        verify["ok"] &= bool(torch.equal(got & 1, ref & 1))
+                    else:
+                        verify["ok"] &= bool(torch.equal(got, ref))
+                verify["orfs_checked"] += b - a
+            del counts_all, offsets_all, whole
+        else:
+            for k in keys:
+                dist.send(to_wire(mine[k].contiguous()), dst=0)
+        barrier()
+        if rank == 0 and not verify["ok"]:
+            print(json.dumps({"error": "sharded results differ from the one-GPU result", "verify": verify}), flush=True)
+            sys.exit(2)
 
     if rank == 0:
         algo_bytes = 4 * total_nt + 8 * (n_orfs + 1) + 24 * n_orfs
         achieved = algo_bytes / (k_main * 1e-3) / 1e9
-        # RP_ALGO_AUTO -> RP_ALGO_TILE from 2 Mi nucleotides up (ribophase.hip), RP_ALGO_WAVE below
-        resolved = ("tile" if total_nt >= (2 << 20) else "wave") if algo == "auto" else algo
-        traffic = measured_traffic(args, n_orfs, resolved)
+        traffic, traffic_src = (measured_traffic(args.cfg, n_orfs, resolved, args.seed) if world == 1 else (None, None))
         flags = out.flags
+        nt_set = int(offsets_set[-1]) if strong else total_nt * world
         result = {
             "metric": "ORFs phase-scored/sec (whole node)",
-            "value": world * n_orfs * args.steps / elapsed,
+            "value": n_job * args.steps / elapsed,
             "unit": "ORFs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * elapsed / max(1, args.steps),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32 codon math, f64 reduction/score (int32 counts)",
             "data": "synthetic",
             "config": {
-                "workload": f"{CFG_NAMES[args.cfg]}: synthetic {n_orfs} ORFs/GPU, mean {total_nt / n_orfs:.0f} nt, "
-                f"Poisson P-site counts ({args.cfg}), resident in HBM",
-                "orfs_per_gpu": n_orfs,
-                "nt_per_gpu": total_nt,
+                "workload": (
+                    f"{CFG_NAMES[args.cfg]}{' sharded over ' + str(world) + ' GPUs (configs[3])' if world > 1 and strong and args.cfg == 'cfg3' else ''}: "
+                    f"one synthetic set of {n_job} ORFs, mean {nt_set / max(1, n_job):.0f} nt, Poisson P-site counts "
+                    f"({args.cfg} length law), resident in HBM"
+                ),
+                "orfs_total": n_job,
+                "nt_total": nt_set,
+                "orfs_rank0": n_orfs,
+                "nt_rank0": total_nt,
                 "algo": algo,
-                "sharding": "independent ORF-index slices, no collective on the data path",
+                "plan": "tile plan built once per index, outside the steps" if plan is not None else "tile index rebuilt in every step",
+                "plan_build_ms": plan_ms,
+                "sharding": "nt-balanced contiguous ORF-index slices of one set, host-side concat, no collective on the data path"
+                if strong else "independent per-GPU sets (weak scaling)",
             },
             "roofline": {
                 "bound": "hbm",
@@ -211,25 +314,33 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": "rp::k_tile_score" if resolved == "tile" else "rp::k_wave_score",
                 "kernel_ms": k_main,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "step_device_ms": dev_ms_per_step,
                 "aux_kernels_ms": {"tile_index": k_index, "orf_finish": k_fin},
                 "step_achieved": algo_bytes / (dev_ms_per_step * 1e-3) / 1e9,
+                "step_frac": algo_bytes / (dev_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
+            "per_rank": ranks,
             "quality": {
-                "tie_flag_rate": float((flags & _lib.FLAG_TIE).ne(0).double().mean()),
-                "recheck64_rate": float((flags & _lib.FLAG_RECHECK64).ne(0).double().mean()),
+                "tie_flag_rate": float((flags & _lib.FLAG_TIE).ne(0).double().mean()) if n_orfs else 0.0,
+                "recheck64_rate": float((flags & _lib.FLAG_RECHECK64).ne(0).double().mean()) if n_orfs else 0.0,
                 "translating": int(out.status.sum()),
             },
         }
-        if world == 1 and args.cpu_sample > 0:
-            n_s = min(max(args.cpu_sample, 200_000), n_orfs)
+        if verify is not None:
+            result["verify"] = verify
+        if pool is not None:
+            per_core = args.cpu_sample
+            n_s = min(max(per_core * pool.n, 200_000), n_orfs)
             o_host = offsets[: n_s + 1].cpu().numpy()
             c_host = counts[: int(o_host[-1])].cpu().numpy()
-            base, extra = cpu_baseline(c_host, o_host, args.cpu_sample)
+            base, one, extra = cpu_baseline(pool, c_host, o_host, per_core)
+            pool.close()
             result["cpu_baseline"] = base
+            result["cpu_baseline_1core"] = one
             result["cpu_closed_form_c"] = extra
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -20,6 +20,8 @@
  *     the 5'->3' profile of ORF i (the list `cov` of detect_orfs.py:277);
  *     offsets has n_orfs+1 monotone entries with offsets[0] == 0.
  *   - counts must satisfy 0 <= counts[k] <= RP_MAX_COUNT.
+ *   - an entry point taking `device` makes it current for the duration of the call and
+ *     restores the calling thread's previous HIP device before it returns.
  *   - there is no CPU fallback: without a usable HIP device every compute entry
  *     point fails with RP_ERR_DEVICE / RP_ERR_HIP.
  */
@@ -33,7 +35,7 @@
 extern "C" {
 #endif
 
-#define RP_VERSION_STRING "0.1.0"
+#define RP_VERSION_STRING "0.2.0"
 
 /* largest admissible P-site count per nucleotide (exact in fp32; codon sums stay inside
  * int32 and a lane's 45-position partial read count inside uint32) */
@@ -71,10 +73,8 @@ typedef enum rp_status {
 typedef enum rp_algo {
     RP_ALGO_AUTO = 0, /* RP_ALGO_TILE, or RP_ALGO_WAVE for batches under 2 Mi nucleotides */
     RP_ALGO_WAVE = 1, /* one wavefront per ORF, streaming straight from HBM */
-    RP_ALGO_TILE = 2, /* LDS-staged flat tiles, ragged lane packing -> one record per (ORF, tile)
+    RP_ALGO_TILE = 2  /* LDS-staged flat tiles, ragged lane packing -> one record per (ORF, tile)
                          segment in the workspace -> one thread per ORF scores and filters */
-    RP_ALGO_TILE_PIPE = 3 /* same records, persistent workgroups that keep the next tile in flight
-                             in registers while they score the current one (experimental) */
 } rp_algo;
 
 /*
@@ -139,6 +139,36 @@ int rp_phase_score_csr_dev(int device, const int32_t *d_counts, const int64_t *d
                            int64_t *d_read_count, int32_t *d_min_codon_cov, uint8_t *d_flags,
                            uint8_t *d_status, const rp_filter_params *filter, void *d_workspace,
                            size_t workspace_bytes, int algo, void *hip_stream);
+
+/*
+ * Tile plans.  export_orf_coverages scores ONE candidate-ORF index against many samples
+ * (detect_orfs.py:510-520 is called once per BAM with the same ribotricer_index), and
+ * everything the tile path derives from the offsets alone -- the tile index, and the check
+ * that the offsets are a valid CSR index -- is the same for all of them.  A plan holds that
+ * part: build it once per index, then call rp_phase_score_csr_plan_dev per sample.
+ *
+ *   rp_plan_bytes        device bytes the plan needs (caller-owned memory, 16-byte aligned)
+ *   rp_plan_create_dev   validates d_offsets (RP_ERR_OFFSETS: offsets[0] != 0, a decreasing
+ *                        step, offsets[n] != total_nt), builds the tile index in d_plan_mem,
+ *                        SYNCHRONISES the stream and returns a small host handle.
+ *                        counts_phase = (address of the counts array / 4) % 4 that the plan
+ *                        will be used with (tiles live on the 16-byte address grid).
+ *   rp_plan_free         frees the host handle only; d_plan_mem stays the caller's.
+ * rp_phase_score_csr_plan_dev = rp_phase_score_csr_dev(RP_ALGO_TILE) minus the index pass;
+ * RP_ERR_ARG when d_counts has a different 16-byte phase than the plan was built for.
+ */
+typedef struct rp_plan rp_plan;
+
+int rp_plan_bytes(int64_t n_orfs, int64_t total_nt, size_t *bytes);
+int rp_plan_create_dev(int device, const int64_t *d_offsets, int64_t n_orfs, int64_t total_nt,
+                       int counts_phase, void *d_plan_mem, size_t plan_bytes, void *hip_stream,
+                       rp_plan **out);
+void rp_plan_free(rp_plan *plan);
+int rp_phase_score_csr_plan_dev(const rp_plan *plan, const int32_t *d_counts, const int64_t *d_offsets,
+                                double *d_phase, int32_t *d_valid, int64_t *d_read_count,
+                                int32_t *d_min_codon_cov, uint8_t *d_flags, uint8_t *d_status,
+                                const rp_filter_params *filter, void *d_workspace,
+                                size_t workspace_bytes, void *hip_stream);
 
 /*
  * Per-frame diagnostics in float64: score_f (NaN when M_f == 0, 0 when N_f == 0),
@@ -263,9 +293,10 @@ int rp_format_double_repr(double value, char *buf);
 size_t rp_format_int_list(const int32_t *values, int64_t n, char *out);
 
 /*
- * Same as rp_phase_score_csr_dev but brackets each internal launch with HIP events
- * on `hip_stream`, synchronises, and reports milliseconds: ms[0] tile-index pass,
- * ms[1] main scoring kernel, ms[2] per-ORF finish kernel, ms[3] whole call.
+ * Same as rp_phase_score_csr_dev (plan == NULL) or rp_phase_score_csr_plan_dev (plan given)
+ * but brackets each internal launch with HIP events on `hip_stream`, synchronises, and
+ * reports milliseconds: ms[0] tile-index pass (0 with a plan), ms[1] main scoring kernel,
+ * ms[2] per-ORF finish kernel, ms[3] whole call.
  * For bench.py's roofline figure; not for production use (it blocks the host).
  */
 int rp_phase_score_csr_dev_timed(int device, const int32_t *d_counts, const int64_t *d_offsets,
@@ -273,7 +304,8 @@ int rp_phase_score_csr_dev_timed(int device, const int32_t *d_counts, const int6
                                  int32_t *d_valid, int64_t *d_read_count,
                                  int32_t *d_min_codon_cov, uint8_t *d_flags, uint8_t *d_status,
                                  const rp_filter_params *filter, void *d_workspace,
-                                 size_t workspace_bytes, int algo, void *hip_stream, float ms[4]);
+                                 size_t workspace_bytes, int algo, const rp_plan *plan,
+                                 void *hip_stream, float ms[4]);
 
 #ifdef __cplusplus
 }

@@ -10,9 +10,6 @@ phasescore_literal   scalar restatement of ribotricer/statistics.py:48-115 that
                      issues the identical ``scipy.signal.coherence`` call
                      (parity pinned against the reference itself through the
                      golden fixtures in tests/golden/, see make_golden.py).
-closed_form          numpy float64 closed form of the same quantity
-                      + the filter block of
-                     ribotricer/detect_orfs.py:278-299.
 phase_oracle.c       plain-C restatement of the closed form over CSR arrays,
                      built by oracle/Makefile into oracle/_build/.
 c_oracle             ctypes loader for the C restatement.

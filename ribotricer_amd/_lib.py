@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libribophase.so")
 
 RP_OK = 0
-RP_ALGO_AUTO, RP_ALGO_WAVE, RP_ALGO_TILE, RP_ALGO_TILE_PIPE = 0, 1, 2, 3
-ALGOS = {"auto": RP_ALGO_AUTO, "wave": RP_ALGO_WAVE, "tile": RP_ALGO_TILE, "pipe": RP_ALGO_TILE_PIPE}
+RP_ALGO_AUTO, RP_ALGO_WAVE, RP_ALGO_TILE = 0, 1, 2
+ALGOS = {"auto": RP_ALGO_AUTO, "wave": RP_ALGO_WAVE, "tile": RP_ALGO_TILE}
 
 FLAG_TIE = 0x01
 FLAG_RECHECK64 = 0x02
@@ -59,7 +59,11 @@ SYMBOLS = {
     "rp_filter_defaults": (_int, [ctypes.POINTER(FilterParams)]),
     "rp_workspace_bytes": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_size_t)]),
     "rp_phase_score_csr_dev": (_int, _SCORE_ARGS),
-    "rp_phase_score_csr_dev_timed": (_int, _SCORE_ARGS + [ctypes.POINTER(ctypes.c_float * 4)]),
+    "rp_phase_score_csr_dev_timed": (_int, _SCORE_ARGS[:-1] + [_vp, _vp, ctypes.POINTER(ctypes.c_float * 4)]),
+    "rp_plan_bytes": (_int, [_i64, _i64, ctypes.POINTER(ctypes.c_size_t)]),
+    "rp_plan_create_dev": (_int, [_int, _vp, _i64, _i64, _int, _vp, ctypes.c_size_t, _vp, ctypes.POINTER(_vp)]),
+    "rp_plan_free": (None, [_vp]),
+    "rp_phase_score_csr_plan_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(FilterParams), _vp, ctypes.c_size_t, _vp]),
     "rp_phase_score_frames_dev": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "rp_phase_score_f64_csr_dev": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "rp_gather_profiles_dev": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
@@ -116,6 +120,12 @@ def filter_defaults() -> FilterParams:
     fp = FilterParams()
     check(load().rp_filter_defaults(ctypes.byref(fp)))
     return fp
+
+
+def plan_bytes(n_orfs: int, total_nt: int) -> int:
+    out = ctypes.c_size_t(0)
+    check(load().rp_plan_bytes(n_orfs, total_nt, ctypes.byref(out)))
+    return out.value
 
 
 def workspace_bytes(n_orfs: int, total_nt: int, algo: int) -> int:

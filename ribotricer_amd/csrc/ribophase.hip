@@ -13,7 +13,6 @@
 #include "../../include/ribophase.h"
 #include "rp_device.hpp"
 #include "rp_tile.hpp"
-#include "rp_tile_pipe.hpp"
 #include <new>
 #include "rp_format.hpp"
 #include "rp_index.hpp"
@@ -41,7 +40,7 @@ int fail(int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                           \
     } while (0)
 
-int select_device(int device)
+int check_device(int device)
 {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -51,9 +50,45 @@ int select_device(int device)
                     e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
     }
     if (device < 0 || device >= n) return fail(RP_ERR_DEVICE, "device %d out of range [0,%d)", device, n);
-    RP_HIP(hipSetDevice(device));
     return RP_OK;
 }
+
+// Makes `device` current for the lifetime of the object and restores the calling thread's
+// previous device afterwards: an entry point must not leave the caller (torch, another
+// engine thread) on a different GPU than it came in with.
+struct DeviceGuard {
+    int rc = RP_OK;
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int device)
+    {
+        rc = check_device(device);
+        if (rc != RP_OK) return;
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) {
+            rc = fail(RP_ERR_HIP, "hipGetDevice failed: %s", hipGetErrorString(e));
+            return;
+        }
+        if (prev != device) {
+            e = hipSetDevice(device);
+            if (e != hipSuccess) {
+                rc = fail(RP_ERR_HIP, "hipSetDevice(%d) failed: %s", device, hipGetErrorString(e));
+                return;
+            }
+            switched = true;
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+#define RP_ON_DEVICE(device)       \
+    DeviceGuard guard_((device));  \
+    if (guard_.rc != RP_OK) return guard_.rc
 
 int grid_for_waves(long long n_items, int waves_per_block)
 {
@@ -84,20 +119,50 @@ struct Timing {
     bool on = false;
 };
 
+bool known_algo(int algo) { return algo == RP_ALGO_AUTO || algo == RP_ALGO_WAVE || algo == RP_ALGO_TILE; }
+
+int launch_tile_index(const int64_t *d_offsets, int64_t n_orfs, const rp::TilePlan &plan,
+                      long long *d_tile_first, int *d_err, hipStream_t stream)
+{
+    const long long threads = n_orfs + 1;
+    const int block = 256;
+    const int grid = (int)((threads + block - 1) / block);
+    hipLaunchKernelGGL(rp::k_tile_index<rp::kTile>, dim3(grid), dim3(block), 0, stream, d_offsets,
+                       (long long)n_orfs, plan, d_tile_first, d_err);
+    RP_HIP(hipGetLastError());
+    return RP_OK;
+}
+
+}  // namespace
+
+// A tile plan: everything the tile path derives from the offsets alone (today: the tile
+// index).  `detect-orfs` scores ONE candidate index against many samples, so the plan is
+// built -- and the offsets validated -- once per index instead of once per call.
+struct rp_plan {
+    int device;
+    long long n_orfs, total_nt;
+    int mis;                // (counts address / 4) % 4 the plan was built for
+    long long *tile_first;  // device, caller-owned (inside d_plan_mem)
+    int *err;               // device, first word of d_plan_mem
+};
+
+namespace {
+
+constexpr size_t kPlanHeader = 128;
+
 int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, int64_t n_orfs,
                int64_t total_nt, double *d_phase, int32_t *d_valid, int64_t *d_read_count,
                int32_t *d_min_codon_cov, uint8_t *d_flags, uint8_t *d_status,
                const rp_filter_params *filter, void *d_workspace, size_t workspace_bytes, int algo,
-               void *hip_stream, Timing *tm)
+               const rp_plan *plan_h, void *hip_stream, Timing *tm)
 {
     if (n_orfs < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "n_orfs=%lld total_nt=%lld must be >= 0", (long long)n_orfs, (long long)total_nt);
-    if (algo != RP_ALGO_AUTO && algo != RP_ALGO_WAVE && algo != RP_ALGO_TILE && algo != RP_ALGO_TILE_PIPE)
-        return fail(RP_ERR_ARG, "unknown algo %d", algo);
+    if (!known_algo(algo)) return fail(RP_ERR_ARG, "unknown algo %d", algo);
     if (n_orfs > 0 && (!d_offsets || !d_phase || !d_valid || !d_read_count || !d_min_codon_cov || !d_flags))
         return fail(RP_ERR_NULL, "offsets and the five output arrays must be non-null");
     if (total_nt > 0 && !d_counts) return fail(RP_ERR_NULL, "d_counts is null but total_nt > 0");
-    int rc = select_device(device);
-    if (rc != RP_OK) return rc;
+    RP_ON_DEVICE(device);
+    int rc = RP_OK;
     hipStream_t stream = (hipStream_t)hip_stream;
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[0], stream));
     if (n_orfs == 0) {
@@ -107,10 +172,9 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     }
     const rp::OrfOutputs out{d_phase, d_valid, d_read_count, d_min_codon_cov, d_flags, d_status};
     const rp::FilterParams fp = make_filter(filter, d_status);
-    // AUTO: the flat-tile path, except for batches so small that its three launches cost more
-    // than the single wave-per-ORF launch (measured crossover ~3 M nt; scripts/bench_small.py)
-    if (algo == RP_ALGO_AUTO) algo = total_nt < kAutoWaveNt ? RP_ALGO_WAVE : RP_ALGO_TILE;
-    if (algo == RP_ALGO_TILE_PIPE && total_nt == 0) algo = RP_ALGO_TILE;  // nothing to prefetch
+    // AUTO: the flat-tile path, except for batches so small that its launches cost more than
+    // the single wave-per-ORF launch (measured crossover ~3 M nt; scripts/bench_small.py)
+    if (algo == RP_ALGO_AUTO) algo = (plan_h == nullptr && total_nt < kAutoWaveNt) ? RP_ALGO_WAVE : RP_ALGO_TILE;
 
     if (algo == RP_ALGO_WAVE) {
         if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[1], stream));
@@ -132,56 +196,33 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
         return fail(RP_ERR_WORKSPACE, "workspace of %zu bytes required, got %zu", need, workspace_bytes);
     if ((reinterpret_cast<uintptr_t>(d_workspace) & 15u) != 0)
         return fail(RP_ERR_WORKSPACE, "workspace must be 16-byte aligned");
-    // RP_ALGO_TILE / RP_ALGO_TILE_PIPE: tile index -> scoring pass (segment records) -> per-ORF finish
-    const bool pipe = algo == RP_ALGO_TILE_PIPE;
-    const int tile = pipe ? rp::kPipeTile : rp::kTile;
-    const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt, d_counts, tile);
-    const rp::TileWorkspace ws = rp::carve_workspace(d_workspace, n_orfs, total_nt, tile);
-
-    // 1. tile index: first ORF starting at or after each tile boundary
-    {
-        const long long threads = n_orfs + 1;
-        const int block = 256;
-        const int grid = (int)((threads + block - 1) / block);
-        if (pipe)
-            hipLaunchKernelGGL(rp::k_tile_index<rp::kPipeTile>, dim3(grid), dim3(block), 0, stream, d_offsets,
-                               (long long)n_orfs, plan, ws);
-        else
-            hipLaunchKernelGGL(rp::k_tile_index<rp::kTile>, dim3(grid), dim3(block), 0, stream, d_offsets,
-                               (long long)n_orfs, plan, ws);
-        RP_HIP(hipGetLastError());
+    // RP_ALGO_TILE: tile index (or the caller's plan) -> scoring pass (segment records) -> per-ORF finish
+    const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt, d_counts, rp::kTile);
+    rp::TileWorkspace ws = rp::carve_workspace(d_workspace, n_orfs, total_nt, rp::kTile);
+    if (plan_h != nullptr) {
+        if (plan_h->device != device || plan_h->n_orfs != n_orfs || plan_h->total_nt != total_nt)
+            return fail(RP_ERR_ARG, "plan was built for device %d, %lld ORFs, %lld nt; called with device %d, %lld ORFs, %lld nt",
+                        plan_h->device, plan_h->n_orfs, plan_h->total_nt, device, (long long)n_orfs, (long long)total_nt);
+        if (plan_h->mis != plan.mis)
+            return fail(RP_ERR_ARG, "plan was built for counts at 16-byte phase %d, d_counts has phase %d", plan_h->mis, plan.mis);
+        ws.tile_first = plan_h->tile_first;
+    } else {
+        // 1. tile index: first ORF starting at or after each tile boundary
+        rc = launch_tile_index(d_offsets, n_orfs, plan, ws.tile_first, nullptr, stream);
+        if (rc != RP_OK) return rc;
     }
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[1], stream));
     // 2. scoring pass over flat tiles: one record per (ORF, tile) segment
-    if (pipe) {
-        // persistent workgroups, next tile prefetched in registers
-        int n_cu = 256;
-        {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-        }
-        int per_cu = rp::kPipeBlocksPerCu;
-        if (const char *e = getenv("RP_PIPE_BLOCKS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : rp::kPipeBlocksPerCu;
-        long long grid_pipe = (long long)n_cu * per_cu;
-        if (grid_pipe > plan.n_tiles) grid_pipe = plan.n_tiles;
-        hipLaunchKernelGGL(rp::k_tile_score_pipe, dim3((unsigned)grid_pipe), dim3(rp::kTileBlock), 0, stream, d_counts,
-                           d_offsets, (long long)n_orfs, plan, ws);
-    } else {
-        hipLaunchKernelGGL(rp::k_tile_score, dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
-                           d_counts, d_offsets, (long long)n_orfs, plan, ws);
-    }
+    hipLaunchKernelGGL(rp::k_tile_score, dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
+                       d_counts, d_offsets, (long long)n_orfs, plan, ws);
     RP_HIP(hipGetLastError());
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));
     // 3. one thread per ORF: add its records, score, filter, store
     {
         const int block = rp::kTileBlock;
         const int grid = (int)((n_orfs + block - 1) / block);
-        if (pipe)
-            hipLaunchKernelGGL(rp::k_orf_finish<rp::kPipeTile>, dim3(grid), dim3(block), 0, stream, d_counts,
-                               d_offsets, (long long)n_orfs, plan, ws, out, fp);
-        else
-            hipLaunchKernelGGL(rp::k_orf_finish<rp::kTile>, dim3(grid), dim3(block), 0, stream, d_counts,
-                               d_offsets, (long long)n_orfs, plan, ws, out, fp);
+        hipLaunchKernelGGL(rp::k_orf_finish<rp::kTile>, dim3(grid), dim3(block), 0, stream, d_counts,
+                           d_offsets, (long long)n_orfs, plan, ws, out, fp);
         RP_HIP(hipGetLastError());
     }
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[3], stream));
@@ -245,19 +286,63 @@ int rp_workspace_bytes(int64_t n_orfs, int64_t total_nt, int algo, size_t *bytes
 {
     if (!bytes) return fail(RP_ERR_NULL, "bytes is null");
     if (n_orfs < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "negative size");
-    if (algo != RP_ALGO_AUTO && algo != RP_ALGO_WAVE && algo != RP_ALGO_TILE && algo != RP_ALGO_TILE_PIPE)
-        return fail(RP_ERR_ARG, "unknown algo %d", algo);
-    if (algo == RP_ALGO_WAVE) {
-        *bytes = 0;
-        return RP_OK;
-    }
-    {   // AUTO may resolve to either tile family: size for the larger
-        const size_t a = rp::workspace_bytes(n_orfs, total_nt, rp::kTile),
-                     p = rp::workspace_bytes(n_orfs, total_nt, rp::kPipeTile);
-        *bytes = a > p ? a : p;
-    }
+    if (!known_algo(algo)) return fail(RP_ERR_ARG, "unknown algo %d", algo);
+    *bytes = algo == RP_ALGO_WAVE ? 0 : rp::workspace_bytes(n_orfs, total_nt, rp::kTile);
     return RP_OK;
 }
+
+int rp_plan_bytes(int64_t n_orfs, int64_t total_nt, size_t *bytes)
+{
+    if (!bytes) return fail(RP_ERR_NULL, "bytes is null");
+    if (n_orfs < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "negative size");
+    *bytes = kPlanHeader + rp::tile_index_bytes(total_nt, rp::kTile);
+    return RP_OK;
+}
+
+int rp_plan_create_dev(int device, const int64_t *d_offsets, int64_t n_orfs, int64_t total_nt,
+                       int counts_phase, void *d_plan_mem, size_t plan_bytes, void *hip_stream,
+                       rp_plan **out)
+{
+    if (!out) return fail(RP_ERR_NULL, "out is null");
+    *out = nullptr;
+    if (n_orfs < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "negative size");
+    if (!d_offsets || !d_plan_mem) return fail(RP_ERR_NULL, "d_offsets / d_plan_mem is null");
+    if (counts_phase < 0 || counts_phase > 3) return fail(RP_ERR_ARG, "counts_phase must be (address / 4) %% 4");
+    size_t need = 0;
+    int rc = rp_plan_bytes(n_orfs, total_nt, &need);
+    if (rc != RP_OK) return rc;
+    if (plan_bytes < need) return fail(RP_ERR_WORKSPACE, "plan memory of %zu bytes required, got %zu", need, plan_bytes);
+    if ((reinterpret_cast<uintptr_t>(d_plan_mem) & 15u) != 0) return fail(RP_ERR_WORKSPACE, "plan memory must be 16-byte aligned");
+    RP_ON_DEVICE(device);
+    hipStream_t stream = (hipStream_t)hip_stream;
+    rp::TilePlan plan;
+    plan.n_orfs = n_orfs;
+    plan.total_nt = total_nt;
+    plan.mis = counts_phase;
+    plan.n_tiles = (total_nt + plan.mis + rp::kTile - 1) / rp::kTile;
+    if (plan.n_tiles < 1) plan.n_tiles = 1;
+    int *d_err = reinterpret_cast<int *>(d_plan_mem);
+    long long *d_tile_first = reinterpret_cast<long long *>(reinterpret_cast<char *>(d_plan_mem) + kPlanHeader);
+    RP_HIP(hipMemsetAsync(d_err, 0, kPlanHeader, stream));
+    rc = launch_tile_index(d_offsets, n_orfs, plan, d_tile_first, d_err, stream);
+    if (rc != RP_OK) return rc;
+    int h_err = 0;
+    RP_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    RP_HIP(hipStreamSynchronize(stream));
+    if (h_err != 0) return fail(RP_ERR_OFFSETS, "offsets must start at 0, be monotone and end at total_nt");
+    rp_plan *h = new (std::nothrow) rp_plan;
+    if (!h) return fail(RP_ERR_SIZE, "out of memory");
+    h->device = device;
+    h->n_orfs = n_orfs;
+    h->total_nt = total_nt;
+    h->mis = counts_phase;
+    h->tile_first = d_tile_first;
+    h->err = d_err;
+    *out = h;
+    return RP_OK;
+}
+
+void rp_plan_free(rp_plan *plan) { delete plan; }
 
 int rp_phase_score_csr_dev(int device, const int32_t *d_counts, const int64_t *d_offsets,
                            int64_t n_orfs, int64_t total_nt, double *d_phase, int32_t *d_valid,
@@ -267,7 +352,19 @@ int rp_phase_score_csr_dev(int device, const int32_t *d_counts, const int64_t *d
 {
     return score_impl(device, d_counts, d_offsets, n_orfs, total_nt, d_phase, d_valid, d_read_count,
                       d_min_codon_cov, d_flags, d_status, filter, d_workspace, workspace_bytes, algo,
-                      hip_stream, nullptr);
+                      nullptr, hip_stream, nullptr);
+}
+
+int rp_phase_score_csr_plan_dev(const rp_plan *plan, const int32_t *d_counts, const int64_t *d_offsets,
+                                double *d_phase, int32_t *d_valid, int64_t *d_read_count,
+                                int32_t *d_min_codon_cov, uint8_t *d_flags, uint8_t *d_status,
+                                const rp_filter_params *filter, void *d_workspace,
+                                size_t workspace_bytes, void *hip_stream)
+{
+    if (!plan) return fail(RP_ERR_NULL, "plan is null");
+    return score_impl(plan->device, d_counts, d_offsets, plan->n_orfs, plan->total_nt, d_phase, d_valid,
+                      d_read_count, d_min_codon_cov, d_flags, d_status, filter, d_workspace,
+                      workspace_bytes, RP_ALGO_TILE, plan, hip_stream, nullptr);
 }
 
 int rp_phase_score_csr_dev_timed(int device, const int32_t *d_counts, const int64_t *d_offsets,
@@ -275,17 +372,17 @@ int rp_phase_score_csr_dev_timed(int device, const int32_t *d_counts, const int6
                                  int32_t *d_valid, int64_t *d_read_count,
                                  int32_t *d_min_codon_cov, uint8_t *d_flags, uint8_t *d_status,
                                  const rp_filter_params *filter, void *d_workspace,
-                                 size_t workspace_bytes, int algo, void *hip_stream, float ms[4])
+                                 size_t workspace_bytes, int algo, const rp_plan *plan,
+                                 void *hip_stream, float ms[4])
 {
     if (!ms) return fail(RP_ERR_NULL, "ms is null");
-    int rc = select_device(device);
-    if (rc != RP_OK) return rc;
+    RP_ON_DEVICE(device);
     Timing tm;
     tm.on = true;
     for (int k = 0; k < 4; ++k) RP_HIP(hipEventCreate(&tm.ev[k]));
-    rc = score_impl(device, d_counts, d_offsets, n_orfs, total_nt, d_phase, d_valid, d_read_count,
-                    d_min_codon_cov, d_flags, d_status, filter, d_workspace, workspace_bytes, algo,
-                    hip_stream, &tm);
+    int rc = score_impl(device, d_counts, d_offsets, n_orfs, total_nt, d_phase, d_valid, d_read_count,
+                        d_min_codon_cov, d_flags, d_status, filter, d_workspace, workspace_bytes, algo,
+                        plan, hip_stream, &tm);
     if (rc == RP_OK) {
         hipError_t e = hipEventSynchronize(tm.ev[3]);
         if (e != hipSuccess) rc = fail(RP_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
@@ -307,8 +404,7 @@ int rp_phase_score_frames_dev(int device, const int32_t *d_counts, const int64_t
     if (n_orfs < 0) return fail(RP_ERR_SIZE, "n_orfs must be >= 0");
     if (n_orfs > 0 && (!d_offsets || !d_frame_score || !d_frame_n || !d_frame_m))
         return fail(RP_ERR_NULL, "offsets and the three output arrays must be non-null");
-    int rc = select_device(device);
-    if (rc != RP_OK) return rc;
+    RP_ON_DEVICE(device);
     if (n_orfs == 0) return RP_OK;
     const int grid = grid_for_waves(n_orfs, rp::kWaveBlock / rp::kWave);
     hipLaunchKernelGGL(rp::k_wave_frames, dim3(grid), dim3(rp::kWaveBlock), 0, (hipStream_t)hip_stream,
@@ -324,8 +420,7 @@ int rp_phase_score_f64_csr_dev(int device, const double *d_values, const int64_t
     if (n_profiles < 0) return fail(RP_ERR_SIZE, "n_profiles must be >= 0");
     if (n_profiles > 0 && (!d_offsets || !d_phase || !d_valid || !d_flags))
         return fail(RP_ERR_NULL, "offsets and the three output arrays must be non-null");
-    int rc = select_device(device);
-    if (rc != RP_OK) return rc;
+    RP_ON_DEVICE(device);
     if (n_profiles == 0) return RP_OK;
     const int grid = grid_for_waves(n_profiles, rp::kWaveBlock / rp::kWave);
     hipLaunchKernelGGL(rp::k_wave_score_f64in, dim3(grid), dim3(rp::kWaveBlock), 0,
@@ -344,8 +439,7 @@ int rp_gather_profiles_dev(int device, const int32_t *d_coverage, int64_t covera
     if (n_orfs < 0 || coverage_len < 0) return fail(RP_ERR_SIZE, "negative size");
     if (n_orfs > 0 && (!d_orf_iv || !d_reverse || !d_offsets))
         return fail(RP_ERR_NULL, "interval CSR, strand flags and offsets must be non-null");
-    int rc = select_device(device);
-    if (rc != RP_OK) return rc;
+    RP_ON_DEVICE(device);
     if (n_orfs == 0) return RP_OK;
     // one wave per batch of 64 ORFs
     const int grid = grid_for_waves((n_orfs + rp::kWave - 1) / rp::kWave, rp::kWaveBlock / rp::kWave);
@@ -452,8 +546,7 @@ int rp_validate_csr_dev(int device, const int32_t *d_counts, const int64_t *d_of
     if (n_orfs < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "negative size");
     if (!d_offsets) return fail(RP_ERR_NULL, "d_offsets is null");
     if (total_nt > 0 && !d_counts) return fail(RP_ERR_NULL, "d_counts is null but total_nt > 0");
-    int rc = select_device(device);
-    if (rc != RP_OK) return rc;
+    RP_ON_DEVICE(device);
     hipStream_t stream = (hipStream_t)hip_stream;
     int *d_err = nullptr;
     // validation is a debugging aid, not the hot path: it owns a 4-byte scratch word

@@ -38,6 +38,10 @@ constexpr int kWave = 64;
 constexpr double kRecheckMargin = 1e-5;
 constexpr double kTileMargin = 1e-5;
 constexpr double kTileMarginAbs = 1e-8;
+// A phase score built from fp32 sums is off by <= kTileMargin * sqrt(score) / (2 sqrt(score)) =
+// 5e-6 (tile path; the wave path's bound is of the same size): when it lands closer than
+// this to phase_score_cutoff the `>=` of detect_orfs.py:290 is decided in float64 instead.
+constexpr double kCutoffMargin = 2e-5;
 
 // ---------------------------------------------------------------------------
 // per-codon accumulation
@@ -322,6 +326,13 @@ __device__ __forceinline__ unsigned char orf_status(const FilterParams &fp, doub
         ok = ok && ratio >= fp.min_valid_codons_ratio && density >= fp.min_density_over_orf;
     }
     return ok ? 1 : 0;
+}
+
+// Is an fp32-based phase score too close to the cutoff for the status comparison
+// (detect_orfs.py:290, `coh >= phase_score_cutoff`) to be trusted?
+__device__ __forceinline__ bool near_cutoff(const FilterParams &fp, double phase)
+{
+    return fp.enabled && fabs(phase - fp.phase_score_cutoff) <= kCutoffMargin;
 }
 
 struct OrfOutputs {

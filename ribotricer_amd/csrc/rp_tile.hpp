@@ -136,22 +136,29 @@ inline TileWorkspace carve_workspace(void *base, long long n_orfs, long long tot
 // ---------------------------------------------------------------------------
 // pass 1: tile_first[b] = lower_bound(offsets[0..n], start position of tile b)
 // ---------------------------------------------------------------------------
+// `err` (may be null) receives bit 0 when the offsets are not a valid CSR index for total_nt
+// nucleotides (offsets[0] != 0, a decreasing step, offsets[n] != total_nt): the plan builder
+// (rp_plan_create_dev) checks it once, so the per-sample scoring calls need not.
 template <int TILE>
 __global__ void k_tile_index(const int64_t *__restrict__ offsets, long long n_orfs, TilePlan plan,
-                             TileWorkspace ws)
+                             long long *__restrict__ tile_first, int *__restrict__ err)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > n_orfs) return;
-    if (i == 0) ws.tile_first[0] = 0;
-    if (i == n_orfs) ws.tile_first[plan.n_tiles] = n_orfs;
+    if (i == 0) tile_first[0] = 0;
+    if (i == n_orfs) tile_first[plan.n_tiles] = n_orfs;
     const long long o = offsets[i];
     const long long o_prev = i > 0 ? (long long)offsets[i - 1] : -1 - (long long)plan.mis;
+    if (err != nullptr) {
+        const bool bad = (i == 0 && o != 0) || (i > 0 && o < o_prev) || (i == n_orfs && o != plan.total_nt);
+        if (bad) atomicOr(err, 1);
+    }
     // tiles b >= 1 whose start position b*TILE - mis lies in (o_prev, o]
     long long b_lo = (o_prev + plan.mis) / TILE + 1;
     long long b_hi = (o + plan.mis) / TILE;
     if (b_lo < 1) b_lo = 1;
     if (b_hi > plan.n_tiles - 1) b_hi = plan.n_tiles - 1;
-    for (long long b = b_lo; b <= b_hi; ++b) ws.tile_first[b] = i;
+    for (long long b = b_lo; b <= b_hi; ++b) tile_first[b] = i;
 }
 
 // ---------------------------------------------------------------------------
@@ -674,14 +681,13 @@ __global__ __launch_bounds__(kTileBlock) void k_orf_finish(const int32_t *__rest
         FrameScore fr[3];
 #pragma unroll
         for (int f = 0; f < 3; ++f) fr[f] = frame_score(p[f], q[f], n[f], m[f]);
-        unsafe = fp32_decision_unsafe(fr, /*tile_sums=*/true);
-        if (!unsafe) {
-            double phase;
-            int valid;
-            unsigned flags;
-            combine_frames(fr, phase, valid, flags);
-            store_orf(out, fp, orf, phase, valid, count, min_codon, flags | split, len);
-        }
+        double phase;
+        int valid;
+        unsigned flags;
+        combine_frames(fr, phase, valid, flags);
+        // re-walk in float64 when the frame decision OR the cutoff comparison is too close to call
+        unsafe = fp32_decision_unsafe(fr, /*tile_sums=*/true) || near_cutoff(fp, phase);
+        if (!unsafe) store_orf(out, fp, orf, phase, valid, count, min_codon, flags | split, len);
     }
     if (!__syncthreads_or(unsafe)) return;
 

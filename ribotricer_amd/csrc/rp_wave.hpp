@@ -79,8 +79,8 @@ __device__ __forceinline__ void wave_reduce_frames(const WalkResult<Real> &w, Fr
 constexpr long long kWaveFp32MaxLen = 16384;
 
 __device__ __forceinline__ void wave_score_orf(const int32_t *__restrict__ v, long long len, int lane,
-                                               double &phase, int &valid, long long &count,
-                                               int &min_codon, unsigned &flags)
+                                               const FilterParams &fp, double &phase, int &valid,
+                                               long long &count, int &min_codon, unsigned &flags)
 {
     FrameScore fr[3];
     unsigned extra = 0;
@@ -90,6 +90,10 @@ __device__ __forceinline__ void wave_score_orf(const int32_t *__restrict__ v, lo
         wave_walk<float>(v, len, lane, w);
         wave_reduce_frames(w, fr, count, min_codon);
         need64 = fp32_decision_unsafe(fr);  // wave-uniform
+        if (!need64 && fp.enabled) {  // status must not hinge on fp32 rounding next to the cutoff
+            combine_frames(fr, phase, valid, flags);
+            need64 = near_cutoff(fp, phase);
+        }
     }
     if (need64) {
         WalkResult<double> w;
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(kWaveBlock) void k_wave_score(const int32_t *__rest
         int valid, min_codon;
         long long count;
         unsigned flags;
-        wave_score_orf(counts + beg, len, lane, phase, valid, count, min_codon, flags);
+        wave_score_orf(counts + beg, len, lane, fp, phase, valid, count, min_codon, flags);
         if (lane == 0) store_orf(out, fp, orf, phase, valid, count, min_codon, flags, len);
     }
 }

@@ -13,7 +13,9 @@ status predicate, for all ORFs of a CSR-packed batch at once.
 from __future__ import annotations
 
 import ctypes
-from typing import NamedTuple, Optional
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from typing import NamedTuple, Optional, Sequence
 
 import numpy as np
 import torch
@@ -100,8 +102,55 @@ def _alloc_outputs(dev: torch.device, n: int, with_status: bool) -> PhaseScores:
     )
 
 
+class TilePlan:
+    """A tile plan (``rp_plan``): what the tile path derives from the offsets alone, built --
+    and the offsets validated -- once per candidate-ORF index.  Owns its device memory."""
+
+    def __init__(self, device: torch.device, offsets: torch.Tensor, total_nt: int, counts_phase: int, stream):
+        n = offsets.numel() - 1
+        self.device = device
+        self.n_orfs = n
+        self.total_nt = total_nt
+        self.counts_phase = counts_phase
+        self.offsets = offsets  # keeps the storage alive: its address cannot be recycled under the cache
+        self.offsets_version = offsets._version
+        self._mem = torch.empty(_lib.plan_bytes(n, total_nt), dtype=torch.uint8, device=device)
+        handle = ctypes.c_void_p(0)
+        _lib.check(
+            _lib.load().rp_plan_create_dev(
+                device.index, _ptr(offsets), n, total_nt, counts_phase, _ptr(self._mem), self._mem.numel(),
+                stream, ctypes.byref(handle),
+            )
+        )
+        self.handle = handle
+
+    def matches(self, offsets: torch.Tensor, total_nt: int, counts_phase: int) -> bool:
+        return (
+            offsets.data_ptr() == self.offsets.data_ptr()
+            and offsets.numel() == self.offsets.numel()
+            and offsets._version == self.offsets_version == self.offsets._version
+            and total_nt == self.total_nt
+            and counts_phase == self.counts_phase
+        )
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                _lib.load().rp_plan_free(h)
+            except Exception:  # pragma: no cover - interpreter shutdown
+                pass
+
+
+AUTO_WAVE_NT = 2 << 20  # RP_ALGO_AUTO: wave kernel below this many nucleotides (ribophase.hip)
+MAX_CACHED_PLANS = 4
+
+
 class PhaseScoreEngine:
-    """Owns the reusable device buffers (outputs + workspace) for one GPU."""
+    """Owns the reusable device buffers (outputs, workspaces, tile plans) for one GPU.
+
+    Thread-safe for concurrent ``score`` calls on DIFFERENT streams: the workspace and the
+    reusable outputs are kept per stream, the plan cache is locked."""
 
     def __init__(self, device=None):
         _lib.load()
@@ -111,25 +160,46 @@ class PhaseScoreEngine:
             raise ValueError("PhaseScoreEngine needs a cuda (HIP) device")
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self._workspace: Optional[torch.Tensor] = None
-        self._out: Optional[PhaseScores] = None
+        self._workspace: dict = {}  # stream handle -> uint8 tensor
+        self._out: dict = {}  # stream handle -> PhaseScores
+        self._plans: list = []  # most recently used last
+        self._lock = threading.Lock()
 
     # -- buffers -----------------------------------------------------------------
-    def _get_workspace(self, nbytes: int) -> Optional[torch.Tensor]:
+    def _get_workspace(self, nbytes: int, stream_key: int) -> Optional[torch.Tensor]:
         if nbytes == 0:
             return None
-        if self._workspace is None or self._workspace.numel() < nbytes:
-            self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        return self._workspace
+        ws = self._workspace.get(stream_key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._workspace[stream_key] = ws
+        return ws
 
-    def _get_outputs(self, n: int, with_status: bool) -> PhaseScores:
-        o = self._out
+    def _get_outputs(self, n: int, with_status: bool, stream_key: int) -> PhaseScores:
+        o = self._out.get(stream_key)
         if o is None or o.phase.numel() != n or (with_status and o.status is None):
             o = _alloc_outputs(self.device, n, with_status)
-            self._out = o
+            self._out[stream_key] = o
         if not with_status and o.status is not None:
             o = o._replace(status=None)
         return o
+
+    def plan_for(self, offsets: torch.Tensor, total_nt: int, counts_phase: int = 0) -> TilePlan:
+        """The cached plan for this offsets tensor (same storage, unmodified), or a new one.
+
+        Building a plan validates the offsets (RibophaseError -3 on a bad index) and
+        synchronises the current stream once."""
+        with self._lock:
+            for k, p in enumerate(self._plans):
+                if p.matches(offsets, total_nt, counts_phase):
+                    self._plans.append(self._plans.pop(k))
+                    return p
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        p = TilePlan(self.device, offsets, total_nt, counts_phase, stream)
+        with self._lock:
+            self._plans.append(p)
+            del self._plans[:-MAX_CACHED_PLANS]
+        return p
 
     # -- the hot path --------------------------------------------------------------
     def score(
@@ -140,13 +210,22 @@ class PhaseScoreEngine:
         algo: str = "auto",
         reuse_outputs: bool = False,
         timings: Optional[list] = None,
+        plan="auto",
     ) -> PhaseScores:
         """Score every ORF of a CSR batch (counts int32, offsets int64, offsets[-1] == len(counts)).
 
         Asynchronous on the current torch stream unless ``timings`` is a list, in
         which case the call blocks and appends [index_ms, main_ms, finish_ms, total_ms].
+
+        ``plan``: "auto" (default) keeps a tile plan per offsets TENSOR -- the first call on
+        a device-resident index builds and validates it (one stream sync), later calls with
+        the same, unmodified tensor skip the index pass, which is how ``detect-orfs`` uses
+        one index for many samples; ``None`` rebuilds the tile index inside every call; a
+        :class:`TilePlan` uses that plan.  Host (numpy) inputs are checked on the host and
+        never planned.
         """
         dev = self.device
+        host_offsets = offsets if isinstance(offsets, np.ndarray) else None
         counts = _as_device(counts, torch.int32, dev)
         offsets = _as_device(offsets, torch.int64, dev)
         if offsets.dim() != 1 or offsets.numel() < 1 or counts.dim() != 1:
@@ -154,36 +233,52 @@ class PhaseScoreEngine:
         n = offsets.numel() - 1
         total_nt = counts.numel()
         algo_id = _lib.ALGOS[algo]
-        ws = self._get_workspace(_lib.workspace_bytes(n, total_nt, algo_id))
+        tile_path = algo == "tile" or (algo == "auto" and total_nt >= AUTO_WAVE_NT) or isinstance(plan, TilePlan)
+        if host_offsets is not None:
+            # the caller's index is on the host: check the one thing the kernels rely on for
+            # in-bounds reads without touching the device
+            if int(host_offsets[-1]) != total_nt or int(host_offsets[0]) != 0:
+                raise RibophaseError(-3, f"offsets must run from 0 to len(counts)={total_nt}, got {int(host_offsets[0])}..{int(host_offsets[-1])}")
+            if plan == "auto":
+                plan = None
+        elif plan == "auto":
+            if tile_path and n > 0:
+                plan = self.plan_for(offsets, total_nt, (counts.data_ptr() // 4) % 4 if total_nt else 0)
+            else:  # small device-resident batch on the wave path: one scalar read-back
+                if int(offsets[-1]) != total_nt:
+                    raise RibophaseError(-3, f"offsets[-1]={int(offsets[-1])} but len(counts)={total_nt}")
+                plan = None
+        stream_obj = torch.cuda.current_stream(dev)
+        stream_key = int(stream_obj.cuda_stream)
+        stream = ctypes.c_void_p(stream_key)
+        ws = self._get_workspace(_lib.workspace_bytes(n, total_nt, _lib.RP_ALGO_TILE if tile_path else algo_id), stream_key)
         with_status = thresholds is not None
-        out = self._get_outputs(n, with_status) if reuse_outputs else _alloc_outputs(dev, n, with_status)
+        out = self._get_outputs(n, with_status, stream_key) if reuse_outputs else _alloc_outputs(dev, n, with_status)
         lib = _lib.load()
-        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        args = [
-            dev.index,
-            _ptr(counts),
-            _ptr(offsets),
-            n,
-            total_nt,
-            _ptr(out.phase),
-            _ptr(out.valid),
-            _ptr(out.read_count),
-            _ptr(out.min_codon_cov),
-            _ptr(out.flags),
-            _ptr(out.status),
-            ctypes.byref(thresholds) if thresholds is not None else None,
-            _ptr(ws),
-            0 if ws is None else ws.numel(),
-            algo_id,
-            stream,
-        ]
-        if timings is None:
-            _lib.check(lib.rp_phase_score_csr_dev(*args))
-        else:
+        outputs = [_ptr(out.phase), _ptr(out.valid), _ptr(out.read_count), _ptr(out.min_codon_cov), _ptr(out.flags), _ptr(out.status)]
+        filt = ctypes.byref(thresholds) if thresholds is not None else None
+        ws_args = [_ptr(ws), 0 if ws is None else ws.numel()]
+        if timings is not None:
             ms = (ctypes.c_float * 4)()
-            _lib.check(lib.rp_phase_score_csr_dev_timed(*args, ctypes.byref(ms)))
+            _lib.check(
+                lib.rp_phase_score_csr_dev_timed(
+                    dev.index, _ptr(counts), _ptr(offsets), n, total_nt, *outputs, filt, *ws_args,
+                    _lib.RP_ALGO_TILE if plan is not None else algo_id, plan.handle if plan is not None else None,
+                    stream, ctypes.byref(ms),
+                )
+            )
             timings.append([float(x) for x in ms])
+        elif plan is not None:
+            if plan.device != dev or plan.n_orfs != n:
+                raise ValueError("plan belongs to another device / index")
+            _lib.check(lib.rp_phase_score_csr_plan_dev(plan.handle, _ptr(counts), _ptr(offsets), *outputs, filt, *ws_args, stream))
+        else:
+            _lib.check(lib.rp_phase_score_csr_dev(dev.index, _ptr(counts), _ptr(offsets), n, total_nt, *outputs, filt, *ws_args, algo_id, stream))
         return out
+
+    def score_sharded(self, counts, offsets, devices, thresholds: Optional[FilterParams] = None, algo: str = "auto") -> dict:
+        """See :func:`score_sharded` (this engine's device is not special)."""
+        return score_sharded(counts, offsets, devices, thresholds=thresholds, algo=algo)
 
     def validate(self, counts, offsets) -> None:
         """Synchronous input check; raises RibophaseError on bad offsets / counts."""
@@ -235,6 +330,7 @@ class PhaseScoreEngine:
 
 
 _engines: dict = {}
+_engines_lock = threading.Lock()
 
 
 def get_engine(device=None) -> PhaseScoreEngine:
@@ -243,9 +339,58 @@ def get_engine(device=None) -> PhaseScoreEngine:
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
-    if dev not in _engines:
-        _engines[dev] = PhaseScoreEngine(dev)
-    return _engines[dev]
+    with _engines_lock:
+        if dev not in _engines:
+            _engines[dev] = PhaseScoreEngine(dev)
+        return _engines[dev]
+
+
+def score_sharded(counts, offsets, devices: Sequence, thresholds: Optional[FilterParams] = None, algo: str = "auto") -> dict:
+    """Score one CSR batch on several GPUs of this node: host numpy arrays back, in ORF order.
+
+    The batch is cut into ``len(devices)`` contiguous ORF-index slices balanced on
+    nucleotides (``sharding.slice_bounds``; ORFs are independent: the loop body of
+    ribotricer/detect_orfs.py:274-324 carries no state between iterations), slice k is
+    copied to ``devices[k]`` and scored there on a stream of its own by a thread of its own
+    (ctypes releases the GIL for the duration of the library call), and the per-ORF results
+    are concatenated on the host.  No collective, no peer traffic besides the slice copies.
+    A device may appear more than once (two slices on one GPU, on two streams).
+    """
+    from .sharding import concat_results, slice_bounds
+
+    devs = [torch.device(d) if not isinstance(d, int) else torch.device("cuda", d) for d in devices]
+    if not devs:
+        raise ValueError("score_sharded needs at least one device")
+    off_host = offsets.cpu().numpy() if isinstance(offsets, torch.Tensor) else np.ascontiguousarray(offsets, dtype=np.int64)
+    n_total = int(off_host[-1]) if off_host.size else 0
+    n_counts = counts.numel() if isinstance(counts, torch.Tensor) else int(np.asarray(counts).size)
+    if off_host.size < 1 or int(off_host[0]) != 0 or n_total != n_counts:
+        raise RibophaseError(-3, "offsets must run from 0 to len(counts)")
+    bounds = slice_bounds(off_host, len(devs))
+
+    def work(k: int) -> dict:
+        dev = devs[k]
+        lo, hi = int(bounds[k]), int(bounds[k + 1])
+        a, b = int(off_host[lo]), int(off_host[hi])
+        eng = get_engine(dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                c = counts[a:b]
+                c = torch.from_numpy(np.ascontiguousarray(c, dtype=np.int32)) if not isinstance(c, torch.Tensor) else c
+                c = c.to(dev, non_blocking=True)
+                o = torch.from_numpy(off_host[lo : hi + 1] - off_host[lo]).to(dev, non_blocking=True)
+                res = eng.score(c, o, thresholds=thresholds, algo=algo, plan=None)
+                host = {k_: (None if v is None else v.cpu()) for k_, v in res._asdict().items()}
+            stream.synchronize()
+        return {k_: (None if v is None else v.numpy()) for k_, v in host.items()}
+
+    if len(devs) == 1:
+        parts = [work(0)]
+    else:
+        with ThreadPoolExecutor(max_workers=len(devs)) as pool:
+            parts = list(pool.map(work, range(len(devs))))
+    return concat_results(parts)
 
 
 def phase_score_csr(counts, offsets, thresholds: Optional[FilterParams] = None, algo: str = "auto", device=None) -> PhaseScores:

@@ -86,6 +86,11 @@ def coverage_entries(merged_alignments, extent: dict, base: dict):
                 hi[k] = extent[key][1]
         keep = (start[code] >= 0) & (pos >= lo[code]) & (pos <= hi[code])
         code, pos, cnt = code[keep], pos[keep], cnt[keep]
+        # the kernels' input contract (include/ribophase.h): 0 <= count <= RP_MAX_COUNT, checked on
+        # the int64 values before they are narrowed -- a silent wrap would only show up as wrong scores
+        if cnt.size and (int(cnt.min()) < 0 or int(cnt.max()) > _lib.MAX_COUNT):
+            bad = int(cnt.min()) if int(cnt.min()) < 0 else int(cnt.max())
+            raise _lib.RibophaseError(-7, f"P-site count {bad} on strand {strand!r} outside [0, {_lib.MAX_COUNT}]")
         all_idx.append(start[code] + (pos - lo[code]))
         all_cnt.append(cnt.astype(np.int32))
     if not all_idx:

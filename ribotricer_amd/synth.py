@@ -71,20 +71,34 @@ def synth_csr_host(n_orfs: int, seed: int = 20260213, cfg: str = "cfg2"):
     return counts, offsets
 
 
-def synth_csr_device(n_orfs: int, seed: int = 20260213, cfg: str = "cfg2", device="cuda", chunk_orfs: int = 2_000_000):
-    """(counts int32, offsets int64) as device tensors; counts drawn by torch.poisson on the GPU."""
+DEVICE_CHUNK_ORFS = 1_000_000  # fixed chunk grid of the device generator (part of the data definition)
+
+
+def synth_csr_device(n_orfs: int, seed: int = 20260213, cfg: str = "cfg2", device="cuda", orf_range=None):
+    """(counts int32, offsets int64) as device tensors; counts drawn by torch.poisson on the GPU.
+
+    The ORF set is defined on a fixed grid of ``DEVICE_CHUNK_ORFS``-ORF chunks, chunk c drawn
+    from its own generator seeded ``seed + 2 + 7919 * c``, so any rank can materialise any
+    ORF-index slice ``orf_range=(lo, hi)`` of the SAME set without generating the rest
+    (BASELINE configs[3]: one 11 M-ORF set sharded over the GPUs).  With ``orf_range`` the
+    returned offsets are rebased to 0 and cover ORFs lo..hi only.
+    """
     import torch
 
     dev = torch.device(device)
     lengths = orf_lengths(n_orfs, seed, cfg)
     offsets_np = offsets_from_lengths(lengths)
     lam_np, framed_np = orf_rates(n_orfs, seed)
-    total = int(offsets_np[-1])
+    lo_all, hi_all = (0, n_orfs) if orf_range is None else (int(orf_range[0]), int(orf_range[1]))
+    base = int(offsets_np[lo_all])
+    total = int(offsets_np[hi_all]) - base
     counts = torch.empty(total, dtype=torch.int32, device=dev)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(seed + 2)
-    for lo in range(0, n_orfs, chunk_orfs):
-        hi = min(n_orfs, lo + chunk_orfs)
+    for c in range(lo_all // DEVICE_CHUNK_ORFS, (max(hi_all, lo_all + 1) - 1) // DEVICE_CHUNK_ORFS + 1):
+        lo, hi = c * DEVICE_CHUNK_ORFS, min(n_orfs, (c + 1) * DEVICE_CHUNK_ORFS)
+        if hi <= lo:
+            continue
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed + 2 + 7919 * c)
         ln = torch.from_numpy(lengths[lo:hi]).to(dev)
         off = torch.from_numpy(offsets_np[lo:hi] - offsets_np[lo]).to(dev)
         lam = torch.from_numpy(lam_np[lo:hi].astype(np.float32)).to(dev)
@@ -93,8 +107,14 @@ def synth_csr_device(n_orfs: int, seed: int = 20260213, cfg: str = "cfg2", devic
         pos = torch.arange(orf_id.numel(), device=dev) - off[orf_id]
         w = torch.where(framed[orf_id], torch.where(pos % 3 == 0, 2.0, 0.5), 1.0)
         rate = lam[orf_id] * w
-        a, b = int(offsets_np[lo]), int(offsets_np[hi])
-        counts[a:b] = torch.poisson(rate, generator=gen).to(torch.int32)
-        del ln, off, lam, framed, orf_id, pos, w, rate
-    offsets = torch.from_numpy(offsets_np).to(dev)
+        chunk = torch.poisson(rate, generator=gen).to(torch.int32)
+        # the part of this chunk that falls inside [lo_all, hi_all)
+        a, b = max(lo, lo_all), min(hi, hi_all)
+        if b > a:
+            src0 = int(offsets_np[a] - offsets_np[lo])
+            n_nt = int(offsets_np[b] - offsets_np[a])
+            dst0 = int(offsets_np[a]) - base
+            counts[dst0 : dst0 + n_nt] = chunk[src0 : src0 + n_nt]
+        del ln, off, lam, framed, orf_id, pos, w, rate, chunk
+    offsets = torch.from_numpy(offsets_np[lo_all : hi_all + 1] - base).to(dev)
     return counts, offsets

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_version_and_status_strings():
-    assert _lib.version() == "0.1.0"
+    assert _lib.version() == "0.2.0"
     lib = _lib.load()
     assert lib.rp_status_string(0) == b"ok"
     assert lib.rp_status_string(-3) == b"bad CSR offsets"
@@ -59,6 +59,13 @@ def test_argument_errors_do_not_need_a_gpu():
     assert lib.rp_workspace_bytes(10, 3000, _lib.RP_ALGO_WAVE, ctypes.byref(out)) == 0 and out.value == 0
     assert lib.rp_workspace_bytes(10, 3000, _lib.RP_ALGO_TILE, ctypes.byref(out)) == 0 and out.value > 0
     assert lib.rp_device_count(None) == -1
+    assert lib.rp_workspace_bytes(1, 1, 3, ctypes.byref(out)) == -8  # the round-1 RP_ALGO_TILE_PIPE is gone
+    assert lib.rp_plan_bytes(10, 3000, ctypes.byref(out)) == 0 and out.value >= 128 + 2 * 8
+    assert lib.rp_plan_bytes(10, 3000, None) == -1
+    handle = ctypes.c_void_p()
+    assert lib.rp_plan_create_dev(0, None, 10, 3000, 0, None, 0, None, ctypes.byref(handle)) == -1
+    assert lib.rp_phase_score_csr_plan_dev(None, None, None, None, None, None, None, None, None, None, None, 0, None) == -1
+    lib.rp_plan_free(None)
 
 
 def test_no_cpu_fallback_without_gpu():

@@ -13,7 +13,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_has_the_contract_fields():
     out = subprocess.run(
-        [sys.executable, os.path.join(REPO, "bench.py"), "--orfs", "20000", "--steps", "3", "--warmup", "1", "--cpu-sample", "300"],
+        [sys.executable, os.path.join(REPO, "bench.py"), "--orfs", "60000", "--steps", "3", "--warmup", "1", "--cpu-sample", "100",
+         "--cpu-cores", "4"],
         capture_output=True, text=True, timeout=600, cwd=REPO,
     )
     assert out.returncode == 0, out.stderr[-2000:]
@@ -24,7 +25,7 @@ def test_bench_line_has_the_contract_fields():
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["unit"] == "ORFs/s"
+    assert d["scaling"] == "strong" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["unit"] == "ORFs/s"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -34,5 +35,32 @@ def test_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    assert c["kind"] in ("port", "reference") and c["cores"] == 4 and c["value"] > 0
+    assert d["cpu_baseline_1core"]["cores"] == 1
     assert d["value"] > 0 and d["ms_per_step"] > 0
+    assert "configs[2]" in d["config"]["workload"] and d["config"]["orfs_total"] == 60000
+    assert d["roofline"]["kernel"] == "rp::k_tile_score"
+
+
+def test_two_ranks_shard_one_set_and_concat_equals_whole():
+    """BASELINE configs[3] in miniature: `bench.py --gpus 2` as two ranks (sharing the one GPU
+    of this box, gloo for the control traffic) cut ONE seeded set with sharding.slice_bounds,
+    score their slices, and rank 0 checks concat == whole on the device."""
+    env = dict(os.environ, RP_BENCH_BACKEND="gloo")
+    port = 29600 + os.getpid() % 300
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--orfs", "300000", "--steps", "3",
+         "--warmup", "1"],
+        capture_output=True, text=True, timeout=900, cwd=REPO, env=env,
+    )
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["verify"]["ok"] is True and d["verify"]["orfs_checked"] == 300000 and d["verify"]["max_abs_dphase"] <= 1e-6
+    assert len(d["per_rank"]) == 2 and sum(r["orfs"] for r in d["per_rank"]) == 300000
+    nts = [r["nt"] for r in d["per_rank"]]
+    assert abs(nts[0] - nts[1]) <= 0.02 * sum(nts)  # nt-balanced
+    assert "configs[3]" in d["config"]["workload"] and "cpu_baseline" not in d

@@ -11,7 +11,7 @@ from ribotricer_amd.engine import PhaseScoreEngine
 a, b = int(sys.argv[1]), int(sys.argv[2])
 eng = PhaseScoreEngine("cuda:0")
 for seed in range(a, b):
-    for algo in ("tile", "pipe"):
+    for algo in ("tile",):
         rng = np.random.default_rng(1000 + seed)
         lens = lengths_for(seed, TILES[algo])
         offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
