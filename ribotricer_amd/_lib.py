@@ -12,7 +12,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libribophase.so")
+# RIBOPHASE_LIB selects another build of the same library (kernel A/B runs: scripts/ab_variants.py)
+LIB_PATH = os.environ.get("RIBOPHASE_LIB") or os.path.join(_HERE, "csrc", "libribophase.so")
 
 RP_OK = 0
 RP_ALGO_AUTO, RP_ALGO_WAVE, RP_ALGO_TILE = 0, 1, 2

@@ -121,15 +121,31 @@ struct Timing {
 
 bool known_algo(int algo) { return algo == RP_ALGO_AUTO || algo == RP_ALGO_WAVE || algo == RP_ALGO_TILE; }
 
-int launch_tile_index(const int64_t *d_offsets, int64_t n_orfs, const rp::TilePlan &plan,
-                      long long *d_tile_first, int *d_err, hipStream_t stream)
+// the part of a launch that depends on the offsets only: tile index + segment descriptors
+int launch_plan_kernels(const int64_t *d_offsets, int64_t n_orfs, const rp::TilePlan &plan,
+                        const rp::TileWorkspace &ws, int *d_err, hipStream_t stream)
 {
-    const long long threads = n_orfs + 1;
     const int block = 256;
-    const int grid = (int)((threads + block - 1) / block);
-    hipLaunchKernelGGL(rp::k_tile_index<rp::kTile>, dim3(grid), dim3(block), 0, stream, d_offsets,
-                       (long long)n_orfs, plan, d_tile_first, d_err);
-    RP_HIP(hipGetLastError());
+    // head rows and descriptors are contiguous: gaps (empty ORFs, unused ids, unused slots) read as 0
+    RP_HIP(hipMemsetAsync(ws.head, 0, rp::head_bytes(plan.total_nt, rp::kTile) + (size_t)ws.n_rec * sizeof(rp::seg_desc_t), stream));
+    {
+        const long long threads = n_orfs + 1;
+        const int grid = (int)((threads + block - 1) / block);
+        hipLaunchKernelGGL(rp::k_tile_index<rp::kTile>, dim3(grid), dim3(block), 0, stream, d_offsets,
+                           (long long)n_orfs, plan, ws.tile_first, d_err);
+        RP_HIP(hipGetLastError());
+    }
+    if (n_orfs > 0) {
+        const int grid = (int)((n_orfs + block - 1) / block);
+        hipLaunchKernelGGL(rp::k_tile_desc<rp::kTile>, dim3(grid), dim3(block), 0, stream, d_offsets,
+                           (long long)n_orfs, plan, ws.tile_first, ws.head, ws.desc);
+        RP_HIP(hipGetLastError());
+    }
+    {
+        const int grid = (int)((plan.n_tiles + block - 1) / block);
+        hipLaunchKernelGGL(rp::k_tile_head, dim3(grid), dim3(block), 0, stream, plan.n_tiles, ws.tile_first, ws.head);
+        RP_HIP(hipGetLastError());
+    }
     return RP_OK;
 }
 
@@ -141,9 +157,9 @@ int launch_tile_index(const int64_t *d_offsets, int64_t n_orfs, const rp::TilePl
 struct rp_plan {
     int device;
     long long n_orfs, total_nt;
-    int mis;                // (counts address / 4) % 4 the plan was built for
-    long long *tile_first;  // device, caller-owned (inside d_plan_mem)
-    int *err;               // device, first word of d_plan_mem
+    int mis;         // (counts address / 4) % 4 the plan was built for
+    void *tables;    // device, caller-owned (inside d_plan_mem): tile index + segment descriptors
+    int *err;        // device, first word of d_plan_mem
 };
 
 namespace {
@@ -189,32 +205,31 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
         return RP_OK;
     }
 
-    size_t need = 0;
-    rc = rp_workspace_bytes(n_orfs, total_nt, algo, &need);
-    if (rc != RP_OK) return rc;
+    // with a plan only the records live in the workspace
+    const size_t need = plan_h ? rp::record_bytes(n_orfs, total_nt, rp::kTile) : rp::workspace_bytes(n_orfs, total_nt, rp::kTile);
     if (!d_workspace || workspace_bytes < need)
         return fail(RP_ERR_WORKSPACE, "workspace of %zu bytes required, got %zu", need, workspace_bytes);
     if ((reinterpret_cast<uintptr_t>(d_workspace) & 15u) != 0)
         return fail(RP_ERR_WORKSPACE, "workspace must be 16-byte aligned");
-    // RP_ALGO_TILE: tile index (or the caller's plan) -> scoring pass (segment records) -> per-ORF finish
-    const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt, d_counts, rp::kTile);
-    rp::TileWorkspace ws = rp::carve_workspace(d_workspace, n_orfs, total_nt, rp::kTile);
+    // RP_ALGO_TILE: plan tables (the caller's, or built here) -> scoring pass (segment records) -> per-ORF finish
+    const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt, rp::counts_phase(d_counts), rp::kTile);
     if (plan_h != nullptr) {
         if (plan_h->device != device || plan_h->n_orfs != n_orfs || plan_h->total_nt != total_nt)
             return fail(RP_ERR_ARG, "plan was built for device %d, %lld ORFs, %lld nt; called with device %d, %lld ORFs, %lld nt",
                         plan_h->device, plan_h->n_orfs, plan_h->total_nt, device, (long long)n_orfs, (long long)total_nt);
         if (plan_h->mis != plan.mis)
             return fail(RP_ERR_ARG, "plan was built for counts at 16-byte phase %d, d_counts has phase %d", plan_h->mis, plan.mis);
-        ws.tile_first = plan_h->tile_first;
-    } else {
-        // 1. tile index: first ORF starting at or after each tile boundary
-        rc = launch_tile_index(d_offsets, n_orfs, plan, ws.tile_first, nullptr, stream);
+    }
+    const rp::TileWorkspace ws = rp::carve_workspace(d_workspace, plan_h ? plan_h->tables : nullptr, n_orfs, total_nt, rp::kTile);
+    if (plan_h == nullptr) {
+        // 1. tile index (first ORF starting at or after each tile boundary) + segment descriptors
+        rc = launch_plan_kernels(d_offsets, n_orfs, plan, ws, nullptr, stream);
         if (rc != RP_OK) return rc;
     }
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[1], stream));
     // 2. scoring pass over flat tiles: one record per (ORF, tile) segment
     hipLaunchKernelGGL(rp::k_tile_score, dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
-                       d_counts, d_offsets, (long long)n_orfs, plan, ws);
+                       d_counts, (long long)n_orfs, plan, ws);
     RP_HIP(hipGetLastError());
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));
     // 3. one thread per ORF: add its records, score, filter, store
@@ -232,6 +247,14 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
 }  // namespace
 
 extern "C" {
+
+#ifdef RP_STAMPS
+// measurement builds only: read the phase stamps of k_tile_score (kStampSlots x 4 x 8 uint64)
+int rp_debug_read_stamps(unsigned long long *out)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rp::rp_dbg_stamps), sizeof(unsigned long long) * rp::kStampSlots * 32) == hipSuccess ? 0 : -1;
+}
+#endif
 
 const char *rp_version(void) { return RP_VERSION_STRING; }
 
@@ -295,7 +318,7 @@ int rp_plan_bytes(int64_t n_orfs, int64_t total_nt, size_t *bytes)
 {
     if (!bytes) return fail(RP_ERR_NULL, "bytes is null");
     if (n_orfs < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "negative size");
-    *bytes = kPlanHeader + rp::tile_index_bytes(total_nt, rp::kTile);
+    *bytes = kPlanHeader + rp::plan_bytes(n_orfs, total_nt, rp::kTile);
     return RP_OK;
 }
 
@@ -315,16 +338,12 @@ int rp_plan_create_dev(int device, const int64_t *d_offsets, int64_t n_orfs, int
     if ((reinterpret_cast<uintptr_t>(d_plan_mem) & 15u) != 0) return fail(RP_ERR_WORKSPACE, "plan memory must be 16-byte aligned");
     RP_ON_DEVICE(device);
     hipStream_t stream = (hipStream_t)hip_stream;
-    rp::TilePlan plan;
-    plan.n_orfs = n_orfs;
-    plan.total_nt = total_nt;
-    plan.mis = counts_phase;
-    plan.n_tiles = (total_nt + plan.mis + rp::kTile - 1) / rp::kTile;
-    if (plan.n_tiles < 1) plan.n_tiles = 1;
+    const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt, counts_phase, rp::kTile);
     int *d_err = reinterpret_cast<int *>(d_plan_mem);
-    long long *d_tile_first = reinterpret_cast<long long *>(reinterpret_cast<char *>(d_plan_mem) + kPlanHeader);
+    void *tables = reinterpret_cast<char *>(d_plan_mem) + kPlanHeader;
+    rp::TileWorkspace ws = rp::carve_workspace(nullptr, tables, n_orfs, total_nt, rp::kTile);
     RP_HIP(hipMemsetAsync(d_err, 0, kPlanHeader, stream));
-    rc = launch_tile_index(d_offsets, n_orfs, plan, d_tile_first, d_err, stream);
+    rc = launch_plan_kernels(d_offsets, n_orfs, plan, ws, d_err, stream);
     if (rc != RP_OK) return rc;
     int h_err = 0;
     RP_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -336,7 +355,7 @@ int rp_plan_create_dev(int device, const int64_t *d_offsets, int64_t n_orfs, int
     h->n_orfs = n_orfs;
     h->total_nt = total_nt;
     h->mis = counts_phase;
-    h->tile_first = d_tile_first;
+    h->tables = tables;
     h->err = d_err;
     *out = h;
     return RP_OK;

@@ -47,10 +47,13 @@ constexpr int kTileBlock = 256;
 #define RP_TILE 7936
 #endif
 constexpr int kTile = RP_TILE;  // positions per tile (31 KiB of int32): 3 lane-run passes of 64 x 15 triplets
-constexpr int kRun = 15;        // triplets per lane run; odd => lane stride 45 dwords, conflict free
+#ifndef RP_KRUN
+#define RP_KRUN 15
+#endif
+constexpr int kRun = RP_KRUN;   // triplets per lane run; odd => lane stride 45 dwords, conflict free
 constexpr int kSegChunk = 64;   // segments set up per round (one per lane of wave 0)
 constexpr int kHalo = 8;        // dwords staged past the tile end (4 needed, 2 chunks loaded)
-constexpr int kLdsCounts = kTile + kHalo + 3 * kRun + 8;  // runs may read (masked) past the halo
+constexpr int kLdsCounts = kTile + kHalo + 3 * kRun + 16;  // runs may read (masked) past the halo
 static_assert(kTile / 3 < 65536, "N_f / M_f of a segment are kept in 16-bit fields");
 constexpr int kMaxRecs = kSegChunk + (kTile / (3 * kRun) + kSegChunk + 2 * 64) / 16 + 1;  // one per (segment, 16-lane row)
 
@@ -62,26 +65,41 @@ struct TilePlan {
 };
 
 // One record per (ORF, tile) segment: the sums over the triplets of the ORF that the tile
-// owns.  Struct of arrays, indexed by  orf + tile : an ORF spanning tiles s..e owns the
-// ids orf+s .. orf+e, and the next ORF starts in a tile >= e, so ids never collide.
-struct SegRecords {
-#ifdef RP_REC_F64
-    typedef double pq_t;
-#else
-    typedef float pq_t;  // the float64 sum of <= 11 fp32 row records, rounded once: +-6e-8 relative
-#endif
-    pq_t *pq;                   // [6][n_rec]  p[0..2], q[0..2]
-    unsigned long long *nn;     // [n_rec]     n[0] | n[1] << 16 | n[2] << 32
-    unsigned long long *mm;     // [n_rec]     same packing
-    unsigned long long *count;  // [n_rec]     reads
-    unsigned *min_codon;        // [n_rec]     RP_MIN_CODON_COV_EMPTY when no codon
-    long long n_rec;
-};
-constexpr size_t kRecordBytes = 6 * sizeof(SegRecords::pq_t) + 3 * 8 + 4;
+// owns.  Indexed by  orf + tile : an ORF spanning tiles s..e owns the ids orf+s .. orf+e, and
+// the next ORF starts in a tile >= e, so ids never collide.  48 bytes, array of structures:
+// the writer (one thread per segment) and the reader (one thread per ORF) each move a record
+// as three 16-byte words, and neighbouring threads hold neighbouring ids.
+//   word 0  p[0] p[1] p[2] q[0]          fp32: the float64 sum of <= 11 fp32 row records, rounded once
+//   word 1  q[1] q[2] count.lo count.hi
+//   word 2  n0|n1<<16  n2|m0<<16  m1|m2<<16  min_codon     (a tile owns < 2^16 triplets)
+constexpr size_t kRecordBytes = 48;
+
+// One descriptor per segment id, derived from the offsets alone (k_tile_desc): where the
+// segment's triplets lie inside its tile's LDS image and how many lanes walk them.
+//   bits  0-12  qfirst   LDS index of the first owned triplet
+//   bits 13-25  endq     ORF end in LDS coordinates, clamped to kTile + kHalo
+//   bits 26-37  ntrip    owned triplets
+//   bits 38-50  tail     LDS index of an owned partial last codon (L % 3 != 0) ...
+//   bits 51-52  part     ... and its length (0 = none)
+//   bits 53-60  lanes    ceil(ntrip / kRun)
+//   bit  63     live     0 = this id is a gap (no segment: empty ORF, or an unused id)
+typedef unsigned long long seg_desc_t;
+static_assert(kTile + kHalo < 8192 && kTile / 3 < 4096 && (kTile / 3 + kRun - 1) / kRun < 256, "descriptor field widths");
+
+// The first kHeadSlots segment slots of every tile are ALSO kept tile-major, behind the tile's
+// own [a0, a1) ORF range: row b = { a0, a1, desc(slot 0), ..., desc(slot kHeadSlots-1) }.  A
+// workgroup reads its row with one load that depends on nothing but blockIdx, so the segment
+// table is ready before the tile data has landed; only tiles with more segments than that
+// (short-ORF batches) also take the dependent path through tile_first and desc.
+constexpr int kHeadRow = 48;                  // 8-byte entries per row (384 B per 31 KiB tile)
+constexpr int kHeadSlots = kHeadRow - 2;
 
 struct TileWorkspace {
     long long *tile_first;  // [n_tiles + 1] first ORF starting at/after each tile start
-    SegRecords rec;
+    seg_desc_t *head;       // [max_tiles][kHeadRow]
+    seg_desc_t *desc;       // [n_rec]
+    uint4 *rec;             // [3 * n_rec]
+    long long n_rec;
 };
 
 inline long long max_tiles(long long total_nt, int tile) { return (total_nt + 3 + tile - 1) / tile + 1; }
@@ -91,16 +109,18 @@ inline long long max_records(long long n_orfs, long long total_nt, int tile)
     return (n_orfs + max_tiles(total_nt, tile) + 1 + 15) & ~15LL;  // keeps every array 16-byte aligned
 }
 
-inline TilePlan make_tile_plan(long long n_orfs, long long total_nt, const void *counts, int tile)
+inline TilePlan make_tile_plan(long long n_orfs, long long total_nt, int mis, int tile)
 {
     TilePlan p;
     p.n_orfs = n_orfs;
     p.total_nt = total_nt;
-    p.mis = (int)((reinterpret_cast<uintptr_t>(counts) >> 2) & 3u);
+    p.mis = mis;
     p.n_tiles = (total_nt + p.mis + tile - 1) / tile;
     if (p.n_tiles < 1) p.n_tiles = 1;
     return p;
 }
+
+inline int counts_phase(const void *counts) { return (int)((reinterpret_cast<uintptr_t>(counts) >> 2) & 3u); }
 
 inline size_t tile_index_bytes(long long total_nt, int tile)
 {
@@ -108,28 +128,43 @@ inline size_t tile_index_bytes(long long total_nt, int tile)
     return (b + 127) & ~(size_t)127;
 }
 
-inline size_t workspace_bytes(long long n_orfs, long long total_nt, int tile)
+inline size_t head_bytes(long long total_nt, int tile)
 {
-    return tile_index_bytes(total_nt, tile) + (size_t)max_records(n_orfs, total_nt, tile) * kRecordBytes;
+    return (size_t)max_tiles(total_nt, tile) * kHeadRow * sizeof(seg_desc_t);
 }
 
-inline TileWorkspace carve_workspace(void *base, long long n_orfs, long long total_nt, int tile)
+// plan part (depends on the offsets only): tile index + segment descriptors
+inline size_t plan_bytes(long long n_orfs, long long total_nt, int tile)
+{
+    return tile_index_bytes(total_nt, tile) + head_bytes(total_nt, tile) +
+           (size_t)max_records(n_orfs, total_nt, tile) * sizeof(seg_desc_t);
+}
+
+// per-call part: the segment records
+inline size_t record_bytes(long long n_orfs, long long total_nt, int tile)
+{
+    return (size_t)max_records(n_orfs, total_nt, tile) * kRecordBytes;
+}
+
+inline size_t workspace_bytes(long long n_orfs, long long total_nt, int tile)
+{
+    return record_bytes(n_orfs, total_nt, tile) + plan_bytes(n_orfs, total_nt, tile);
+}
+
+// records first (always in the workspace), then -- unless the caller brings a plan -- the plan part
+inline TileWorkspace carve_workspace(void *base, void *plan_base, long long n_orfs, long long total_nt, int tile)
 {
     TileWorkspace ws;
     char *p = reinterpret_cast<char *>(base);
-    ws.tile_first = reinterpret_cast<long long *>(p);
-    p += tile_index_bytes(total_nt, tile);
-    const size_t n = (size_t)max_records(n_orfs, total_nt, tile);
-    ws.rec.n_rec = (long long)n;
-    ws.rec.pq = reinterpret_cast<SegRecords::pq_t *>(p);
-    p += 6 * n * sizeof(SegRecords::pq_t);
-    ws.rec.nn = reinterpret_cast<unsigned long long *>(p);
-    p += n * sizeof(unsigned long long);
-    ws.rec.mm = reinterpret_cast<unsigned long long *>(p);
-    p += n * sizeof(unsigned long long);
-    ws.rec.count = reinterpret_cast<unsigned long long *>(p);
-    p += n * sizeof(unsigned long long);
-    ws.rec.min_codon = reinterpret_cast<unsigned *>(p);
+    ws.n_rec = max_records(n_orfs, total_nt, tile);
+    ws.rec = reinterpret_cast<uint4 *>(p);
+    p += record_bytes(n_orfs, total_nt, tile);
+    char *q = plan_base ? reinterpret_cast<char *>(plan_base) : p;
+    ws.tile_first = reinterpret_cast<long long *>(q);
+    q += tile_index_bytes(total_nt, tile);
+    ws.head = reinterpret_cast<seg_desc_t *>(q);
+    q += head_bytes(total_nt, tile);
+    ws.desc = reinterpret_cast<seg_desc_t *>(q);
     return ws;
 }
 
@@ -159,6 +194,65 @@ __global__ void k_tile_index(const int64_t *__restrict__ offsets, long long n_or
     if (b_lo < 1) b_lo = 1;
     if (b_hi > plan.n_tiles - 1) b_hi = plan.n_tiles - 1;
     for (long long b = b_lo; b <= b_hi; ++b) tile_first[b] = i;
+}
+
+// Segment descriptors: one thread per ORF walks the tiles it spans.  Everything here depends
+// on the offsets only, so with a plan it runs once per index, not once per sample.
+template <int TILE>
+__global__ void k_tile_desc(const int64_t *__restrict__ offsets, long long n_orfs, TilePlan plan,
+                            const long long *__restrict__ tile_first, seg_desc_t *__restrict__ head,
+                            seg_desc_t *__restrict__ desc)
+{
+    const long long orf = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (orf >= n_orfs) return;
+    const long long beg = offsets[orf];
+    const long long end = offsets[orf + 1];
+    if (end <= beg) return;  // empty profile: its slot stays a gap, k_orf_finish reads no record for it
+    if (beg < 0 || end > plan.total_nt) return;  // not a CSR index (rp_plan_create_dev reports it): stay in bounds
+    const long long b_first = (beg + plan.mis) / TILE;
+    const long long b_last = (end - 1 + plan.mis) / TILE;
+    for (long long b = b_first; b <= b_last; ++b) {
+        const long long t0 = b * (long long)TILE - plan.mis;
+        long long t1 = t0 + TILE;
+        if (t1 > plan.total_nt) t1 = plan.total_nt;
+        const int kt = (int)(t1 - t0);  // tile length in positions (<= TILE)
+        int qfirst;                     // LDS index of the first triplet start >= tile start
+        if (b > b_first) {              // the ORF straddles in from the left
+            const unsigned m3 = (unsigned)((unsigned long long)(t0 - beg) % 3ull);
+            qfirst = m3 == 0 ? 0 : 3 - (int)m3;
+        } else {
+            qfirst = (int)(beg - t0);
+        }
+        const long long rem = end - t0;  // > 0
+        const int endq = rem <= TILE + kHalo ? (int)rem : TILE + kHalo;
+        const int lim_q = kt < endq ? kt : endq;  // owned triplets start below this
+        const int ntrip = lim_q > qfirst ? (lim_q - qfirst + 2) / 3 : 0;
+        // partial last codon (L % 3 != 0): common.py:164-180 still sums it; it belongs to the
+        // tile that holds its first position and is added by the record stage
+        int tail = 0, part = 0;
+        if (rem <= TILE + kHalo && endq > qfirst) {
+            const int pt = (endq - qfirst) % 3;
+            if (pt != 0 && endq - pt < kt) {
+                tail = endq - pt;
+                part = pt;
+            }
+        }
+        const int lanes = (ntrip + kRun - 1) / kRun;
+        const seg_desc_t d = (seg_desc_t)qfirst | ((seg_desc_t)endq << 13) | ((seg_desc_t)ntrip << 26) |
+                             ((seg_desc_t)tail << 38) | ((seg_desc_t)part << 51) | ((seg_desc_t)lanes << 53) | (1ull << 63);
+        desc[orf + b] = d;
+        const long long slot = orf - (tile_first[b] - 1);  // slot 0 = the ORF straddling in from the left
+        if (slot >= 0 && slot < kHeadSlots) head[b * kHeadRow + 2 + slot] = d;
+    }
+}
+
+// the [a0, a1) header of every head row (one thread per tile; after k_tile_index)
+__global__ void k_tile_head(long long n_tiles, const long long *__restrict__ tile_first, seg_desc_t *__restrict__ head)
+{
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_tiles) return;
+    head[b * kHeadRow + 0] = (seg_desc_t)tile_first[b];
+    head[b * kHeadRow + 1] = (seg_desc_t)tile_first[b + 1];
 }
 
 // ---------------------------------------------------------------------------
@@ -328,15 +422,10 @@ __device__ __forceinline__ int wave_add_scan(int x)
     return x;
 }
 
-// The lane run: kRun triplets = 3*kRun codon starts read from 3*kRun + 2 consecutive LDS
-// dwords.  `lim` = number of leading codon starts that are real codons of this lane's ORF
-// and owned by this run.  Predicates are evaluated once per POSITION (is the count zero?
-// does it equal its successor?) and combined per codon on the scalar unit.
 #ifndef RP_KRUNBLOCK
 #define RP_KRUNBLOCK 3
 #endif
 constexpr int kRunBlock = RP_KRUNBLOCK;  // triplets per fully unrolled block of the lane run
-static_assert(kRun % kRunBlock == 0, "kRun must be a multiple of kRunBlock");
 
 // min(x, hi) for x, hi >= 0 on the BIT PATTERNS: non-negative IEEE floats order like
 // unsigned integers (+inf = 0x7f800000 included), so this is one 32-bit-encoded v_min_u32
@@ -352,95 +441,175 @@ __device__ __forceinline__ float min_nonneg(float x, float hi)
 // clamp(x, 0, 1): folds into the producing instruction's clamp modifier
 __device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 
-// The lane run, predicate-free: every test is folded into arithmetic so the float part of
-// the loop is 15 VALU instructions per codon with no v_cmp / v_cndmask / scalar mask traffic
-// (the masked integer count / minimum of frame 0 adds 2 per codon):
-//   vF  = clamp(lim - c, 0, 1)          1 while codon c is a real codon of this run
-//   r   = min(rsq(q), vF)               1/sqrt(q);  a == b == c gives rsq(0) = inf -> 1, and
-//                                       its d0 = d1 = 0 make the products below exactly 0
-//   P  += d0 r,  Q += d1 r              unit-vector sums
-//   u   = min(q, vF)                    q is an integer: 0 or >= 1, so u is exactly 1 for a
-//                                       counted codon, 0 otherwise                  -> M
-//   E  += (vF - u) * min(a, 1)          flat non-zero codons; N = M + E
-// M and E are sums of <= kRun exact 0/1 values per frame.
-// Counts are converted to fp32 first, exact below 2^24 (RP_MAX_COUNT).
-__device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, LaneSums &o)
+// ---------------------------------------------------------------------------------------
+// The lane run: <= kRun triplets = 3*kRun codon starts of ONE segment out of consecutive LDS
+// dwords (lane stride 3*kRun dwords, odd -> bank-conflict free), one codon of each reading
+// frame per position, fp32, no v_cmp / v_cndmask in the float part (statistics.py:67-91):
+//   d0 = a - b, d1 = b - c   exact (counts < 2^24);   q = d0^2 + d0 d1 + d1^2
+//   r  = rsq(q);   P += d0 r,  Q += d1 r          the unit vector in the oblique basis
+//   M += [q != 0],  E += [q == 0][a != 0]         N = M + E (codons that are not all-zero)
+//   frame 0 also sums the integer codon (read count, minimum codon coverage)
+// A run is walked in blocks of kRunBlock triplets, "ragged block first".  Only ONE block of a
+// lane can hold codon starts that are not the lane's to count -- the last one that holds any
+// (the run is short, or it ends the ORF and the last triplet's frame-1/2 codons reach past
+// it) -- so that block is processed FIRST, by every lane at once, with validity folded into
+// the arithmetic (vF = clamp(lim - c): r = min(rsq(q), vF), u = min(q, vF), ...; the mins
+// work on the float bit patterns).  The blocks below it are full by construction and are
+// walked downwards with NO validity arithmetic at all (lanes with fewer blocks drop out
+// through EXEC): 12 VALU instructions per position + the integer codon sum, against 17 for a
+// fully masked walk.  The two look-ahead values of a block are the first two of the block
+// above it, kept in registers, so every count is read from LDS and converted exactly once.
+// ---------------------------------------------------------------------------------------
+struct RunAcc {
+    float P[3], Q[3], M[3], E[3];
+    float T[3];  // unmasked blocks: codons with q == 0 (flat, all-zero included); M = codons - T
+    unsigned cnt, mn;
+};
+
+// One block of 3 * kRunBlock codon starts at s[0..]; (nf0, nf1) = the two values after the
+// block as floats.  MASKED: only the first `lim` starts count.  On return (nf0, nf1) are the
+// block's own first two values, for the block below.
+template <bool MASKED>
+__device__ __forceinline__ void run_block(const int *__restrict__ s, int lim, float &nf0, float &nf1, RunAcc &a)
 {
-    int v0 = s[0], v1 = s[1];
-    float f0 = (float)v0, f1 = (float)v1;
-    float df0 = f0 - f1;
-    float limf = (float)lim;
-    float P[3] = {0.f, 0.f, 0.f}, Q[3] = {0.f, 0.f, 0.f};
-    float M[3] = {0.f, 0.f, 0.f}, E[3] = {0.f, 0.f, 0.f};
-    unsigned cnt = 0, mn = (unsigned)RP_MIN_CODON_COV_EMPTY;
-#pragma unroll 1
-    for (int blk = 0; blk < kRun / kRunBlock; ++blk) {
+    constexpr int B = 3 * kRunBlock;
+    int v[B];
+    float f[B + 2];
 #pragma unroll
-        for (int c = 0; c < 3 * kRunBlock; ++c) {
-            const int f = c % 3;
-            const int v2 = s[c + 2];
-            const float f2 = (float)v2;
-            const float df1 = f1 - f2;
-            const float qq = __builtin_fmaf(df0, df0 + df1, df1 * df1);
+    for (int c = 0; c < B; ++c) v[c] = s[c];
+#pragma unroll
+    for (int c = 0; c < B; ++c) f[c] = (float)v[c];
+    f[B] = nf0;
+    f[B + 1] = nf1;
+    float d[B + 1];
+#pragma unroll
+    for (int c = 0; c <= B; ++c) d[c] = f[c] - f[c + 1];
+    const float limf = (float)lim;
+    if constexpr (MASKED) {
+#pragma unroll
+        for (int c = 0; c < B; ++c) {
+            const int fr = c % 3;
+            const float qq = __builtin_fmaf(d[c], d[c] + d[c + 1], d[c + 1] * d[c + 1]);
             const float vF = clamp01(limf - (float)c);
             const float r = min_nonneg(__builtin_amdgcn_rsqf(qq), vF);
-            P[f] = __builtin_fmaf(df0, r, P[f]);
-            Q[f] = __builtin_fmaf(df1, r, Q[f]);
-            const float u = min_nonneg(qq, vF);  // q is 0 or >= 1: exactly 1 for a counted codon
-            M[f] += u;
-            E[f] = __builtin_fmaf(vF - u, min_nonneg(f0, 1.0f), E[f]);
-            if (f == 0) {
+            a.P[fr] = __builtin_fmaf(d[c], r, a.P[fr]);
+            a.Q[fr] = __builtin_fmaf(d[c + 1], r, a.Q[fr]);
+            const float u = min_nonneg(qq, vF);
+            a.M[fr] += u;
+            a.E[fr] = __builtin_fmaf(vF - u, min_nonneg(f[c], 1.0f), a.E[fr]);
+            if (fr == 0) {
+                const unsigned codon = (unsigned)(v[c] + v[c + 1] + v[c + 2]);
                 const bool valid = c < lim;
-                const unsigned codon = (unsigned)(v0 + v1 + v2);
-                cnt += valid ? codon : 0u;
-                mn = min(mn, valid ? codon : (unsigned)RP_MIN_CODON_COV_EMPTY);
+                a.cnt += valid ? codon : 0u;
+                a.mn = min(a.mn, valid ? codon : (unsigned)RP_MIN_CODON_COV_EMPTY);
             }
-            v0 = v1;
-            v1 = v2;
-            f0 = f1;
-            f1 = f2;
-            df0 = df1;
         }
-        s += 3 * kRunBlock;
-        lim -= 3 * kRunBlock;
-        limf -= (float)(3 * kRunBlock);
+    } else {
+        // every codon start of the block counts: no validity arithmetic, and no clamp of the
+        // reciprocal root either -- q is kept off zero by a 2^-40 folded into d^2 (q >= 1 absorbs
+        // it exactly; for a == b == c it makes rsq finite, 2^20, and the products with d = 0
+        // vanish); that same root tells the flat codons apart: clamp(r - 2) is 1 for them, 0 else
+        constexpr float kDust = 0x1p-40f;
+        float sq[B + 1];
+#pragma unroll
+        for (int c = 0; c <= B; ++c) sq[c] = __builtin_fmaf(d[c], d[c], kDust);
+#pragma unroll
+        for (int c = 0; c < B; ++c) {
+            const int fr = c % 3;
+            const float qq = __builtin_fmaf(d[c + 1], f[c] - f[c + 2], sq[c]);  // d0^2 + d1 (d0 + d1)
+            const float r = __builtin_amdgcn_rsqf(qq);  // <= 1 for q >= 1, 2^20 for q == 0
+            a.P[fr] = __builtin_fmaf(d[c], r, a.P[fr]);
+            a.Q[fr] = __builtin_fmaf(d[c + 1], r, a.Q[fr]);
+            const float t = clamp01(r - 2.0f);          // 1 exactly for a flat codon (r = 2^20), else 0 (r <= 1)
+            a.T[fr] += t;
+            a.E[fr] = __builtin_fmaf(t, min_nonneg(f[c], 1.0f), a.E[fr]);
+            if (fr == 0) {
+                const unsigned codon = (unsigned)(v[c] + v[c + 1] + v[c + 2]);
+                a.cnt += codon;
+                a.mn = min(a.mn, codon);
+            }
+        }
+    }
+    nf0 = f[0];
+    nf1 = f[1];
+}
+
+__device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, LaneSums &o)
+{
+    constexpr int B = 3 * kRunBlock;
+    constexpr int kBlocks = (kRun + kRunBlock - 1) / kRunBlock;
+    RunAcc a;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) a.P[f] = a.Q[f] = a.M[f] = a.E[f] = a.T[f] = 0.f;
+    a.cnt = 0;
+    a.mn = (unsigned)RP_MIN_CODON_COV_EMPTY;
+    // last block holding a valid codon start (block 0 for an idle lane: lim == 0 masks it all)
+    const int lb = lim > 0 ? (lim - 1) / B : 0;
+    // all block addresses as constant offsets from ONE per-lane base (the lowest block a lane
+    // could reach, which may lie below its run -- never dereferenced there)
+    const int *lo = s + (lb - (kBlocks - 1)) * B;
+    float nf0 = (float)lo[kBlocks * B], nf1 = (float)lo[kBlocks * B + 1];
+    run_block<true>(lo + (kBlocks - 1) * B, lim - lb * B, nf0, nf1, a);
+#pragma unroll
+    for (int it = 1; it < kBlocks; ++it) {
+        if (lb >= it)  // lanes whose run has fewer blocks sit this one out (EXEC)
+            run_block<false>(lo + (kBlocks - 1 - it) * B, B, nf0, nf1, a);
     }
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
-        o.p[f] = P[f];
-        o.q[f] = Q[f];
+        o.p[f] = a.P[f];
+        o.q[f] = a.Q[f];
     }
-    // M_f and N_f = M_f + E_f are exact small integers (<= kRun): frames 0 and 1 are packed
-    // in float first (15 * 65536 + 15 < 2^24), so each 64-bit word costs two conversions
-    const unsigned m_lo = (unsigned)(int)__builtin_fmaf(M[1], 65536.0f, M[0]);
-    const unsigned m_hi = (unsigned)(int)M[2];
-    const unsigned n_lo = (unsigned)(int)__builtin_fmaf(M[1] + E[1], 65536.0f, M[0] + E[0]);
-    const unsigned n_hi = (unsigned)(int)(M[2] + E[2]);
+    // every codon of the lb unmasked blocks is a valid one: M = (masked block's M) + codons - T
+    const float full = (float)(lb * kRunBlock);
+#pragma unroll
+    for (int f = 0; f < 3; ++f) a.M[f] += full - a.T[f];
+    const unsigned m_lo = (unsigned)(int)__builtin_fmaf(a.M[1], 65536.0f, a.M[0]);
+    const unsigned m_hi = (unsigned)(int)a.M[2];
+    const unsigned n_lo = (unsigned)(int)__builtin_fmaf(a.M[1] + a.E[1], 65536.0f, a.M[0] + a.E[0]);
+    const unsigned n_hi = (unsigned)(int)(a.M[2] + a.E[2]);
     o.mm = ((unsigned long long)m_hi << 32) | m_lo;
     o.nn = ((unsigned long long)n_hi << 32) | n_lo;
-    o.count = cnt;
-    o.mn = mn;
+    o.count = a.cnt;
+    o.mn = a.mn;
 }
 
-__device__ __forceinline__ void store_record(const SegRecords &r, long long id, const double p[3],
+__device__ __forceinline__ void store_record(uint4 *__restrict__ rec, long long id, const double p[3],
                                              const double q[3], unsigned long long nn, unsigned long long mm,
                                              unsigned long long count, unsigned min_codon)
 {
-#pragma unroll
-    for (int f = 0; f < 3; ++f) {
-        r.pq[f * r.n_rec + id] = (SegRecords::pq_t)p[f];
-        r.pq[(3 + f) * r.n_rec + id] = (SegRecords::pq_t)q[f];
-    }
-    r.nn[id] = nn;
-    r.mm[id] = mm;
-    r.count[id] = count;
-    r.min_codon[id] = min_codon;
+    uint4 *r = rec + 3 * id;
+    r[0] = make_uint4(__float_as_uint((float)p[0]), __float_as_uint((float)p[1]), __float_as_uint((float)p[2]),
+                      __float_as_uint((float)q[0]));
+    r[1] = make_uint4(__float_as_uint((float)q[1]), __float_as_uint((float)q[2]), (unsigned)count, (unsigned)(count >> 32));
+    // 16-bit fields n0 n1 n2 m0 m1 m2: nn = n0 | n1 << 16 | n2 << 32, mm likewise
+    r[2] = make_uint4((unsigned)nn, (unsigned)(nn >> 32) | ((unsigned)mm << 16), (unsigned)(mm >> 16), min_codon);
 }
 
 constexpr int kMaxVl = kTile / (3 * kRun) + kSegChunk + 2 * kWave;  // virtual lanes per chunk (upper bound)
 
-__global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__restrict__ counts,
-                                                           const int64_t *__restrict__ offsets,
+#ifndef RP_MIN_WAVES
+#define RP_MIN_WAVES 4
+#endif
+
+// Phase stamps (-DRP_STAMPS, measurement builds only): per wave, the shader-clock time spent
+// up to each point of the kernel, summed over all workgroups into rp_dbg_stamps[wave][k].
+#ifdef RP_STAMPS
+constexpr int kStampEvery = 64, kStampSlots = 4096;
+__device__ unsigned long long rp_dbg_stamps[kStampSlots][4][8];  // plain stores by every 64th workgroup
+#define RP_STAMP_DECL unsigned long long t_stamp_[8]; int n_stamp_ = 0;
+#define RP_STAMP() do { t_stamp_[n_stamp_++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define RP_STAMP_FLUSH()                                                                        \
+    do {                                                                                        \
+        if (lane == 0 && blockIdx.x % kStampEvery == 0 && blockIdx.x / kStampEvery < kStampSlots) \
+            for (int k_ = 0; k_ < n_stamp_; ++k_) rp_dbg_stamps[blockIdx.x / kStampEvery][wave][k_] = t_stamp_[k_]; \
+    } while (0)
+#else
+#define RP_STAMP_DECL
+#define RP_STAMP() do {} while (0)
+#define RP_STAMP_FLUSH() do {} while (0)
+#endif
+__global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const int32_t *__restrict__ counts,
                                                            long long n_orfs, TilePlan plan,
                                                            TileWorkspace ws)
 {
@@ -463,29 +632,47 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
     long long t1 = t0 + kTile;
     if (t1 > plan.total_nt) t1 = plan.total_nt;
 
+    RP_STAMP_DECL
+    RP_STAMP();  // 0: entry
     // Issue the tile DMA, then everything that does not depend on it -- the tile index, the
-    // scratch clear and (wave 0) the offsets of the first 64 segment slots -- then wait once.
+    // scratch clear and (wave 0) the descriptors of the first 64 segment slots -- then wait once.
     // Slot L of a chunk holds ORF c0 + L; the first chunk starts at c0 = a0 - 1, so slot 0 is
     // the ORF that straddles in from the left, when there is one.
     load_tile_to_lds(counts, t0, plan.total_nt, s_counts, tid);
-    const long long a0 = ws.tile_first[b];
-    const long long a1 = ws.tile_first[b + 1];
-    long long beg0 = 0, end0 = 0;
+    // [a0, a1): the ORFs that start in this tile (uniform -> scalar loads, issued before the wait)
+    const long long a0 = (long long)ws.head[b * kHeadRow + 0];
+    const long long a1 = (long long)ws.head[b * kHeadRow + 1];
+    seg_desc_t d0 = 0;
+    // the serial stretches of a workgroup -- wave 0 building the segment table while the other
+    // waves wait at the barrier, and the record stage that holds the LDS tile at the end -- are
+    // run by the YOUNGEST wave on its SIMD, which loses every arbitration against the older
+    // workgroups' lane runs; lift it for those stretches only
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);
+    seg_desc_t hrow = 0;
     if (wave == 0) {
         // wave 0 owns the segment scratch until the first barrier: it alone clears it (the
         // other waves are still busy issuing DMA rows and must not clobber its marks later)
+        if (lane < kHeadRow) hrow = ws.head[b * kHeadRow + lane];  // depends on blockIdx only
         for (int k = lane; k < kMaxVl; k += kWave) s_owner[k] = 0;
         s_ints[lane].nn = 0;
         s_ints[lane].mm = 0;
         s_ints[lane].count = 0;
         s_ints[lane].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
-        const long long orf = a0 - 1 + lane;
-        if (orf >= 0 && orf < a1) {
-            beg0 = offsets[orf];
-            end0 = offsets[orf + 1];
-        }
     }
+    RP_STAMP();  // 1: DMA issued, setup loads issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is tracked by vmcnt only
+    RP_STAMP();  // 2: this wave's loads have landed
+    if (wave == 0) {
+        // slot L of the first chunk = ORF a0 - 1 + L; the head row holds slots 0 .. kHeadSlots-1
+        // at entries 2 ..: shift them down by two lanes; the (rare) further slots of the chunk
+        // come from the per-segment array
+        const int lo = __builtin_amdgcn_ds_bpermute(((lane + 2) & 63) << 2, (int)(unsigned)hrow);
+        const int hi = __builtin_amdgcn_ds_bpermute(((lane + 2) & 63) << 2, (int)(unsigned)(hrow >> 32));
+        d0 = ((seg_desc_t)(unsigned)hi << 32) | (unsigned)lo;
+        const long long orf = a0 - 1 + lane;
+        if (lane >= kHeadSlots) d0 = (orf < a1) ? ws.desc[orf + b] : 0;
+        if (orf >= a1) d0 = 0;
+    }
 
     for (long long c0 = a0 - 1; c0 < a1; c0 += kSegChunk) {
         const bool first_chunk = c0 == a0 - 1;
@@ -500,57 +687,38 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
             __syncthreads();  // previous chunk's readers are done, scratch is clear
         }
 
-        // ---- segment setup + lane allocation (wave 0; needs only offsets, not the tile) ----
+        // ---- segment table + lane allocation (wave 0; from the plan's descriptors, not the tile) ----
         if (wave == 0) {
-            int lanes = 0;
-            int live = 0;
-            const long long orf = c0 + lane;
-            if (orf >= 0 && orf < a1) {
-                const long long beg = first_chunk ? beg0 : (long long)offsets[orf];
-                const long long end = first_chunk ? end0 : (long long)offsets[orf + 1];
-                const bool head = orf < a0;  // only ORF a0 - 1 can be; it counts if it reaches the tile
-                if (!head || end > t0) {
-                    const int kt = (int)(t1 - t0);  // tile length in positions (<= kTile)
-                    int qfirst;                     // LDS index of the first triplet start >= tile start
-                    if (head) {
-                        const unsigned long long rel0 = (unsigned long long)(t0 - beg);  // > 0
-                        // 2^32 == 1 (mod 3)
-                        const unsigned m3 = ((unsigned)(rel0 >> 32) % 3u + (unsigned)(rel0 & 0xffffffffu) % 3u) % 3u;
-                        qfirst = m3 == 0 ? 0 : 3 - (int)m3;
-                    } else {
-                        qfirst = (int)(beg - t0);
-                    }
-                    const long long rem = end - t0;  // >= 0
-                    const int endq = rem <= kTile + kHalo ? (int)rem : kTile + kHalo;
-                    const int lim_q = kt < endq ? kt : endq;  // owned triplets start below this
-                    const int ntrip = lim_q > qfirst ? (lim_q - qfirst + 2) / 3 : 0;
-                    // partial last codon (L % 3 != 0): common.py:164-180 still sums it; it belongs to
-                    // the tile that holds its first position and is added by the record stage
-                    int tail = -1;
-                    if (rem <= kTile + kHalo && endq > qfirst) {
-                        const int part = (endq - qfirst) % 3;
-                        if (part != 0 && endq - part < kt) tail = (endq - part) | (part << 16);
-                    }
-                    s_tail[lane] = tail;
-                    s_qfirst[lane] = qfirst;
-                    s_endq[lane] = endq;
-                    s_ntrip[lane] = ntrip;
-                    live = 1;
-                    lanes = (ntrip + kRun - 1) / kRun;
-                }
+            seg_desc_t d = d0;
+            if (!first_chunk) {
+                const long long orf = c0 + lane;
+                d = orf < a1 ? ws.desc[orf + b] : 0;  // (orf >= 0 here: c0 >= a0 - 1 + 64)
             }
+            const int live = (int)(d >> 63);
+            const int lanes = (int)(d >> 53) & 0xff;
+            const int part = (int)(d >> 51) & 3;
+            s_qfirst[lane] = (int)d & 0x1fff;
+            s_endq[lane] = (int)(d >> 13) & 0x1fff;
+            s_ntrip[lane] = (int)(d >> 26) & 0xfff;
+            s_tail[lane] = part ? (((int)(d >> 38) & 0x1fff) | (part << 16)) : -1;
             s_live[lane] = live;
             const int incl = wave_add_scan(lanes);
             const int vs = incl - lanes;
             s_vlstart[lane] = vs;
-            if (lane == kWave - 1) s_vlstart[kSegChunk] = incl;
-            if (lanes > 0) {
+            // (descriptors of a valid index never ask for more than kMaxVl lanes per chunk; an
+            // index with overlapping profiles could, and must not run the marks out of bounds)
+            if (lane == kWave - 1) s_vlstart[kSegChunk] = incl <= kMaxVl ? incl : 0;
+            if (lanes > 0 && incl <= kMaxVl) {
                 s_owner[vs] = lane + 1;
                 // every wave-pass must find its segment at its first lane
                 for (int w = (vs >> 6) + 1; (w << 6) < incl; ++w) s_owner[w << 6] = lane + 1;
             }
         }
+        if (first_chunk) RP_STAMP();  // 3: segment table built (wave 0) / arrived at barrier 1
         __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
+        if (first_chunk) RP_STAMP();  // 4: tile + segment table ready (barrier 1)
+
         const int total_vl = s_vlstart[kSegChunk];
 
         // ---- lane runs + segmented wave reduction ---------------------------------------
@@ -577,6 +745,7 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
                 atomicAdd(&acc.count, (unsigned long long)sv.count);
                 atomicMin(&acc.min_codon, sv.mn);
             }
+
             // float sums: deterministic segmented scan inside each 16-lane row
             const int key = active ? seg + 1 : kSegChunk + 1;
             seg_scan_rows(sv, key);
@@ -591,7 +760,10 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
                 }
             }
         }
+        if (first_chunk) RP_STAMP();  // 5: this wave's lane runs done
         __syncthreads();
+        if (first_chunk) RP_STAMP();  // 6: all lane runs done (barrier 2)
+        if (wave == 0) __builtin_amdgcn_s_setprio(3);
 
         // ---- one thread per segment: row records -> one float64 segment record ---------------
         if (tid < kSegChunk && s_live[tid]) {
@@ -629,6 +801,8 @@ __global__ __launch_bounds__(kTileBlock, 4) void k_tile_score(const int32_t *__r
         }
         if (c0 + kSegChunk < a1) __syncthreads();  // the next chunk clears the scratch
     }
+    RP_STAMP();  // 7: records stored
+    RP_STAMP_FLUSH();
 }
 
 // ---------------------------------------------------------------------------
@@ -662,19 +836,23 @@ __global__ __launch_bounds__(kTileBlock) void k_orf_finish(const int32_t *__rest
         if (len > 0) {
             const long long b_first = (beg + plan.mis) / TILE;
             const long long b_last = (beg + len - 1 + plan.mis) / TILE;
-            const SegRecords &r = ws.rec;
             for (long long b = b_first; b <= b_last; ++b) {  // tile order: deterministic sums
-                const long long id = orf + b;
-                const unsigned long long nn = r.nn[id], mm = r.mm[id];
-#pragma unroll
-                for (int f = 0; f < 3; ++f) {
-                    p[f] += (double)r.pq[f * r.n_rec + id];
-                    q[f] += (double)r.pq[(3 + f) * r.n_rec + id];
-                    n[f] += (int)((nn >> (16 * f)) & 0xffffu);
-                    m[f] += (int)((mm >> (16 * f)) & 0xffffu);
-                }
-                count += (long long)r.count[id];
-                min_codon = min(min_codon, (int)r.min_codon[id]);
+                const uint4 *r = ws.rec + 3 * (orf + b);
+                const uint4 w0 = r[0], w1 = r[1], w2 = r[2];
+                p[0] += (double)__uint_as_float(w0.x);
+                p[1] += (double)__uint_as_float(w0.y);
+                p[2] += (double)__uint_as_float(w0.z);
+                q[0] += (double)__uint_as_float(w0.w);
+                q[1] += (double)__uint_as_float(w1.x);
+                q[2] += (double)__uint_as_float(w1.y);
+                count += (long long)(((unsigned long long)w1.w << 32) | w1.z);
+                n[0] += (int)(w2.x & 0xffffu);
+                n[1] += (int)(w2.x >> 16);
+                n[2] += (int)(w2.y & 0xffffu);
+                m[0] += (int)(w2.y >> 16);
+                m[1] += (int)(w2.z & 0xffffu);
+                m[2] += (int)(w2.z >> 16);
+                min_codon = min(min_codon, (int)w2.w);
             }
             if (b_last > b_first) split = RP_FLAG_SPLIT;
         }

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""A/B of libribophase builds on ONE box: every variant is timed in its own process,
+variants interleaved over several rounds (boxes and clocks drift by a few percent).
+
+    python scripts/ab_variants.py base=ribotricer_amd/csrc/libribophase.so k11=variants/k11.so \
+        --cfgs cfg2:1000000,cfg3:3000000 --rounds 3
+
+Each run checks parity against the C oracle on a 20 000-ORF sample first (a fast kernel
+with different results is not a candidate) and prints the HIP-event medians of the
+scoring and finish kernels.
+"""
+import argparse
+import json
+import os
+import statistics
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def one(cfg, n_orfs, calls):
+    sys.path.insert(0, REPO)
+    import numpy as np
+    import torch
+
+    from oracle import c_oracle
+    from ribotricer_amd.engine import PhaseScoreEngine, make_filter
+    from ribotricer_amd.synth import synth_csr_device, synth_csr_host
+
+    eng = PhaseScoreEngine("cuda:0")
+    ok = True
+    msg = ""
+    for pc, pn in (("cfg3", 20000), ("cfg5", 6000)):
+        c, o = synth_csr_host(pn, seed=77, cfg=pc)
+        ref = c_oracle.phase_score_csr(c, o, n_threads=8)
+        r = eng.score(c, o, thresholds=make_filter(), algo="tile").cpu_numpy()
+        good = (np.abs(r["phase"] - ref.phase).max() <= 1e-6 and np.array_equal(r["valid"], ref.valid)
+                and np.array_equal(r["read_count"], ref.read_count) and np.array_equal(r["min_codon_cov"], ref.min_codon_cov)
+                and np.array_equal(r["flags"] & 1, ref.flags & 1))
+        if not good:
+            ok = False
+            msg += f"{pc}: dphase={np.abs(r['phase'] - ref.phase).max():.2e} valid_diff={(r['valid'] != ref.valid).sum()} "
+    counts, offsets = synth_csr_device(n_orfs, cfg=cfg, device="cuda:0")
+    th = make_filter()
+    for _ in range(10):
+        eng.score(counts, offsets, thresholds=th, algo="tile", reuse_outputs=True)
+    torch.cuda.synchronize()
+    t = []
+    for _ in range(calls):
+        eng.score(counts, offsets, thresholds=th, algo="tile", reuse_outputs=True, timings=t)
+    # whole-step time without the per-launch events
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(calls):
+        eng.score(counts, offsets, thresholds=th, algo="tile", reuse_outputs=True)
+    e1.record()
+    torch.cuda.synchronize()
+    print(json.dumps({"ok": ok, "msg": msg, "main_ms": statistics.median(x[1] for x in t),
+                      "finish_ms": statistics.median(x[2] for x in t), "step_ms": e0.elapsed_time(e1) / calls,
+                      "nt": counts.numel(), "n": offsets.numel() - 1}))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("variants", nargs="*")
+    ap.add_argument("--cfgs", default="cfg2:1000000,cfg3:3000000")
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--calls", type=int, default=40)
+    ap.add_argument("--one", nargs=2)
+    a = ap.parse_args()
+    if a.one:
+        one(a.one[0], int(a.one[1]), a.calls)
+        return
+    variants = [v.split("=", 1) for v in a.variants]
+    cfgs = [c.split(":") for c in a.cfgs.split(",")]
+    res = {}
+    for r in range(a.rounds):
+        for name, path in variants:
+            for cfg, n in cfgs:
+                env = dict(os.environ, RIBOPHASE_LIB=os.path.abspath(path))
+                out = subprocess.run([sys.executable, __file__, "--one", cfg, n, "--calls", str(a.calls)], env=env,
+                                     capture_output=True, text=True, timeout=600)
+                line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+                if out.returncode != 0 or not line:
+                    res.setdefault((name, cfg), []).append(None)
+                    print(f"# {name} {cfg} FAILED: {out.stderr[-400:]}", flush=True)
+                    continue
+                res.setdefault((name, cfg), []).append(json.loads(line[-1]))
+    print(f"{'variant':<14} {'cfg':<6} {'parity':<7} {'main_ms (rounds)':<34} {'best':>8} {'GB/s':>7} {'frac':>6} {'finish':>8} {'step':>8}")
+    for (name, cfg), runs in res.items():
+        good = [x for x in runs if x]
+        if not good:
+            print(f"{name:<14} {cfg:<6} FAILED")
+            continue
+        mains = [x["main_ms"] for x in good]
+        best = min(mains)
+        x0 = good[0]
+        by = 4 * x0["nt"] + 8 * (x0["n"] + 1) + 24 * x0["n"]
+        gbs = by / (best * 1e-3) / 1e9
+        par = "ok" if all(x["ok"] for x in good) else "BAD"
+        print(f"{name:<14} {cfg:<6} {par:<7} {' '.join(f'{m:.4f}' for m in mains):<34} {best:8.4f} {gbs:7.0f} {gbs / 8000:6.3f} "
+              f"{min(x['finish_ms'] for x in good):8.4f} {min(x['step_ms'] for x in good):8.4f}"
+              + ("   " + good[0]["msg"] if par == "BAD" else ""), flush=True)
+
+
+if __name__ == "__main__":
+    main()
