@@ -142,7 +142,7 @@ int launch_plan_kernels(const int64_t *d_offsets, int64_t n_orfs, const rp::Tile
         RP_HIP(hipGetLastError());
     }
     {
-        const int grid = (int)((plan.n_tiles + block - 1) / block);
+        const int grid = (int)((plan.n_tiles * 64 + block - 1) / block);
         hipLaunchKernelGGL(rp::k_tile_head, dim3(grid), dim3(block), 0, stream, plan.n_tiles, ws.tile_first, ws.head);
         RP_HIP(hipGetLastError());
     }

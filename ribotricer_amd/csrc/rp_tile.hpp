@@ -43,6 +43,10 @@
 namespace rp {
 
 constexpr int kTileBlock = 256;
+#ifndef RP_LOADERS
+#define RP_LOADERS 1
+#endif
+constexpr int kLoaders = RP_LOADERS;  // waves (the last ones of the workgroup) that issue the tile DMA
 #ifndef RP_TILE
 #define RP_TILE 7936
 #endif
@@ -66,12 +70,12 @@ struct TilePlan {
 
 // One record per (ORF, tile) segment: the sums over the triplets of the ORF that the tile
 // owns.  Indexed by  orf + tile : an ORF spanning tiles s..e owns the ids orf+s .. orf+e, and
-// the next ORF starts in a tile >= e, so ids never collide.  48 bytes, array of structures:
-// the writer (one thread per segment) and the reader (one thread per ORF) each move a record
-// as three 16-byte words, and neighbouring threads hold neighbouring ids.
-//   word 0  p[0] p[1] p[2] q[0]          fp32: the float64 sum of <= 11 fp32 row records, rounded once
-//   word 1  q[1] q[2] count.lo count.hi
-//   word 2  n0|n1<<16  n2|m0<<16  m1|m2<<16  min_codon     (a tile owns < 2^16 triplets)
+// the next ORF starts in a tile >= e, so ids never collide.  48 bytes as three 16-byte words
+// in three planes (rec[k * n_rec + id]): writers (a wave per plane, a thread per segment) and
+// readers (a thread per ORF) then touch consecutive words with consecutive threads.
+//   plane 0  p[0] p[1] p[2] q[0]          fp32: the float64 sum of <= 11 fp32 row records, rounded once
+//   plane 1  q[1] q[2] count.lo count.hi
+//   plane 2  n0|n1<<16  n2|m0<<16  m1|m2<<16  min_codon     (a tile owns < 2^16 triplets)
 constexpr size_t kRecordBytes = 48;
 
 // One descriptor per segment id, derived from the offsets alone (k_tile_desc): where the
@@ -87,12 +91,16 @@ typedef unsigned long long seg_desc_t;
 static_assert(kTile + kHalo < 8192 && kTile / 3 < 4096 && (kTile / 3 + kRun - 1) / kRun < 256, "descriptor field widths");
 
 // The first kHeadSlots segment slots of every tile are ALSO kept tile-major, behind the tile's
-// own [a0, a1) ORF range: row b = { a0, a1, desc(slot 0), ..., desc(slot kHeadSlots-1) }.  A
-// workgroup reads its row with one load that depends on nothing but blockIdx, so the segment
-// table is ready before the tile data has landed; only tiles with more segments than that
-// (short-ORF batches) also take the dependent path through tile_first and desc.
-constexpr int kHeadRow = 48;                  // 8-byte entries per row (384 B per 31 KiB tile)
-constexpr int kHeadSlots = kHeadRow - 2;
+// own [a0, a1) ORF range, and followed by the tile's lane map:
+//   row b = { a0, a1, desc(slot 0) ... desc(slot kHeadSlots-1), vlmap[256 bytes] }
+// vlmap[v] = the slot whose segment virtual lane v walks (0xff: none).  A workgroup reads its
+// row with loads that depend on nothing but blockIdx, so every wave knows which triplets its
+// lanes walk before the tile data has landed; only tiles with more segments than kHeadSlots
+// (short-ORF batches) take the dependent path through the per-segment array and a table in LDS.
+constexpr int kHeadSlots = 46;
+constexpr int kHeadMapAt = 2 + kHeadSlots;    // 8-byte index where the lane map starts
+constexpr int kHeadRow = kHeadMapAt + 256 / 8;  // 8-byte entries per row (640 B per 31 KiB tile)
+static_assert(kTile / (3 * kRun) + kHeadSlots + 1 <= 256, "a head-row tile must fit one pass per wave");
 
 struct TileWorkspace {
     long long *tile_first;  // [n_tiles + 1] first ORF starting at/after each tile start
@@ -246,13 +254,31 @@ __global__ void k_tile_desc(const int64_t *__restrict__ offsets, long long n_orf
     }
 }
 
-// the [a0, a1) header of every head row (one thread per tile; after k_tile_index)
+// the [a0, a1) header and the lane map of every head row (64 threads per tile, one per four
+// virtual lanes; after k_tile_desc)
 __global__ void k_tile_head(long long n_tiles, const long long *__restrict__ tile_first, seg_desc_t *__restrict__ head)
 {
-    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long b = t >> 6;
+    const int j = (int)(t & 63);
     if (b >= n_tiles) return;
-    head[b * kHeadRow + 0] = (seg_desc_t)tile_first[b];
-    head[b * kHeadRow + 1] = (seg_desc_t)tile_first[b + 1];
+    seg_desc_t *row = head + b * kHeadRow;
+    if (j == 0) {
+        row[0] = (seg_desc_t)tile_first[b];
+        row[1] = (seg_desc_t)tile_first[b + 1];
+    }
+    unsigned out = 0xffffffffu;
+    int vs = 0;
+    for (int slot = 0; slot < kHeadSlots; ++slot) {
+        const int ve = vs + ((int)(row[2 + slot] >> 53) & 0xff);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = 4 * j + k;
+            if (v >= vs && v < ve) out = (out & ~(0xffu << (8 * k))) | ((unsigned)slot << (8 * k));
+        }
+        vs = ve;
+    }
+    reinterpret_cast<unsigned *>(row + kHeadMapAt)[j] = out;
 }
 
 // ---------------------------------------------------------------------------
@@ -277,8 +303,8 @@ struct SegInts {
 // Interior tiles use the LDS-DMA form of global_load (no VGPR round trip, one instruction
 // per KiB row, rows dealt round-robin to the four waves); the first / last tile take the
 // guarded path with zero fill.  The DMA is NOT waited for here.
-__device__ __forceinline__ void load_tile_to_lds(const int32_t *__restrict__ counts, long long t0,
-                                                 long long total_nt, int *s_counts, int tid)
+__device__ __forceinline__ int load_tile_to_lds(const int32_t *__restrict__ counts, long long t0,
+                                                long long total_nt, int *s_counts, int tid)
 {
     constexpr int n_chunks = (kTile + kHalo) / 4;  // 16-byte chunks
     constexpr int kRowPos = 256;                    // positions per DMA row (64 lanes x 16 B)
@@ -290,14 +316,16 @@ __device__ __forceinline__ void load_tile_to_lds(const int32_t *__restrict__ cou
         typedef __attribute__((address_space(3))) void *lptr_t;
         const int lane = tid & (kWave - 1);
         const int32_t *src = counts + t0 + 4 * lane;
-        // rows dealt round-robin to waves 1-3: issuing stalls a wave until the memory pipe has
-        // taken its requests, and wave 0 builds the segment table meanwhile.  The wave index is
-        // made scalar so that the row loop is straight-line code (row = w, w+3, ...; M0 and the
-        // global offset are SALU arithmetic) instead of one exec-mask branch per row.
-        constexpr int kIssuers = kTileBlock / kWave - 1;
+        // rows dealt round-robin to the LAST kLoaders waves.  A wave with LDS-DMA in flight cannot
+        // wait for anything else it has loaded short of vmcnt(0) (measured on gfx950: LDS-DMA and
+        // ordinary loads retire out of order with respect to each other, so a counted vmcnt(N)
+        // does not cover an older ordinary load), so the waves that walk the first passes issue
+        // none and get their plan rows early.  The wave index is made scalar so that the row loop
+        // is straight-line code (M0 and the global offset are SALU arithmetic).
+        constexpr int kIssuers = kLoaders;
         constexpr int kRows = kTile / kRowPos;
         constexpr int kEven = kRows / kIssuers;  // rows every issuing wave takes
-        const int w = __builtin_amdgcn_readfirstlane(tid >> 6) - 1;
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6) - (kTileBlock / kWave - kIssuers);
         if (w >= 0) {
 #pragma unroll
             for (int k = 0; k < kEven; ++k) {
@@ -312,7 +340,9 @@ __device__ __forceinline__ void load_tile_to_lds(const int32_t *__restrict__ cou
                 __builtin_amdgcn_global_load_lds((gptr_t)(src + kTile), (lptr_t)(s_counts + kTile), 16, 0, 0);
         }
         // NOTE: no wait here -- the caller waits (vmcnt only tracks the DMA) after it has
-        // issued its own independent loads
+        // issued its own independent loads.  Returned: how many loads this wave put in flight.
+        if (w < 0) return 0;
+        return kEven + (w < kRows - kEven * kIssuers ? 1 : 0) + (w == kIssuers - 1 ? 1 : 0);
     } else {
 #pragma unroll 1
         for (int c = tid; c < n_chunks; c += kTileBlock) {
@@ -324,6 +354,7 @@ __device__ __forceinline__ void load_tile_to_lds(const int32_t *__restrict__ cou
             if (pos + 3 >= 0 && pos + 3 < total_nt) v.w = counts[pos + 3];
             *reinterpret_cast<int4 *>(s_counts + 4 * c) = v;
         }
+        return 0;  // (the caller then waits for everything)
     }
 }
 
@@ -574,18 +605,6 @@ __device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, Lan
     o.mn = a.mn;
 }
 
-__device__ __forceinline__ void store_record(uint4 *__restrict__ rec, long long id, const double p[3],
-                                             const double q[3], unsigned long long nn, unsigned long long mm,
-                                             unsigned long long count, unsigned min_codon)
-{
-    uint4 *r = rec + 3 * id;
-    r[0] = make_uint4(__float_as_uint((float)p[0]), __float_as_uint((float)p[1]), __float_as_uint((float)p[2]),
-                      __float_as_uint((float)q[0]));
-    r[1] = make_uint4(__float_as_uint((float)q[1]), __float_as_uint((float)q[2]), (unsigned)count, (unsigned)(count >> 32));
-    // 16-bit fields n0 n1 n2 m0 m1 m2: nn = n0 | n1 << 16 | n2 << 32, mm likewise
-    r[2] = make_uint4((unsigned)nn, (unsigned)(nn >> 32) | ((unsigned)mm << 16), (unsigned)(mm >> 16), min_codon);
-}
-
 constexpr int kMaxVl = kTile / (3 * kRun) + kSegChunk + 2 * kWave;  // virtual lanes per chunk (upper bound)
 
 #ifndef RP_MIN_WAVES
@@ -609,6 +628,92 @@ __device__ unsigned long long rp_dbg_stamps[kStampSlots][4][8];  // plain stores
 #define RP_STAMP() do {} while (0)
 #define RP_STAMP_FLUSH() do {} while (0)
 #endif
+// One pass of a wave: every lane walks its run, then the per-segment reduction.
+__device__ __forceinline__ void tile_pass(const int *__restrict__ s_counts, SegInts *__restrict__ s_ints,
+                                          RunRec *__restrict__ s_rec, int q0, int lim, bool active, int seg, int vl)
+{
+    LaneSums sv;
+    lane_run(s_counts + q0, lim, sv);
+
+    // integer sums: exact and order independent -> LDS atomics straight per segment
+    if (active) {
+        SegInts &acc = s_ints[seg];
+        atomicAdd(&acc.nn, sv.nn);  // three 16-bit fields per word: no carry between them
+        atomicAdd(&acc.mm, sv.mm);
+        atomicAdd(&acc.count, (unsigned long long)sv.count);
+        atomicMin(&acc.min_codon, sv.mn);
+    }
+
+    // float sums: deterministic segmented scan inside each 16-lane row
+    const int key = active ? seg + 1 : kSegChunk + 1;
+    seg_scan_rows(sv, key);
+    const int key_next = dpp_fetch<0x101 /* row_shl:1 */, 0xf>(0, key);  // 0 at the row's last lane
+    const bool run_end = active && (key_next != key);
+    if (run_end) {
+        RunRec &rec = s_rec[seg + (vl >> 4)];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            rec.p[f] = sv.p[f];
+            rec.q[f] = sv.q[f];
+        }
+    }
+}
+
+// Record stage: row records + integer sums -> ONE record per live segment.  The three words
+// of a record live in three planes (rec[k * n_rec + id]); wave k < 3 writes plane k for all
+// 64 slots (thread = slot), so the three short dependency chains run side by side on three
+// SIMDs and every store instruction covers consecutive 16-byte words.
+__device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, const SegInts *__restrict__ s_ints,
+                                             const RunRec *__restrict__ s_rec, const int *__restrict__ s_vlstart,
+                                             const int *__restrict__ s_tail, const int *__restrict__ s_live,
+                                             uint4 *__restrict__ rec, long long n_rec, long long id0, int wave, int seg)
+{
+    if (wave >= 3 || !s_live[seg]) return;
+    const int vs = s_vlstart[seg];
+    const int ve = s_vlstart[seg + 1];
+    const int w_first = vs >> 4;
+    const int w_last = ve > vs ? (ve - 1) >> 4 : w_first - 1;
+    const int tail = s_tail[seg];
+    unsigned codon = 0;
+    if (tail >= 0 && wave > 0) {
+        codon = (unsigned)s_counts[tail & 0xffff];
+        if ((tail >> 16) == 2) codon += (unsigned)s_counts[(tail & 0xffff) + 1];
+    }
+    uint4 out;
+    if (wave == 0) {  // p[0] p[1] p[2] q[0]
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int w = w_first; w <= w_last; ++w) {
+            const RunRec &r = s_rec[seg + w];
+            a0 += (double)r.p[0];
+            a1 += (double)r.p[1];
+            a2 += (double)r.p[2];
+            a3 += (double)r.q[0];
+        }
+        out = make_uint4(__float_as_uint((float)a0), __float_as_uint((float)a1), __float_as_uint((float)a2), __float_as_uint((float)a3));
+    } else if (wave == 1) {  // q[1] q[2] count
+        double a0 = 0.0, a1 = 0.0;
+        for (int w = w_first; w <= w_last; ++w) {
+            const RunRec &r = s_rec[seg + w];
+            a0 += (double)r.q[1];
+            a1 += (double)r.q[2];
+        }
+        unsigned long long count = ve > vs ? s_ints[seg].count : 0ull;
+        if (tail >= 0) count += codon;
+        out = make_uint4(__float_as_uint((float)a0), __float_as_uint((float)a1), (unsigned)count, (unsigned)(count >> 32));
+    } else {  // n0 n1 n2 m0 m1 m2 (16-bit fields: nn = n0 | n1 << 16 | n2 << 32, mm likewise), min
+        unsigned long long nn = 0, mm = 0;
+        unsigned min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
+        if (ve > vs) {
+            nn = s_ints[seg].nn;
+            mm = s_ints[seg].mm;
+            min_codon = s_ints[seg].min_codon;
+        }
+        if (tail >= 0) min_codon = min(min_codon, codon);
+        out = make_uint4((unsigned)nn, (unsigned)(nn >> 32) | ((unsigned)mm << 16), (unsigned)(mm >> 16), min_codon);
+    }
+    rec[wave * n_rec + id0 + seg] = out;
+}
+
 __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const int32_t *__restrict__ counts,
                                                            long long n_orfs, TilePlan plan,
                                                            TileWorkspace ws)
@@ -629,79 +734,115 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
     const int wave = tid >> 6;
     const long long b = blockIdx.x;
     const long long t0 = b * (long long)kTile - plan.mis;  // position of LDS index 0 (may be < 0 for b == 0)
-    long long t1 = t0 + kTile;
-    if (t1 > plan.total_nt) t1 = plan.total_nt;
 
     RP_STAMP_DECL
     RP_STAMP();  // 0: entry
-    // Issue the tile DMA, then everything that does not depend on it -- the tile index, the
-    // scratch clear and (wave 0) the descriptors of the first 64 segment slots -- then wait once.
-    // Slot L of a chunk holds ORF c0 + L; the first chunk starts at c0 = a0 - 1, so slot 0 is
-    // the ORF that straddles in from the left, when there is one.
-    load_tile_to_lds(counts, t0, plan.total_nt, s_counts, tid);
-    // [a0, a1): the ORFs that start in this tile (uniform -> scalar loads, issued before the wait)
+    // The tile's head row first -- its [a0, a1) ORF range through the scalar unit, its segment
+    // descriptors one per lane, in EVERY wave -- then the tile DMA behind it.  Slot L of the
+    // tile holds ORF a0 - 1 + L: slot 0 is the ORF that straddles in from the left, if any.
     const long long a0 = (long long)ws.head[b * kHeadRow + 0];
     const long long a1 = (long long)ws.head[b * kHeadRow + 1];
-    seg_desc_t d0 = 0;
-    // the serial stretches of a workgroup -- wave 0 building the segment table while the other
-    // waves wait at the barrier, and the record stage that holds the LDS tile at the end -- are
-    // run by the YOUNGEST wave on its SIMD, which loses every arbitration against the older
-    // workgroups' lane runs; lift it for those stretches only
-    if (wave == 0) __builtin_amdgcn_s_setprio(3);
-    seg_desc_t hrow = 0;
-    if (wave == 0) {
-        // wave 0 owns the segment scratch until the first barrier: it alone clears it (the
-        // other waves are still busy issuing DMA rows and must not clobber its marks later)
-        if (lane < kHeadRow) hrow = ws.head[b * kHeadRow + lane];  // depends on blockIdx only
-        for (int k = lane; k < kMaxVl; k += kWave) s_owner[k] = 0;
+    seg_desc_t d;
+    unsigned vmap;
+    {   // both depend on blockIdx only; lanes past the row's descriptors re-read its first word
+        const seg_desc_t *row = ws.head + b * kHeadRow;
+        const seg_desc_t *src = row + (lane < kHeadSlots ? 2 + lane : 0);
+        const unsigned char *msrc = reinterpret_cast<const unsigned char *>(row + kHeadMapAt) + tid;
+        asm volatile("global_load_dwordx2 %0, %2, off\n\tglobal_load_ubyte %1, %3, off"
+                     : "=&v"(d), "=&v"(vmap)
+                     : "v"(src), "v"(msrc)
+                     : "memory");
+    }
+    load_tile_to_lds(counts, t0, plan.total_nt, s_counts, tid);
+    if (wave == 0) {  // the integer accumulators of the 64 slots (before anyone's atomics: barrier 1)
         s_ints[lane].nn = 0;
         s_ints[lane].mm = 0;
         s_ints[lane].count = 0;
         s_ints[lane].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
     }
-    RP_STAMP();  // 1: DMA issued, setup loads issued
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is tracked by vmcnt only
-    RP_STAMP();  // 2: this wave's loads have landed
-    if (wave == 0) {
-        // slot L of the first chunk = ORF a0 - 1 + L; the head row holds slots 0 .. kHeadSlots-1
-        // at entries 2 ..: shift them down by two lanes; the (rare) further slots of the chunk
-        // come from the per-segment array
-        const int lo = __builtin_amdgcn_ds_bpermute(((lane + 2) & 63) << 2, (int)(unsigned)hrow);
-        const int hi = __builtin_amdgcn_ds_bpermute(((lane + 2) & 63) << 2, (int)(unsigned)(hrow >> 32));
-        d0 = ((seg_desc_t)(unsigned)hi << 32) | (unsigned)lo;
-        const long long orf = a0 - 1 + lane;
-        if (lane >= kHeadSlots) d0 = (orf < a1) ? ws.desc[orf + b] : 0;
-        if (orf >= a1) d0 = 0;
+    RP_STAMP();  // 1: loads issued
+
+    if (a1 - a0 + 1 <= kHeadSlots) {
+        // ---- the common case: all segments of the tile sit in the head row ---------------------
+        // Every wave works out what ITS 64 virtual lanes walk by itself, in registers (the plan's
+        // lane map names the segment, a wave-wide scan + three lane fetches give the run), while
+        // the tile is still streaming in: no table in LDS to wait for, nothing serial in front of
+        // barrier 1 but the DMA.  (<= kHeadSlots segments need < 256 virtual lanes: one pass per wave.)
+        // the two row loads came through inline asm (hipcc's own counter bookkeeping would put a
+        // vmcnt(0) in front of every LDS access of the DMA-issuing waves' code path, i.e. of all
+        // waves); tying their registers to the wait keeps every use behind it.  Waves without DMA
+        // in flight get their rows as soon as they arrive; the loader waves wait for the tile too.
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(d), "+v"(vmap) : : "memory");
+        if (lane >= kHeadSlots) d = 0;
+        RP_STAMP();  // 2: descriptors here
+        const int lanes_i = (int)(d >> 53) & 0xff;
+        const int incl = wave_add_scan(lanes_i);
+        const int vs_i = incl - lanes_i;
+        const int total_vl = __builtin_amdgcn_readlane(incl, kWave - 1);
+        const int vbase = wave * kWave;
+        const int vl = vbase + lane;
+        const bool pass = vbase < total_vl;  // wave-uniform
+        const bool active = vmap != 0xffu;    // == vl < total_vl
+        const int seg = active ? (int)vmap : 0;
+        int q0 = 0, lim = 0;
+        if (pass) {
+            // the segment's fields, from the lane that holds its descriptor
+            const unsigned dlo = (unsigned)__builtin_amdgcn_ds_bpermute(seg << 2, (int)(unsigned)d);
+            const unsigned dhi = (unsigned)__builtin_amdgcn_ds_bpermute(seg << 2, (int)(unsigned)(d >> 32));
+            const int vs_s = __builtin_amdgcn_ds_bpermute(seg << 2, vs_i);
+            const seg_desc_t ds = ((seg_desc_t)dhi << 32) | dlo;
+            const int r = vl - vs_s;
+            int n_run = ((int)(ds >> 26) & 0xfff) - r * kRun;
+            n_run = n_run > kRun ? kRun : n_run;
+            q0 = active ? ((int)ds & 0x1fff) + 3 * kRun * r : 0;
+            const int rem0 = ((int)(ds >> 13) & 0x1fff) - q0;  // positions of the ORF from q0 on (clamped far end)
+            lim = rem0 - 2 < 3 * n_run ? rem0 - 2 : 3 * n_run;
+            if (!active) lim = 0;
+        }
+        if (wave == 0) {  // what the record stage needs, per slot
+            const int part = (int)(d >> 51) & 3;
+            s_vlstart[lane] = vs_i;
+            if (lane == kWave - 1) s_vlstart[kSegChunk] = incl;
+            s_tail[lane] = part ? (((int)(d >> 38) & 0x1fff) | (part << 16)) : -1;
+            s_live[lane] = (int)(d >> 63);
+        }
+        RP_STAMP();  // 3: mapped, arrived at barrier 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is tracked by vmcnt only
+        __syncthreads();
+        RP_STAMP();  // 4: tile landed (barrier 1)
+        if (pass) tile_pass(s_counts, s_ints, s_rec, q0, lim, active, seg, vl);
+        RP_STAMP();  // 5: this wave's lane runs done
+        __syncthreads();
+        RP_STAMP();  // 6: all lane runs done (barrier 2)
+        record_stage(s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, ws.rec, ws.n_rec, a0 - 1 + b, wave, lane);
+        RP_STAMP();  // 7: records stored
+        RP_STAMP_FLUSH();
+        return;
     }
 
+    // ---- many short ORFs: > kHeadSlots segments, in chunks of 64 through a table in LDS --------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (long long c0 = a0 - 1; c0 < a1; c0 += kSegChunk) {
-        const bool first_chunk = c0 == a0 - 1;
-        if (!first_chunk) {  // (the first chunk's scratch was cleared while the tile streamed in)
-            for (int k = tid; k < kMaxVl; k += kTileBlock) s_owner[k] = 0;
-            if (tid < kSegChunk) {
-                s_ints[tid].nn = 0;
-                s_ints[tid].mm = 0;
-                s_ints[tid].count = 0;
-                s_ints[tid].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
-            }
-            __syncthreads();  // previous chunk's readers are done, scratch is clear
+        for (int k = tid; k < kMaxVl; k += kTileBlock) s_owner[k] = 0;
+        if (c0 != a0 - 1 && tid < kSegChunk) {
+            s_ints[tid].nn = 0;
+            s_ints[tid].mm = 0;
+            s_ints[tid].count = 0;
+            s_ints[tid].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
         }
+        __syncthreads();  // previous chunk's readers are done, scratch is clear
 
-        // ---- segment table + lane allocation (wave 0; from the plan's descriptors, not the tile) ----
+        // segment table + lane allocation (wave 0; from the plan's descriptors, not the tile)
         if (wave == 0) {
-            seg_desc_t d = d0;
-            if (!first_chunk) {
-                const long long orf = c0 + lane;
-                d = orf < a1 ? ws.desc[orf + b] : 0;  // (orf >= 0 here: c0 >= a0 - 1 + 64)
-            }
-            const int live = (int)(d >> 63);
-            const int lanes = (int)(d >> 53) & 0xff;
-            const int part = (int)(d >> 51) & 3;
-            s_qfirst[lane] = (int)d & 0x1fff;
-            s_endq[lane] = (int)(d >> 13) & 0x1fff;
-            s_ntrip[lane] = (int)(d >> 26) & 0xfff;
-            s_tail[lane] = part ? (((int)(d >> 38) & 0x1fff) | (part << 16)) : -1;
-            s_live[lane] = live;
+            const long long orf = c0 + lane;
+            const seg_desc_t dc = (orf >= 0 && orf < a1) ? ws.desc[orf + b] : 0;
+            const int lanes = (int)(dc >> 53) & 0xff;
+            const int part = (int)(dc >> 51) & 3;
+            s_qfirst[lane] = (int)dc & 0x1fff;
+            s_endq[lane] = (int)(dc >> 13) & 0x1fff;
+            s_ntrip[lane] = (int)(dc >> 26) & 0xfff;
+            s_tail[lane] = part ? (((int)(dc >> 38) & 0x1fff) | (part << 16)) : -1;
+            s_live[lane] = (int)(dc >> 63);
             const int incl = wave_add_scan(lanes);
             const int vs = incl - lanes;
             s_vlstart[lane] = vs;
@@ -714,14 +855,8 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
                 for (int w = (vs >> 6) + 1; (w << 6) < incl; ++w) s_owner[w << 6] = lane + 1;
             }
         }
-        if (first_chunk) RP_STAMP();  // 3: segment table built (wave 0) / arrived at barrier 1
         __syncthreads();
-        __builtin_amdgcn_s_setprio(0);
-        if (first_chunk) RP_STAMP();  // 4: tile + segment table ready (barrier 1)
-
         const int total_vl = s_vlstart[kSegChunk];
-
-        // ---- lane runs + segmented wave reduction ---------------------------------------
         for (int vbase = wave * kWave; vbase < total_vl; vbase += kTileBlock) {
             const int vl = vbase + lane;
             const bool active = vl < total_vl;
@@ -733,76 +868,13 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
             const int rem0 = s_endq[seg] - q0;  // positions of the ORF from q0 on (clamped far end)
             int lim = rem0 - 2 < 3 * n_run ? rem0 - 2 : 3 * n_run;
             if (!active) lim = 0;
-
-            LaneSums sv;
-            lane_run(s_counts + q0, lim, sv);
-
-            // integer sums: exact and order independent -> LDS atomics straight per segment
-            if (active) {
-                SegInts &acc = s_ints[seg];
-                atomicAdd(&acc.nn, sv.nn);  // three 16-bit fields per word: no carry between them
-                atomicAdd(&acc.mm, sv.mm);
-                atomicAdd(&acc.count, (unsigned long long)sv.count);
-                atomicMin(&acc.min_codon, sv.mn);
-            }
-
-            // float sums: deterministic segmented scan inside each 16-lane row
-            const int key = active ? seg + 1 : kSegChunk + 1;
-            seg_scan_rows(sv, key);
-            const int key_next = dpp_fetch<0x101 /* row_shl:1 */, 0xf>(0, key);  // 0 at the row's last lane
-            const bool run_end = active && (key_next != key);
-            if (run_end) {
-                RunRec &rec = s_rec[seg + (vl >> 4)];
-#pragma unroll
-                for (int f = 0; f < 3; ++f) {
-                    rec.p[f] = sv.p[f];
-                    rec.q[f] = sv.q[f];
-                }
-            }
+            tile_pass(s_counts, s_ints, s_rec, q0, lim, active, seg, vl);
         }
-        if (first_chunk) RP_STAMP();  // 5: this wave's lane runs done
         __syncthreads();
-        if (first_chunk) RP_STAMP();  // 6: all lane runs done (barrier 2)
-        if (wave == 0) __builtin_amdgcn_s_setprio(3);
-
-        // ---- one thread per segment: row records -> one float64 segment record ---------------
-        if (tid < kSegChunk && s_live[tid]) {
-            const int seg = tid;
-            const int vs = s_vlstart[seg];
-            const int ve = s_vlstart[seg + 1];
-            double p[3] = {0.0, 0.0, 0.0}, q[3] = {0.0, 0.0, 0.0};
-            unsigned long long nn = 0, mm = 0, count = 0;
-            unsigned min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
-            if (ve > vs) {
-                const int w_first = vs >> 4;
-                const int w_last = (ve - 1) >> 4;
-                for (int w = w_first; w <= w_last; ++w) {
-                    const RunRec &rec = s_rec[seg + w];
-#pragma unroll
-                    for (int f = 0; f < 3; ++f) {
-                        p[f] += (double)rec.p[f];
-                        q[f] += (double)rec.q[f];
-                    }
-                }
-                const SegInts &acc = s_ints[seg];
-                nn = acc.nn;
-                mm = acc.mm;
-                count = acc.count;
-                min_codon = acc.min_codon;
-            }
-            const int tail = s_tail[seg];
-            if (tail >= 0) {
-                unsigned codon = (unsigned)s_counts[tail & 0xffff];
-                if ((tail >> 16) == 2) codon += (unsigned)s_counts[(tail & 0xffff) + 1];
-                count += codon;
-                min_codon = min(min_codon, codon);
-            }
-            store_record(ws.rec, c0 + seg + b, p, q, nn, mm, count, min_codon);
-        }
-        if (c0 + kSegChunk < a1) __syncthreads();  // the next chunk clears the scratch
+        record_stage(s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, ws.rec, ws.n_rec, c0 + b, wave, lane);
+        // (the next chunk's clear of the scratch waits at its own barrier)
+        __syncthreads();
     }
-    RP_STAMP();  // 7: records stored
-    RP_STAMP_FLUSH();
 }
 
 // ---------------------------------------------------------------------------
@@ -837,8 +909,7 @@ __global__ __launch_bounds__(kTileBlock) void k_orf_finish(const int32_t *__rest
             const long long b_first = (beg + plan.mis) / TILE;
             const long long b_last = (beg + len - 1 + plan.mis) / TILE;
             for (long long b = b_first; b <= b_last; ++b) {  // tile order: deterministic sums
-                const uint4 *r = ws.rec + 3 * (orf + b);
-                const uint4 w0 = r[0], w1 = r[1], w2 = r[2];
+                const uint4 w0 = ws.rec[orf + b], w1 = ws.rec[ws.n_rec + orf + b], w2 = ws.rec[2 * ws.n_rec + orf + b];
                 p[0] += (double)__uint_as_float(w0.x);
                 p[1] += (double)__uint_as_float(w0.y);
                 p[2] += (double)__uint_as_float(w0.z);
