@@ -60,12 +60,14 @@ typedef enum rp_status {
 } rp_status;
 
 /* bits of the per-ORF flags byte */
-#define RP_FLAG_TIE 0x01u      /* two candidate frames score within RP_TIE_RTOL with different N
-                                  (the reference's pick is decided by scipy rounding noise,
-                                  SURVEY.md Appendix A.4); valid_codons follows the exact-
-                                  arithmetic rule: the earlier frame wins */
+#define RP_FLAG_TIE 0x01u      /* two candidate frames score within RP_TIE_RTOL with different N: the
+                                  reference's pick is decided by the last bits of what numpy / scipy
+                                  computed.  Such ORFs are re-scored by a
+                                  replay of exactly that arithmetic (RP_FLAG_REPLAY) */
 #define RP_FLAG_RECHECK64 0x02u /* frame decision was re-derived in float64 on device */
 #define RP_FLAG_SPLIT 0x04u    /* profile spanned more than one tile (several segment records) */
+#define RP_FLAG_REPLAY 0x08u   /* phase / valid_codons of this tie-flagged ORF come from the on-device
+                                  replay of the reference's own float64 (numpy / scipy) arithmetic */
 
 #define RP_TIE_RTOL 1e-9
 

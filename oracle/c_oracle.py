@@ -32,12 +32,12 @@ class OracleResult(NamedTuple):
 
 def build(force: bool = False) -> None:
     """Compile the C restatement with gcc (a few hundred ms)."""
-    src = os.path.join(_HERE, "phase_oracle.c")
+    srcs = [os.path.join(_HERE, "phase_oracle.c"), os.path.join(_HERE, "scipy_replay.c")]
     lib = os.path.join(_BUILD, "libphase_oracle.so")
     if (
         not force
         and os.path.exists(lib)
-        and os.path.getmtime(lib) >= os.path.getmtime(src)
+        and os.path.getmtime(lib) >= max(os.path.getmtime(s) for s in srcs)
         and os.path.exists(os.path.join(_BUILD, "libphase_oracle_omp.so"))
     ):
         return
@@ -59,6 +59,8 @@ def _load(openmp: bool) -> ctypes.CDLL:
     p = ctypes.c_void_p
     lib.rp_oracle_phase_score_csr.restype = ctypes.c_int
     lib.rp_oracle_phase_score_csr.argtypes = [p, p, ctypes.c_int64, p, p, p, p, p, p, p, p, ctypes.c_int]
+    lib.rp_oracle_replay_csr.restype = ctypes.c_int
+    lib.rp_oracle_replay_csr.argtypes = [p, p, ctypes.c_int64, p, p, p, p]
     lib.rp_oracle_phase_score_f64.restype = ctypes.c_int
     lib.rp_oracle_phase_score_f64.argtypes = [p, ctypes.c_int64, p, p, p, p, p, p]
     _libs[key] = lib
@@ -110,3 +112,23 @@ def phasescore_f64(values):
     if rc != 0:
         raise ValueError(f"rp_oracle_phase_score_f64 failed with code {rc}")
     return float(phase[0]), int(valid[0]), int(flags[0]), fs, fn, fm
+
+
+class ReplayResult(NamedTuple):
+    phase: np.ndarray  # float64 [n]  the reference's own bits (np.sqrt of the winning Cxy)
+    valid: np.ndarray  # int32 [n]
+    frame_score: np.ndarray  # float64 [n,3]  Cxy[f=1/3] per frame (NaN for an empty frame)
+    frame_n: np.ndarray  # int32 [n,3]
+
+
+def replay_csr(counts, offsets) -> ReplayResult:
+    """Bit-for-bit replay of the reference's numpy/scipy arithmetic (oracle/scipy_replay.c)."""
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = offsets.size - 1
+    res = ReplayResult(np.empty(n, np.float64), np.empty(n, np.int32), np.empty((n, 3), np.float64), np.empty((n, 3), np.int32))
+    rc = _load(False).rp_oracle_replay_csr(_ptr(counts), _ptr(offsets), n, _ptr(res.phase), _ptr(res.valid),
+                                           _ptr(res.frame_score), _ptr(res.frame_n))
+    if rc != 0:
+        raise ValueError(f"rp_oracle_replay_csr failed with status {rc}")
+    return res

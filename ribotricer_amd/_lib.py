@@ -22,6 +22,7 @@ ALGOS = {"auto": RP_ALGO_AUTO, "wave": RP_ALGO_WAVE, "tile": RP_ALGO_TILE}
 FLAG_TIE = 0x01
 FLAG_RECHECK64 = 0x02
 FLAG_SPLIT = 0x04
+FLAG_REPLAY = 0x08
 MIN_CODON_COV_EMPTY = 2147483647
 MAX_COUNT = 16777215
 

@@ -8,7 +8,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 #include <cstdlib>
+#include <mutex>
 
 #include "../../include/ribophase.h"
 #include "rp_device.hpp"
@@ -89,6 +91,57 @@ struct DeviceGuard {
 #define RP_ON_DEVICE(device)       \
     DeviceGuard guard_((device));  \
     if (guard_.rc != RP_OK) return guard_.rc
+
+// The tie replay (rp_device.hpp, replay_tie_wave) needs, per codon (a,b,c), exactly what the
+// reference's Python + scipy make of it (statistics.py:75-90 and the first half of
+// scipy.signal.coherence): norm = sqrt(pow(real,2) + pow(image,2)) with glibc's pow(), which
+// is not x*x, then the three values of the segment's spectra.  They depend on the codon alone,
+// so all codons with counts < 16 are tabulated HERE, once per device, with this host's libm --
+// the libm the reference itself would run on.  Same operation order as oracle/scipy_replay.c.
+constexpr int kMaxDevices = 64;
+std::mutex g_tab_mutex;
+bool g_tab_ready[kMaxDevices] = {};
+
+#pragma clang fp contract(off)
+void fill_codon_table(rp::CodonTerms *tab)
+{
+    constexpr int B = rp::kCodonTabBits, N = 1 << B;
+    double (*volatile libm_pow)(double, double) = pow;  // not foldable into x*x
+    const double c23 = cos(2 * M_PI / 3), c43 = cos(4 * M_PI / 3), s23 = sin(2 * M_PI / 3), s43 = sin(4 * M_PI / 3);
+    const double tw = 0x1.bb67ae8584caap-1, scale = 0x1.5555555555555p-2;
+    for (int a = 0; a < N; ++a)
+        for (int b = 0; b < N; ++b)
+            for (int c = 0; c < N; ++c) {
+                const double real = ((double)a + (double)b * c23) + (double)c * c43;
+                const double image = (double)b * s23 + (double)c * s43;
+                double norm = sqrt(libm_pow(real, 2.0) + libm_pow(image, 2.0));
+                if (norm == 0.0) norm = 1.0;
+                const double v0 = (double)a / norm, v1 = (double)b / norm, v2 = (double)c / norm;
+                const double m = ((v0 + v1) + v2) / 3.0;
+                const double d0 = v0 - m, d1 = v1 - m, d2 = v2 - m;
+                const double xr = d0 + (-0.5) * (d1 + d2);
+                const double xi = tw * (d2 - d1);
+                rp::CodonTerms &t = tab[(a << (2 * B)) | (b << B) | c];
+                t.pxx = (fma(xr, xr, xi * xi) * scale) * 2.0;
+                t.pxr = (xr * scale) * 2.0;
+                t.pxi = (-xi * scale) * 2.0;
+                t.pad = 0.0;
+            }
+}
+#pragma clang fp contract(on)
+
+int ensure_norm_table(int device)  // call with `device` current
+{
+    if (device < 0 || device >= kMaxDevices) return fail(RP_ERR_DEVICE, "device index %d beyond the %d this build tracks", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_tab_mutex);
+    if (g_tab_ready[device]) return RP_OK;
+    constexpr int N = 1 << (3 * rp::kCodonTabBits);
+    static rp::CodonTerms tab[N];
+    fill_codon_table(tab);
+    RP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rp::rp_codon_tab), tab, sizeof(tab)));
+    g_tab_ready[device] = true;
+    return RP_OK;
+}
 
 int grid_for_waves(long long n_items, int waves_per_block)
 {
@@ -178,7 +231,8 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
         return fail(RP_ERR_NULL, "offsets and the five output arrays must be non-null");
     if (total_nt > 0 && !d_counts) return fail(RP_ERR_NULL, "d_counts is null but total_nt > 0");
     RP_ON_DEVICE(device);
-    int rc = RP_OK;
+    int rc = ensure_norm_table(device);
+    if (rc != RP_OK) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[0], stream));
     if (n_orfs == 0) {
@@ -234,9 +288,9 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));
     // 3. one thread per ORF: add its records, score, filter, store
     {
-        const int block = rp::kTileBlock;
-        const int grid = (int)((n_orfs + block - 1) / block);
-        hipLaunchKernelGGL(rp::k_orf_finish<rp::kTile>, dim3(grid), dim3(block), 0, stream, d_counts,
+        const int block = rp::kFinishBlock;
+        const long long grid = (n_orfs + block - 1) / block;
+        hipLaunchKernelGGL(rp::k_orf_finish<rp::kTile>, dim3((unsigned)grid), dim3(block), 0, stream, d_counts,
                            d_offsets, (long long)n_orfs, plan, ws, out, fp);
         RP_HIP(hipGetLastError());
     }

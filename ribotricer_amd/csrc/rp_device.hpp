@@ -301,6 +301,156 @@ __device__ __forceinline__ bool fp32_decision_unsafe(const FrameScore (&fr)[3], 
     return unsafe;
 }
 
+// ---------------------------------------------------------------------------
+// Exact frame ties: replay of the reference's own float64 arithmetic.
+//
+// When two reading frames score the same in exact arithmetic, statistics.py:109's strict `>`
+// is decided by the last bits of what numpy/scipy computed.  For those ORFs
+// (RP_FLAG_TIE, ~0.3 %) a wave repeats that computation operation for operation in IEEE
+// float64 -- per codon in parallel, the sums as the same left folds numpy performs -- and its
+// (phase, valid_codons) replace the closed form's.  The sequence (established against scipy
+// 1.15.3 / numpy 2.2.6 on x86-64 with FMA; oracle/scipy_replay.c is its CPU twin and is
+// bit-identical to the reference on every golden vector):
+//   codon (a,b,c): real = (a + b cos(2pi/3)) + c cos(4pi/3), image = b sin(2pi/3) + c sin(4pi/3)
+//                  norm = sqrt(pow(real,2) + pow(image,2))   statistics.py:75-85
+//                  v = (a,b,c) / norm                        statistics.py:86-90
+//   coherence():   m = ((v0+v1)+v2)/3, d = v - m             detrend 'constant'
+//                  X = (d0 - (d1+d2)/2, tw (d2-d1))          pocketfft radix-3, bin 1
+//                  pxx = (fma(Xr,Xr,Xi Xi)/3) 2 ; pxy = ((Xr/3) 2, (-Xi/3) 2) ; pyy = 2/3
+//                  Pxx = fold(pxx)/N, Pyy = fold(pyy)/N, Pxy = fold(pxy) * (1/N)   (N == 1: no mean)
+//                  |Pxy| = max sqrt(fma(q,q,1)), q = min/max ; Cxy = |Pxy|^2 / Pxx / Pyy
+// pow() is glibc's, which is NOT x*x (it differs in the last bit for 0.8 % of the arguments),
+// and everything up to (pxx, pxy) depends on the codon (a,b,c) alone: the three numbers of
+// every codon with counts < 16 come from a table the HOST fills once per device with its own
+// libm (ribophase.hip: the libm the reference would run on) -- tie-flagged ORFs are sparse, so
+// that is nearly all of them; rarer, larger codons are evaluated here with x*x for pow.  No fp
+// contraction anywhere in here: every fused operation is explicit.
+// ---------------------------------------------------------------------------
+constexpr int kCodonTabBits = 4;
+struct alignas(32) CodonTerms {
+    double pxx, pxr, pxi, pad;
+};
+__device__ CodonTerms rp_codon_tab[1 << (3 * kCodonTabBits)];
+
+__device__ __forceinline__ double readlane_f64(double x, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+
+#pragma clang fp contract(off)
+// (pxx, pxr, pxi) of one non-zero codon
+__device__ __forceinline__ void replay_codon_terms(int a, int b, int c, double &pxx, double &pxr, double &pxi)
+{
+    constexpr double kC23 = -0x1.ffffffffffffcp-2, kC43 = -0x1.0000000000004p-1;
+    constexpr double kS23 = 0x1.bb67ae8584cabp-1, kS43 = -0x1.bb67ae8584ca8p-1;
+    constexpr double kTwI = 0x1.bb67ae8584caap-1, kScale = 0x1.5555555555555p-2;
+    if ((unsigned)(a | b | c) < (1u << kCodonTabBits)) {
+        const CodonTerms t = rp_codon_tab[(a << (2 * kCodonTabBits)) | (b << kCodonTabBits) | c];
+        pxx = t.pxx;
+        pxr = t.pxr;
+        pxi = t.pxi;
+    } else {
+        const double real = ((double)a + (double)b * kC23) + (double)c * kC43;
+        const double image = (double)b * kS23 + (double)c * kS43;
+        double norm = __builtin_sqrt(real * real + image * image);
+        if (norm == 0.0) norm = 1.0;
+        const double v0 = (double)a / norm, v1 = (double)b / norm, v2 = (double)c / norm;
+        const double m = ((v0 + v1) + v2) / 3.0;
+        const double d0 = v0 - m, d1 = v1 - m, d2 = v2 - m;
+        const double xr = d0 + (-0.5) * (d1 + d2);
+        const double xi = kTwI * (d2 - d1);
+        pxx = (__builtin_fma(xr, xr, xi * xi) * kScale) * 2.0;
+        pxr = (xr * kScale) * 2.0;
+        pxi = (-xi * kScale) * 2.0;
+    }
+}
+
+// One wave, one ORF.  Lane t takes triplets t, t + 64, ...: five counts give it one codon of
+// each reading frame (one pass over the profile for all three frames); the per-frame sums are
+// then folded in codon order, wave-uniform, exactly as numpy folds them.
+__device__ __forceinline__ void replay_tie_wave(const int32_t *__restrict__ v, long long len, int lane,
+                                             double &phase, int &valid)
+{
+    constexpr double kPyySeg = 0x1.5555555555555p-1;
+    double sxx[3] = {0.0, 0.0, 0.0}, sxr[3] = {0.0, 0.0, 0.0}, sxi[3] = {0.0, 0.0, 0.0};  // wave-uniform folds
+    int n[3] = {0, 0, 0};
+    const long long n_trip = len / 3;  // frame f has a codon at triplet j iff 3j + f + 2 < len
+    const long long last = len > 0 ? len - 1 : 0;
+    for (long long j0 = 0; j0 < n_trip; j0 += kWave) {
+        const long long j = j0 + lane;
+        const long long p = 3 * j;
+        int w[5] = {0, 0, 0, 0, 0};
+        if (j < n_trip) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int x = v[p + k < last ? p + k : last];  // clamped, masked below
+                w[k] = p + k < len ? x : 0;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const bool nz = j < n_trip && p + f + 2 < len && (w[f] | w[f + 1] | w[f + 2]) != 0;
+            double pxx = 0.0, pxr = 0.0, pxi = 0.0;
+            if (nz) replay_codon_terms(w[f], w[f + 1], w[f + 2], pxx, pxr, pxi);
+            unsigned long long mask = __ballot(nz);
+            while (mask != 0) {  // numpy's reductions here are plain left folds in segment order
+                const int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const double t0 = readlane_f64(pxx, l), t1 = readlane_f64(pxr, l), t2 = readlane_f64(pxi, l);
+                if (n[f] == 0) {
+                    sxx[f] = t0;
+                    sxr[f] = t1;
+                    sxi[f] = t2;
+                } else {
+                    sxx[f] = sxx[f] + t0;
+                    sxr[f] = sxr[f] + t1;
+                    sxi[f] = sxi[f] + t2;
+                }
+                ++n[f];
+            }
+        }
+    }
+    double coh = 0.0;
+    int val = -1;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        if (n[f] == 0) {  // empty frame: reset (statistics.py:94-95)
+            coh = 0.0;
+            val = 0;
+            continue;
+        }
+        double pxx_m = sxx[f], pyy_m = kPyySeg, re = sxr[f], im = sxi[f];
+        if (n[f] > 1) {
+            const double dn = (double)n[f];
+            pxx_m = sxx[f] / dn;
+            double syy = kPyySeg;
+            for (int k = 1; k < n[f]; ++k) syy = syy + kPyySeg;
+            pyy_m = syy / dn;
+            const double scl = 1.0 / dn;
+            re = sxr[f] * scl;
+            im = sxi[f] * scl;
+        }
+        const double ar = __builtin_fabs(re), ai = __builtin_fabs(im);
+        const double mx = ar > ai ? ar : ai, mn = ar > ai ? ai : ar;
+        double ab = 0.0;
+        if (mx != 0.0) {
+            const double q = mn / mx;
+            ab = mx * __builtin_sqrt(__builtin_fma(q, q, 1.0));
+        }
+        const double score = ((ab * ab) / pxx_m) / pyy_m;
+        if (score > coh) {  // the reference's own strict '>' (statistics.py:109); NaN never wins
+            coh = score;
+            val = n[f];
+        }
+        if (val == -1) val = n[f];
+    }
+    phase = __builtin_sqrt(coh);
+    valid = val;
+}
+#pragma clang fp contract(fast)
+
 // detect_orfs.py:281,285-299
 struct FilterParams {
     double phase_score_cutoff;

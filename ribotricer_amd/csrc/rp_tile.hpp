@@ -166,7 +166,7 @@ inline TileWorkspace carve_workspace(void *base, void *plan_base, long long n_or
     char *p = reinterpret_cast<char *>(base);
     ws.n_rec = max_records(n_orfs, total_nt, tile);
     ws.rec = reinterpret_cast<uint4 *>(p);
-    p += record_bytes(n_orfs, total_nt, tile);
+    p += (size_t)ws.n_rec * kRecordBytes;
     char *q = plan_base ? reinterpret_cast<char *>(plan_base) : p;
     ws.tile_first = reinterpret_cast<long long *>(q);
     q += tile_index_bytes(total_nt, tile);
@@ -884,18 +884,19 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
 // queue drained by a fourth kernel was measured slower: the single contended atomic alone
 // cost more than the re-walks.)
 // ---------------------------------------------------------------------------
+constexpr int kFinishBlock = kWave;  // one wave per workgroup: a re-walk holds up nobody else
+
 template <int TILE>
-__global__ __launch_bounds__(kTileBlock) void k_orf_finish(const int32_t *__restrict__ counts,
-                                                           const int64_t *__restrict__ offsets,
-                                                           long long n_orfs, TilePlan plan,
-                                                           TileWorkspace ws, OrfOutputs out,
-                                                           FilterParams fp)
+__global__ __launch_bounds__(kFinishBlock) void k_orf_finish(const int32_t *__restrict__ counts,
+                                                             const int64_t *__restrict__ offsets,
+                                                             long long n_orfs, TilePlan plan,
+                                                             TileWorkspace ws, OrfOutputs out,
+                                                             FilterParams fp)
 {
-    constexpr int kWaves = kTileBlock / kWave;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
-    const long long orf = (long long)blockIdx.x * kTileBlock + threadIdx.x;
-    long long beg = 0, len = 0;
+    const int lane = threadIdx.x;
+    const long long orf = (long long)blockIdx.x * kFinishBlock + lane;
+    long long beg = 0, len = 0, count = 0;
+    int min_codon = RP_MIN_CODON_COV_EMPTY;
     unsigned split = 0;
     bool unsafe = false;
     if (orf < n_orfs) {
@@ -903,8 +904,6 @@ __global__ __launch_bounds__(kTileBlock) void k_orf_finish(const int32_t *__rest
         len = (long long)offsets[orf + 1] - beg;
         double p[3] = {0, 0, 0}, q[3] = {0, 0, 0};
         int n[3] = {0, 0, 0}, m[3] = {0, 0, 0};
-        long long count = 0;
-        int min_codon = RP_MIN_CODON_COV_EMPTY;
         if (len > 0) {
             const long long b_first = (beg + plan.mis) / TILE;
             const long long b_last = (beg + len - 1 + plan.mis) / TILE;
@@ -938,89 +937,36 @@ __global__ __launch_bounds__(kTileBlock) void k_orf_finish(const int32_t *__rest
         unsafe = fp32_decision_unsafe(fr, /*tile_sums=*/true) || near_cutoff(fp, phase);
         if (!unsafe) store_orf(out, fp, orf, phase, valid, count, min_codon, flags | split, len);
     }
-    if (!__syncthreads_or(unsafe)) return;
 
-    constexpr long long kBlockWalkLen = 2048;  // a single wave needs ~3 us per 1000 nt
-    __shared__ long long s_list_orf[kTileBlock], s_list_beg[kTileBlock], s_list_len[kTileBlock];
-    __shared__ unsigned s_list_split[kTileBlock];
-    __shared__ int s_n;
-    __shared__ double s_part[kWaves][6];
-    __shared__ int s_parti[kWaves][7];
-    __shared__ long long s_partc[kWaves];
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    if (unsafe) {  // hand orf / start / length over: the re-walk then needs no dependent index loads
-        const int slot = atomicAdd(&s_n, 1);
-        s_list_orf[slot] = orf;
-        s_list_beg[slot] = beg;
-        s_list_len[slot] = len;
-        s_list_split[slot] = split;
-    }
-    __syncthreads();
-    const int n_list = s_n;
-    for (int k = 0; k < n_list; ++k) {  // workgroup-uniform loop
-        const long long orf_s = s_list_orf[k];
-        const long long beg_s = s_list_beg[k];
-        const long long len_s = s_list_len[k];
-        const unsigned split_s = s_list_split[k];
-        const bool block_walk = len_s > kBlockWalkLen;
-        if (!block_walk && (k & (kWaves - 1)) != wave) continue;
+    // The too-close-to-call ORFs of this wave (~0.4 %), one after the other, by the whole wave:
+    // float64 walk from global memory (the integer results stand: they are exact), then -- on an
+    // exact frame tie -- the replay of the reference's own arithmetic (rp_device.hpp).
+    unsigned long long todo = __ballot(unsafe);
+    while (todo != 0) {
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const long long orf_s = readlane64(orf, l);
+        const long long beg_s = readlane64(beg, l);
+        const long long len_s = readlane64(len, l);
+        const long long count_s = readlane64(count, l);
+        const int min_s = __builtin_amdgcn_readlane(min_codon, l);
+        const unsigned split_s = (unsigned)__builtin_amdgcn_readlane((int)split, l);
         WalkResult<double> w;
-        if (block_walk)
-            wave_walk<double>(counts + beg_s, len_s, (int)threadIdx.x, w, kTileBlock);
-        else
-            wave_walk<double>(counts + beg_s, len_s, lane, w);
+        wave_walk<double>(counts + beg_s, len_s, lane, w);
         FrameScore fr2[3];
-        long long count2;
-        int min2;
-        if (block_walk) {
-            // per-wave sums -> LDS -> every thread adds the four partials in the same order
 #pragma unroll
-            for (int f = 0; f < 3; ++f) {
-                const double ps = wave_sum(w.acc[f].p), qs = wave_sum(w.acc[f].q);
-                const int ns = wave_sum(w.acc[f].n), ms = wave_sum(w.acc[f].m);
-                if (lane == 0) {
-                    s_part[wave][2 * f] = ps;
-                    s_part[wave][2 * f + 1] = qs;
-                    s_parti[wave][2 * f] = ns;
-                    s_parti[wave][2 * f + 1] = ms;
-                }
-            }
-            const long long cs = wave_sum(w.count);
-            const int mins = wave_min(w.min_codon);
-            if (lane == 0) {
-                s_partc[wave] = cs;
-                s_parti[wave][6] = mins;
-            }
-            __syncthreads();
-            count2 = 0;
-            min2 = RP_MIN_CODON_COV_EMPTY;
-#pragma unroll
-            for (int f = 0; f < 3; ++f) {
-                double ps = 0.0, qs = 0.0;
-                int ns = 0, ms = 0;
-                for (int wv = 0; wv < kWaves; ++wv) {
-                    ps += s_part[wv][2 * f];
-                    qs += s_part[wv][2 * f + 1];
-                    ns += s_parti[wv][2 * f];
-                    ms += s_parti[wv][2 * f + 1];
-                }
-                fr2[f] = frame_score(ps, qs, ns, ms);
-            }
-            for (int wv = 0; wv < kWaves; ++wv) {
-                count2 += s_partc[wv];
-                min2 = min(min2, s_parti[wv][6]);
-            }
-            __syncthreads();  // partial slots are reused by the next long item
-        } else {
-            wave_reduce_frames(w, fr2, count2, min2);
-        }
+        for (int f = 0; f < 3; ++f)
+            fr2[f] = frame_score(wave_sum(w.acc[f].p), wave_sum(w.acc[f].q), wave_sum(w.acc[f].n), wave_sum(w.acc[f].m));
         double phase;
         int valid;
         unsigned flags;
         combine_frames(fr2, phase, valid, flags);
-        if (lane == 0 && (!block_walk || wave == 0))
-            store_orf(out, fp, orf_s, phase, valid, count2, min2, flags | split_s | RP_FLAG_RECHECK64, len_s);
+        if (flags & RP_FLAG_TIE) {
+            replay_tie_wave(counts + beg_s, len_s, lane, phase, valid);
+            flags |= RP_FLAG_REPLAY;
+        }
+        if (lane == 0)
+            store_orf(out, fp, orf_s, phase, valid, count_s, min_s, flags | split_s | RP_FLAG_RECHECK64, len_s);
     }
 }
 

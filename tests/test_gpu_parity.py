@@ -16,9 +16,10 @@ from oracle import c_oracle
 pytestmark = pytest.mark.gpu
 
 PHASE_TOL = 1e-6
-# (ORFs flagged RP_FLAG_TIE, flagged ORFs whose valid_codons differs from the reference's
-# scipy-noise-decided pick) per fixture; every unflagged ORF is bit-exact (assert_matches_fixture)
-TIE_CENSUS = {"g2": (23, 16), "g3": (167, 98), "g4": (0, 0)}
+# (ORFs flagged RP_FLAG_TIE, flagged ORFs whose valid_codons differs from the reference's pick)
+# per fixture.  Round 1 left the second number at 16 / 98 (exact-arithmetic tie rule); the
+# on-device replay of the reference's float64 arithmetic brings it to 0.
+TIE_CENSUS = {"g2": (23, 0), "g3": (167, 0), "g4": (0, 0)}
 ALGOS = ["wave", "tile"]
 
 
@@ -51,8 +52,9 @@ def test_known_answers(eng, g1, algo):
     res = run(eng, counts, offsets, algo)
     for i, row in enumerate(g1):
         assert abs(res["phase"][i] - row["phase"]) <= PHASE_TOL, row["input"]
-        if not res["flags"][i] & 1:
-            assert res["valid"][i] == row["valid"], row["input"]
+        assert res["valid"][i] == row["valid"], row["input"]  # tie cases of SURVEY A.5 included
+        if res["flags"][i] & 1:
+            assert res["phase"][i] == row["phase"], row["input"]  # replayed: the reference's bits
     assert_matches_oracle(res, counts, offsets)
 
 
@@ -223,8 +225,8 @@ def test_status_predicate(eng, algo):
     ):
         res = run(eng, counts, offsets, algo, thresholds=make_filter(**kw))
         o = assert_matches_oracle(res, counts, offsets)
-        expect = reference_status(
-            res["phase"], o.valid, o.read_count, o.min_codon_cov, lengths,
+        expect = reference_status(  # (valid: checked above, the replayed ties included)
+            res["phase"], res["valid"], o.read_count, o.min_codon_cov, lengths,
             cutoff=kw.get("phase_score_cutoff", 0.428571428571), min_valid=kw.get("min_valid_codons", 5),
             min_reads=kw.get("min_reads_per_codon", 0), min_ratio=kw.get("min_valid_codons_ratio", 0),
             min_density=kw.get("min_density_over_orf", 0.0),
@@ -253,7 +255,9 @@ def test_status_next_to_the_cutoff(eng, algo):
         delta = [1e-9, 3e-8, 1e-7, 2e-7][j % 4] * (1 if j % 2 else -1)
         cutoff = float(o.phase[i]) + delta
         res = run(eng, counts, offsets, algo, thresholds=make_filter(phase_score_cutoff=cutoff))
-        expect = reference_status(o.phase, o.valid, o.read_count, o.min_codon_cov, lengths, cutoff=cutoff)
+        tie = (res["flags"] & 1) != 0  # replayed ORFs carry the reference's own phase / valid bits
+        expect = reference_status(np.where(tie, res["phase"], o.phase), np.where(tie, res["valid"], o.valid), o.read_count,
+                                  o.min_codon_cov, lengths, cutoff=cutoff)
         assert np.array_equal(res["status"], expect), (int(i), cutoff)
         assert res["status"][i] == (1 if delta < 0 else 0)
         n_near += int((res["flags"][np.abs(o.phase - cutoff) < 1e-6] & 2).all())

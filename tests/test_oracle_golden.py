@@ -113,3 +113,25 @@ def test_literal_restatement_bit_exact_sample(g2, g3, g5):
     for row in g5:
         p, v = phasescore_literal(row["input"])
         assert p == row["phase"] and v == row["valid"]
+
+
+# ------------------------------------------------------------------ the scipy replay (oracle/scipy_replay.c)
+@pytest.mark.parametrize("name", ["g2", "g3", "g4"])
+def test_scipy_replay_is_the_reference_bit_for_bit(request, name):
+    """The C replay of the reference's numpy/scipy arithmetic reproduces the reference's
+    phase score (every bit), valid_codons and per-frame coherence on EVERY golden ORF, the
+    exact frame ties included -- this is what the device-side tie replay is checked against."""
+    g = request.getfixturevalue(name)
+    r = c_oracle.replay_csr(g["counts"], g["offsets"])
+    assert np.array_equal(r.valid, g["valid"])
+    assert np.array_equal(r.phase, g["phase"])
+    assert np.array_equal(r.frame_n, g["frame_n"])
+    live = g["frame_n"] > 0
+    assert np.array_equal(r.frame_score[live], g["frame_score"][live], equal_nan=True)
+
+
+def test_scipy_replay_known_answers(g1):
+    for row in g1:
+        c = np.array(row["input"], np.int32)
+        r = c_oracle.replay_csr(c, np.array([0, c.size], np.int64))
+        assert r.phase[0] == row["phase"] and r.valid[0] == row["valid"], row["input"]
