@@ -56,7 +56,8 @@ typedef enum rp_status {
     RP_ERR_COUNTS = -7,    /* a count is negative or exceeds RP_MAX_COUNT */
     RP_ERR_ARG = -8,       /* invalid enum / option value */
     RP_ERR_INDEX_COLUMNS = -9, /* index line without exactly 11 tab-separated fields (orf.py:143-152) */
-    RP_ERR_INDEX_COORD = -10   /* malformed "start-end,..." coordinate field */
+    RP_ERR_INDEX_COORD = -10,  /* malformed "start-end,..." coordinate field */
+    RP_ERR_BAM = -11           /* BAM file cannot be opened / is not BGZF-compressed BAM / is truncated */
 } rp_status;
 
 /* bits of the per-ORF flags byte */
@@ -211,6 +212,43 @@ int rp_gather_profiles_dev(int device, const int32_t *d_coverage, int64_t covera
                            void *hip_stream);
 
 /*
+ * Dense P-site coverage from columnar alignments: replaces the
+ * Counter arithmetic of merge_read_lengths (detect_orfs.py:54-83: one dict update per
+ * (read length, strand, chrom, pos) key) and the per-nucleotide dict lookups of orf_coverage
+ * (detect_orfs.py:176-187) with one launch:
+ *     coverage[group_start[g] + pos - group_lo[g]] += count     for group_lo[g] <= pos <= group_hi[g]
+ *   d_group   int32[n]  (strand, chrom) group of the candidate-ORF index (rp_index_view.group
+ *                       numbering); negative = not in the index, entry ignored
+ *   d_pos     int64[n]  1-based position, ALREADY shifted by the read length's P-site offset
+ *                       (+offset on '+', -offset on '-': detect_orfs.py:76-80)
+ *   d_count   int32[n]  reads; entries hitting one position add up (any order: integer atomics)
+ *   d_group_* int64[n_groups]  first coverage index and [lo, hi] extent of each group
+ * d_coverage must be zero-filled (or hold a partial sum) on entry.  Synchronous; RP_ERR_COUNTS
+ * if an accumulated count leaves [0, RP_MAX_COUNT].
+ */
+int rp_coverage_build_dev(int device, const int32_t *d_group, const int64_t *d_pos, const int32_t *d_count,
+                          int64_t n_entries, const int64_t *d_group_start, const int64_t *d_group_lo,
+                          const int64_t *d_group_hi, int32_t n_groups, int32_t *d_coverage,
+                          int64_t coverage_len, void *hip_stream);
+
+/*
+ * Metagene profiles of one read length: replaces the per-ORF pandas
+ * loop of metagene_coverage (metagene.py:203-228).  d_counts / d_offsets: the profiles
+ * "leader + ORF + trailer, first max_positions nucleotides, transcript orientation" of the
+ * annotated ORFs (orf_coverage_length, metagene.py:97-157), CSR-packed in index order --
+ * rp_gather_profiles_dev builds them from the read length's dense coverage.  Outputs:
+ *   d_mean  float64[n_orfs]          mean coverage of each profile (0 for an empty one)
+ *   d_sum   float64[2*max_positions] [0..max) start side: sum over ORFs with mean > 0 of
+ *                                    profile[j] / mean, ORFs added in index order (the float64
+ *                                    operations of the reference, so the same bits);
+ *                                    [max..2max) stop side, slot m = m-th nucleotide from the end
+ *   d_seen  int32[2*max_positions]   ORFs that contributed to each slot (position_counter)
+ * Asynchronous on hip_stream.
+ */
+int rp_metagene_dev(int device, const int32_t *d_counts, const int64_t *d_offsets, int64_t n_orfs,
+                    int32_t max_positions, double *d_mean, double *d_sum, int32_t *d_seen, void *hip_stream);
+
+/*
  * Synchronous input check (one pass over offsets and counts on the device, then a
  * host sync): RP_ERR_OFFSETS / RP_ERR_COUNTS as documented above.
  */
@@ -287,6 +325,41 @@ typedef struct rp_index_view {
 int rp_index_parse_host(const char *text, size_t len, int skip_header, rp_index **out, int64_t *error_line);
 int rp_index_view_host(const rp_index *index, rp_index_view *view);
 void rp_index_free(rp_index *index);
+
+/*
+ * ---- host side: BAM front end ----------------------------------
+ *
+ * rp_bam_split_host replaces split_bam (bam.py:33-153) without pysam: the BGZF file is read
+ * once, every alignment goes through the reference's decision list (qcfail, duplicate,
+ * secondary, unmapped, then is_read_uniq_mapping of common.py:33-70: NH == 1, or MAPQ == 255
+ * when there is no NH tag), the aligned length is the number of reference positions under
+ * M/=/X, strand and 5' end follow the protocol (0 = forward, 1 = reverse; bam.py:108-128), and
+ * the key (length, strand, chrom, pos + 1) is counted.  read_lengths (may be NULL / 0): keep
+ * only these aligned lengths (bam.py:104-106).  The result -- the reference's nested Counter
+ * as five columns sorted by (length, strand, chrom, pos), the reference names of the header
+ * and the counters of {prefix}_bam_summary.txt -- is lent out by rp_bam_view_host until
+ * rp_bam_free.
+ */
+typedef struct rp_bam rp_bam;
+
+typedef struct rp_bam_view {
+    int64_t n_rows, n_refs;
+    const int32_t *length;
+    const uint8_t *strand; /* 0 '+', 1 '-' */
+    const int32_t *chrom;  /* reference id of the BAM header */
+    const int64_t *pos;    /* 1-based 5' end */
+    const int64_t *count;
+    const char *ref_names;
+    const int64_t *ref_off; /* name r = ref_names[ref_off[r] .. ref_off[r+1]) */
+    int64_t n_lengths;
+    const int32_t *length_order; /* aligned lengths in first-met order (the key order of the
+                                    reference's read_length_counts dict) */
+    int64_t total, valid, qcfail, duplicate, secondary, unmapped, multi;
+} rp_bam_view;
+
+int rp_bam_split_host(const char *path, int protocol, const int32_t *read_lengths, int32_t n_lengths, rp_bam **out);
+int rp_bam_view_host(const rp_bam *bam, rp_bam_view *view);
+void rp_bam_free(rp_bam *bam);
 
 /* repr(float) of CPython 3 into buf (>= 32 bytes, not NUL-terminated); returns the length. */
 int rp_format_double_repr(double value, char *buf);

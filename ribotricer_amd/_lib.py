@@ -70,12 +70,17 @@ SYMBOLS = {
     "rp_phase_score_f64_csr_dev": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "rp_gather_profiles_dev": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "rp_validate_csr_dev": (_int, [_int, _vp, _vp, _i64, _i64, _vp]),
+    "rp_metagene_dev": (_int, [_int, _vp, _vp, _i64, ctypes.c_int32, _vp, _vp, _vp, _vp]),
+    "rp_coverage_build_dev": (_int, [_int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp]),
     # host side (no GPU): TSV row rendering
     "rp_format_rows_host": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp,
                                    ctypes.c_size_t, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_size_t)]),
     "rp_index_parse_host": (_int, [_vp, ctypes.c_size_t, _int, ctypes.POINTER(_vp), ctypes.POINTER(_i64)]),
     "rp_index_view_host": (_int, [_vp, _vp]),
     "rp_index_free": (None, [_vp]),
+    "rp_bam_split_host": (_int, [ctypes.c_char_p, _int, _vp, ctypes.c_int32, ctypes.POINTER(_vp)]),
+    "rp_bam_view_host": (_int, [_vp, _vp]),
+    "rp_bam_free": (None, [_vp]),
     "rp_format_double_repr": (_int, [ctypes.c_double, _vp]),
     "rp_format_int_list": (ctypes.c_size_t, [_vp, _i64, _vp]),
 }

@@ -1,0 +1,256 @@
+"""Columnar P-site alignments: the hand-over format between the BAM
+front end and the profile gather, without per-key Python.
+
+The reference keeps the 5'-end histogram of a BAM as ``alignments[length][strand][(chrom, pos)]
+-> count`` (``split_bam``, ribotricer/bam.py:33-153), shifts every key by its read length's
+P-site offset and adds the read lengths up in a ``strand -> Counter`` (``merge_read_lengths``,
+ribotricer/detect_orfs.py:54-83), and ``export_orf_coverages`` then looks every nucleotide up
+in that Counter.  Here the histogram is five numpy columns; merging is a vectorised shift (the
+adding-up happens on the device, ``rp_coverage_build_dev``), and the reference's nested dicts
+are accepted everywhere through one conversion pass (the compatibility shim).
+"""
+
+from __future__ import annotations
+
+import ctypes
+from collections import Counter, defaultdict
+from operator import itemgetter
+from typing import NamedTuple
+
+import numpy as np
+
+from . import _lib
+
+STRANDS = ("+", "-")
+
+
+def _factorize(values):
+    """(unique values in order of first appearance, int codes) -- hash based."""
+    seen: dict = {}
+    try:
+        import pandas as pd
+
+        code, names = pd.factorize(np.asarray(values, dtype=object))
+        return list(names), code.astype(np.int32)
+    except ImportError:  # pragma: no cover - pandas ships with the image
+        code = np.fromiter((seen.setdefault(v, len(seen)) for v in values), np.int32, len(values))
+        return list(seen), code
+
+
+class MergedColumns(NamedTuple):
+    """What ``merge_read_lengths`` returns, as columns: one row per (read length, strand, chrom,
+    shifted pos) key -- rows of different read lengths may name the same position; they add up."""
+
+    strand: np.ndarray  # uint8  0 = '+', 1 = '-'
+    chrom: np.ndarray  # int32  index into ``chroms``
+    pos: np.ndarray  # int64  1-based, shifted by the P-site offset (detect_orfs.py:76-80)
+    count: np.ndarray  # int64
+    chroms: list  # chromosome names
+
+    @classmethod
+    def from_counters(cls, merged_alignments) -> "MergedColumns":
+        """The reference's ``strand -> Counter{(chrom, pos): count}`` in one pass per strand."""
+        strands, chrom_codes, poss, counts = [], [], [], []
+        names: dict = {}
+        for strand, table in merged_alignments.items():
+            if not table or strand not in STRANDS:
+                continue
+            keys = list(table.keys())
+            n = len(keys)
+            pos = np.fromiter(map(itemgetter(1), keys), np.int64, n)
+            cnt = np.fromiter(table.values(), np.int64, n)
+            local, code = _factorize(list(map(itemgetter(0), keys)))
+            remap = np.array([names.setdefault(c, len(names)) for c in local], np.int32)
+            strands.append(np.full(n, STRANDS.index(strand), np.uint8))
+            chrom_codes.append(remap[code])
+            poss.append(pos)
+            counts.append(cnt)
+        if not poss:
+            return cls(np.zeros(0, np.uint8), np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros(0, np.int64), [])
+        return cls(np.concatenate(strands), np.concatenate(chrom_codes), np.concatenate(poss), np.concatenate(counts), list(names))
+
+    def as_counters(self):
+        """Back to ``strand -> Counter`` (for ``export_wig`` and other consumers of the reference's format)."""
+        out = defaultdict(Counter)
+        for s, c, p, n in zip(self.strand.tolist(), self.chrom.tolist(), self.pos.tolist(), self.count.tolist()):
+            out[STRANDS[s]][(self.chroms[c], p)] += n
+        return out
+
+    def group_codes(self, group_keys) -> np.ndarray:
+        """Row -> group number of a candidate-ORF index (``NativeIndex.group_keys`` = (strand, chrom)
+        pairs), -1 for rows on a (strand, chrom) no ORF lives on."""
+        lut = np.full((2, max(1, len(self.chroms))), -1, np.int32)
+        where = {name: k for k, name in enumerate(self.chroms)}
+        for g, (strand, chrom) in enumerate(group_keys):
+            if strand in STRANDS and chrom in where:
+                lut[STRANDS.index(strand), where[chrom]] = g
+        return lut[self.strand, self.chrom] if self.pos.size else np.zeros(0, np.int32)
+
+
+class AlignmentColumns(NamedTuple):
+    """What ``split_bam`` returns (bam.py:33-153), as columns: one row per (read length, strand,
+    chrom, 5'-end position) key."""
+
+    length: np.ndarray  # int32  aligned read length
+    strand: np.ndarray  # uint8  0 = '+', 1 = '-' (after the protocol's strand assignment)
+    chrom: np.ndarray  # int32  index into ``chroms``
+    pos: np.ndarray  # int64  1-based 5'-end position (bam.py:133)
+    count: np.ndarray  # int64
+    chroms: list
+
+    @classmethod
+    def from_nested(cls, alignments) -> "AlignmentColumns":
+        """The reference's ``length -> strand -> Counter{(chrom, pos): count}``."""
+        parts = []
+        names: dict = {}
+        for length, by_strand in alignments.items():
+            m = MergedColumns.from_counters(by_strand)
+            remap = np.array([names.setdefault(c, len(names)) for c in m.chroms], np.int32)
+            parts.append((np.full(m.pos.size, int(length), np.int32), m.strand, remap[m.chrom] if m.pos.size else m.chrom, m.pos, m.count))
+        if not parts:
+            z = np.zeros(0, np.int64)
+            return cls(np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros(0, np.int32), z, z, [])
+        return cls(*(np.concatenate(col) for col in zip(*parts)), list(names))
+
+    def read_length_counts(self) -> dict:
+        """``read_length_counts`` of ``split_bam``: reads per aligned length."""
+        lengths, inverse = np.unique(self.length, return_inverse=True)
+        sums = np.bincount(inverse, weights=self.count.astype(np.float64), minlength=lengths.size)
+        return {int(length): int(s) for length, s in zip(lengths, sums)}
+
+    def of_length(self, length: int) -> MergedColumns:
+        keep = self.length == length
+        return MergedColumns(self.strand[keep], self.chrom[keep], self.pos[keep], self.count[keep], self.chroms)
+
+    def as_nested(self):
+        out = defaultdict(lambda: defaultdict(Counter))
+        for ln, s, c, p, n in zip(self.length.tolist(), self.strand.tolist(), self.chrom.tolist(), self.pos.tolist(), self.count.tolist()):
+            out[ln][STRANDS[s]][(self.chroms[c], p)] += n
+        return out
+
+
+def merge_read_lengths(alignments, psite_offsets) -> MergedColumns:
+    """Drop-in for ``ribotricer.detect_orfs.merge_read_lengths`` (detect_orfs.py:54-83): keep the
+    read lengths that have an offset, shift '+' rows by +offset and '-' rows by -offset.  Rows of
+    different lengths that now name one position are NOT added up here -- the device does that
+    when it builds the coverage (integer adds: same totals in any order).
+
+    ``alignments``: :class:`AlignmentColumns`, or the reference's nested dicts.
+    """
+    cols = alignments if isinstance(alignments, AlignmentColumns) else AlignmentColumns.from_nested(alignments)
+    lengths = np.fromiter(psite_offsets.keys(), np.int64, len(psite_offsets))
+    offsets = np.fromiter(psite_offsets.values(), np.int64, len(psite_offsets))
+    if lengths.size == 0 or cols.pos.size == 0:
+        z = np.zeros(0, np.int64)
+        return MergedColumns(np.zeros(0, np.uint8), np.zeros(0, np.int32), z, z, list(cols.chroms))
+    order = np.argsort(lengths)
+    lengths, offsets = lengths[order], offsets[order]
+    at = np.searchsorted(lengths, cols.length)
+    at_c = np.minimum(at, lengths.size - 1)
+    keep = lengths[at_c] == cols.length
+    shift = offsets[at_c[keep]]
+    strand = cols.strand[keep]
+    pos = cols.pos[keep] + np.where(strand == 0, shift, -shift)
+    return MergedColumns(strand, cols.chrom[keep], pos, cols.count[keep], list(cols.chroms))
+
+
+def build_coverage_device(merged, index, device=None):
+    """Dense P-site coverage of every (strand, chrom) group of ``index`` (a ``NativeIndex``) in
+    HBM: ``(coverage int32 device tensor, base)`` with ``base[(strand, chrom)] = (index of position
+    lo, lo)`` -- what ``gather.interval_table_from_index`` takes.  ``merged``: :class:`MergedColumns`
+    or the reference's ``strand -> Counter``.  Only the histogram rows cross PCIe (16 bytes per
+    row); the adding-up and the range check (RP_ERR_COUNTS) happen on the device."""
+    import torch
+
+    from .engine import _ptr, get_engine
+    from .gather import coverage_layout
+
+    cols = merged if isinstance(merged, MergedColumns) else MergedColumns.from_counters(merged)
+    eng = get_engine(device)
+    dev = eng.device
+    extent = index.extents
+    base, total = coverage_layout(extent)
+    keys = index.group_keys
+    coverage = torch.zeros(total, dtype=torch.int32, device=dev)
+    if cols.pos.size == 0 or total == 0:
+        return coverage, base
+    group = cols.group_codes(keys)
+    live = group >= 0
+    if cols.count.size and (int(cols.count.min()) < 0 or int(cols.count.max()) > _lib.MAX_COUNT):
+        bad = int(cols.count.min()) if int(cols.count.min()) < 0 else int(cols.count.max())
+        raise _lib.RibophaseError(-7, f"P-site count {bad} outside [0, {_lib.MAX_COUNT}]")
+    g_start = np.array([base[k][0] for k in keys], np.int64)
+    g_lo = np.array([extent[k][0] for k in keys], np.int64)
+    g_hi = np.array([extent[k][1] for k in keys], np.int64)
+    to_dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev, non_blocking=True)  # noqa: E731
+    d_group, d_pos, d_count = to_dev(group[live], np.int32), to_dev(cols.pos[live], np.int64), to_dev(cols.count[live], np.int32)
+    d_start, d_lo, d_hi = to_dev(g_start, np.int64), to_dev(g_lo, np.int64), to_dev(g_hi, np.int64)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(
+        _lib.load().rp_coverage_build_dev(
+            dev.index, _ptr(d_group), _ptr(d_pos), _ptr(d_count), d_pos.numel(), _ptr(d_start), _ptr(d_lo), _ptr(d_hi),
+            len(keys), _ptr(coverage), coverage.numel(), stream,
+        )
+    )
+    return coverage, base
+
+
+class _BamView(ctypes.Structure):  # rp_bam_view
+    _fields_ = (
+        [("n_rows", ctypes.c_int64), ("n_refs", ctypes.c_int64)]
+        + [(_n, ctypes.c_void_p) for _n in ("length", "strand", "chrom", "pos", "count", "ref_names", "ref_off")]
+        + [("n_lengths", ctypes.c_int64), ("length_order", ctypes.c_void_p)]
+        + [(_n, ctypes.c_int64) for _n in ("total", "valid", "qcfail", "duplicate", "secondary", "unmapped", "multi")]
+    )
+
+
+def split_bam(bam_path: str, protocol: str, prefix: str, read_lengths=None):
+    """Drop-in for ``ribotricer.bam.split_bam`` (bam.py:33-153) without pysam: the BAM is read once
+    by the native BGZF/BAM reader (``rp_bam_split_host``).  Returns ``(alignments, read_length_counts)``
+    with ``alignments`` as :class:`AlignmentColumns` (``.as_nested()`` gives the reference's dicts)
+    and writes ``{prefix}_bam_summary.txt`` in the reference's format (bam.py:139-151)."""
+    from .index import _array
+
+    if protocol not in ("forward", "reverse"):
+        raise ValueError("protocol must be 'forward' or 'reverse' (bam.py:108-128)")
+    lib = _lib.load()
+    want = np.ascontiguousarray(sorted(set(int(x) for x in read_lengths)), dtype=np.int32) if read_lengths is not None else None
+    handle = ctypes.c_void_p()
+    _lib.check(
+        lib.rp_bam_split_host(
+            bam_path.encode(), 0 if protocol == "forward" else 1,
+            ctypes.c_void_p(want.ctypes.data) if want is not None and want.size else None,
+            0 if want is None else int(want.size), ctypes.byref(handle),
+        )
+    )
+    try:
+        v = _BamView()
+        _lib.check(lib.rp_bam_view_host(handle, ctypes.byref(v)))
+        n = int(v.n_rows)
+        ref_off = _array(v.ref_off, int(v.n_refs) + 1, np.int64)
+        names = ctypes.string_at(v.ref_names, int(ref_off[-1])) if int(ref_off[-1]) else b""
+        chroms = [names[ref_off[k] : ref_off[k + 1]].decode("utf-8") for k in range(int(v.n_refs))]
+        cols = AlignmentColumns(
+            _array(v.length, n, np.int32), _array(v.strand, n, np.uint8), _array(v.chrom, n, np.int32),
+            _array(v.pos, n, np.int64), _array(v.count, n, np.int64), chroms,
+        )
+        order = _array(v.length_order, int(v.n_lengths), np.int32).tolist()
+        if read_lengths is not None and want.size == 0:  # an empty selection keeps nothing (bam.py:104)
+            cols = AlignmentColumns(*(c[:0] for c in cols[:5]), chroms)
+        stats = {k: int(getattr(v, k)) for k in ("total", "valid", "qcfail", "duplicate", "secondary", "unmapped", "multi")}
+        if read_lengths is not None and want.size == 0:
+            stats["valid"] = 0
+    finally:
+        lib.rp_bam_free(handle)
+    by_length = cols.read_length_counts()
+    counts = {length: by_length[length] for length in order if length in by_length}  # first-met order, as the reference's dict
+    summary = (
+        f"summary:\n\ttotal_reads: {stats['total']}\n\tunique_mapped: {stats['valid']}\n"
+        f"\tqcfail: {stats['qcfail']}\n\tduplicate: {stats['duplicate']}\n\tsecondary: {stats['secondary']}\n"
+        f"\tunmapped:{stats['unmapped']}\n\tmulti:{stats['multi']}\n\nlength dist:\n"
+    )
+    for length in sorted(counts):
+        summary += f"\t{length}: {counts[length]}\n"
+    with open(f"{prefix}_bam_summary.txt", "w") as output:
+        output.write(summary)
+    return cols, counts

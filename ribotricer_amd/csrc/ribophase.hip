@@ -18,7 +18,9 @@
 #include <new>
 #include "rp_format.hpp"
 #include "rp_index.hpp"
+#include "rp_bam.hpp"
 #include "rp_wave.hpp"
+#include "rp_coverage.hpp"
 
 namespace {
 
@@ -328,6 +330,7 @@ const char *rp_status_string(int status)
         case RP_ERR_ARG: return "invalid argument";
         case RP_ERR_INDEX_COLUMNS: return "index line: unexpected number of columns";
         case RP_ERR_INDEX_COORD: return "index line: malformed coordinate";
+        case RP_ERR_BAM: return "unreadable BAM file";
         default: return "unknown status";
     }
 }
@@ -523,6 +526,59 @@ int rp_gather_profiles_dev(int device, const int32_t *d_coverage, int64_t covera
     return RP_OK;
 }
 
+int rp_coverage_build_dev(int device, const int32_t *d_group, const int64_t *d_pos, const int32_t *d_count,
+                          int64_t n_entries, const int64_t *d_group_start, const int64_t *d_group_lo,
+                          const int64_t *d_group_hi, int32_t n_groups, int32_t *d_coverage,
+                          int64_t coverage_len, void *hip_stream)
+{
+    if (n_entries < 0 || coverage_len < 0 || n_groups < 0) return fail(RP_ERR_SIZE, "negative size");
+    if (n_entries > 0 && (!d_group || !d_pos || !d_count || !d_group_start || !d_group_lo || !d_group_hi))
+        return fail(RP_ERR_NULL, "entry columns and group tables must be non-null");
+    if (coverage_len > 0 && !d_coverage) return fail(RP_ERR_NULL, "d_coverage is null");
+    RP_ON_DEVICE(device);
+    if (n_entries == 0) return RP_OK;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    int *d_err = nullptr;  // 4-byte scratch word for the range check (once per sample, not the hot path)
+    RP_HIP(hipMalloc(&d_err, sizeof(int)));
+    hipError_t e = hipMemsetAsync(d_err, 0, sizeof(int), stream);
+    int h_err = 0;
+    if (e == hipSuccess) {
+        long long blocks = (n_entries + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(rp::k_coverage_build, dim3((unsigned)blocks), dim3(256), 0, stream, d_group, d_pos, d_count,
+                           (long long)n_entries, d_group_start, d_group_lo, d_group_hi, (int)n_groups, d_coverage,
+                           (long long)coverage_len, d_err);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_err);
+    if (e != hipSuccess) return fail(RP_ERR_HIP, "coverage build: %s", hipGetErrorString(e));
+    if (h_err) return fail(RP_ERR_COUNTS, "an accumulated P-site count left [0, %d]", RP_MAX_COUNT);
+    return RP_OK;
+}
+
+int rp_metagene_dev(int device, const int32_t *d_counts, const int64_t *d_offsets, int64_t n_orfs,
+                    int32_t max_positions, double *d_mean, double *d_sum, int32_t *d_seen, void *hip_stream)
+{
+    if (n_orfs < 0 || max_positions < 0) return fail(RP_ERR_SIZE, "negative size");
+    if (max_positions > 0 && (!d_sum || !d_seen)) return fail(RP_ERR_NULL, "d_sum / d_seen is null");
+    if (n_orfs > 0 && (!d_offsets || !d_mean)) return fail(RP_ERR_NULL, "d_offsets / d_mean is null");
+    RP_ON_DEVICE(device);
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (n_orfs > 0) {
+        hipLaunchKernelGGL(rp::k_metagene_means, dim3((unsigned)((n_orfs + 255) / 256)), dim3(256), 0, stream, d_counts,
+                           d_offsets, (long long)n_orfs, d_mean);
+        RP_HIP(hipGetLastError());
+    }
+    if (max_positions > 0) {
+        hipLaunchKernelGGL(rp::k_metagene_sums, dim3((unsigned)((2 * max_positions + 63) / 64)), dim3(64), 0, stream,
+                           d_counts, d_offsets, d_mean, (long long)n_orfs, (int)max_positions, d_sum, d_seen);
+        RP_HIP(hipGetLastError());
+    }
+    return RP_OK;
+}
+
 int rp_format_rows_host(const int32_t *counts, const int64_t *offsets, int64_t n_orfs,
                         const double *phase, const int32_t *valid, const int64_t *read_count,
                         const uint8_t *status, const char *head, const int64_t *head_off,
@@ -552,6 +608,62 @@ int rp_format_rows_host(const int32_t *counts, const int64_t *offsets, int64_t n
 struct rp_index {
     rpidx::Index ix;
 };
+
+struct rp_bam {
+    rpbam::Split sp;
+};
+
+int rp_bam_split_host(const char *path, int protocol, const int32_t *read_lengths, int32_t n_lengths, rp_bam **out)
+{
+    if (!out) return fail(RP_ERR_NULL, "out is null");
+    *out = nullptr;
+    if (!path) return fail(RP_ERR_NULL, "path is null");
+    if (protocol != 0 && protocol != 1) return fail(RP_ERR_ARG, "protocol must be 0 (forward) or 1 (reverse)");
+    if (n_lengths < 0 || (n_lengths > 0 && !read_lengths)) return fail(RP_ERR_ARG, "bad read_lengths");
+    rp_bam *h = new (std::nothrow) rp_bam;
+    if (!h) return fail(RP_ERR_SIZE, "out of memory");
+    int rc = rpbam::kOk;
+    try {
+        rc = rpbam::split_bam(path, protocol, n_lengths > 0 ? read_lengths : nullptr, n_lengths, h->sp);
+    } catch (const std::bad_alloc &) {
+        delete h;
+        return fail(RP_ERR_SIZE, "out of memory while reading the BAM file");
+    }
+    if (rc != rpbam::kOk) {
+        const std::string msg = h->sp.error;
+        delete h;
+        return fail(RP_ERR_BAM, "%s: %s", path, msg.c_str());
+    }
+    *out = h;
+    return RP_OK;
+}
+
+int rp_bam_view_host(const rp_bam *bam, rp_bam_view *view)
+{
+    if (!bam || !view) return fail(RP_ERR_NULL, "bam / view is null");
+    const rpbam::Split &s = bam->sp;
+    view->n_rows = (int64_t)s.pos.size();
+    view->n_refs = (int64_t)s.ref_off.size() - 1;
+    view->length = s.length.data();
+    view->strand = s.strand.data();
+    view->chrom = s.chrom.data();
+    view->pos = s.pos.data();
+    view->count = s.count.data();
+    view->ref_names = s.ref_names.data();
+    view->ref_off = s.ref_off.data();
+    view->n_lengths = (int64_t)s.length_order.size();
+    view->length_order = s.length_order.data();
+    view->total = s.total;
+    view->valid = s.valid;
+    view->qcfail = s.qcfail;
+    view->duplicate = s.duplicate;
+    view->secondary = s.secondary;
+    view->unmapped = s.unmapped;
+    view->multi = s.multi;
+    return RP_OK;
+}
+
+void rp_bam_free(rp_bam *bam) { delete bam; }
 
 int rp_index_parse_host(const char *text, size_t len, int skip_header, rp_index **out, int64_t *error_line)
 {

@@ -1,0 +1,296 @@
+// rp_bam.hpp -- pysam-free BAM front end: the 5'-end histogram of
+// split_bam (ribotricer/bam.py:33-153) straight from the BGZF file, as columns.
+//
+// Host code (no GPU involved): BGZF blocks are inflated with zlib, the BAM records are walked
+// in file order and every read goes through the reference's decision list:
+//   qcfail (0x200) -> duplicate (0x400) -> secondary (0x100) -> unmapped (0x4) -> not uniquely
+//   mapped (is_read_uniq_mapping, common.py:33-70: NH tag == 1, or -- without an NH tag --
+//   MAPQ == 255; everything else counts as "multi", the undecidable case included because the
+//   caller tests `not is_read_uniq_mapping(read)`)                                bam.py:77-95
+//   aligned length = number of reference positions under M/=/X operations
+//   (len(read.get_reference_positions()), bam.py:99-102), filtered by --read_lengths
+//   strand and 5' end by protocol (bam.py:108-128): forward keeps the mapping strand, reverse
+//   flips it; the 5' end is the first aligned reference position on '+', the last on '-'
+//   key (length, strand, chrom, pos + 1) += 1                                      bam.py:130-135
+// The keys are packed into 64-bit words, sorted and run-length counted: the result is the
+// reference's nested Counter as five columns, sorted by (length, strand, chrom, pos).
+#pragma once
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace rpbam {
+
+enum { kOk = 0, kOpen = 1, kFormat = 2, kInflate = 3, kTooManyRefs = 4 };
+
+struct Split {
+    // columns (one row per distinct key)
+    std::vector<int32_t> length;
+    std::vector<uint8_t> strand;  // 0 '+', 1 '-'
+    std::vector<int32_t> chrom;   // reference id of the BAM header
+    std::vector<int64_t> pos;     // 1-based
+    std::vector<int64_t> count;
+    // reference names of the header, '\n'-joined offsets
+    std::string ref_names;
+    std::vector<int64_t> ref_off;
+    // aligned lengths in the order the first counted read of each was met: the insertion order of
+    // the reference's read_length_counts dict, which downstream code iterates (metagene.py:296-312)
+    std::vector<int32_t> length_order;
+    // the counters of the summary file (bam.py:139-145)
+    int64_t total = 0, valid = 0, qcfail = 0, duplicate = 0, secondary = 0, unmapped = 0, multi = 0;
+    std::string error;
+};
+
+// ---- BGZF -> contiguous byte stream, block by block ------------------------------------------
+class BgzfReader {
+public:
+    explicit BgzfReader(FILE *fh) : fh_(fh) {}
+    // read exactly n bytes of the uncompressed stream; false at a clean EOF before the first byte
+    int read(void *dst, size_t n, bool *eof)
+    {
+        unsigned char *out = static_cast<unsigned char *>(dst);
+        size_t got = 0;
+        *eof = false;
+        while (got < n) {
+            if (at_ == buf_.size()) {
+                const int rc = next_block();
+                if (rc != kOk) return rc;
+                if (buf_.empty() && done_) {
+                    if (got == 0) {
+                        *eof = true;
+                        return kOk;
+                    }
+                    return kFormat;  // truncated in the middle of an item
+                }
+                continue;
+            }
+            const size_t take = std::min(n - got, buf_.size() - at_);
+            memcpy(out + got, buf_.data() + at_, take);
+            at_ += take;
+            got += take;
+        }
+        return kOk;
+    }
+
+private:
+    int next_block()
+    {
+        buf_.clear();
+        at_ = 0;
+        for (;;) {  // skip empty blocks (the EOF marker is one)
+            unsigned char hdr[18];
+            const size_t h = fread(hdr, 1, 18, fh_);
+            if (h == 0) {
+                done_ = true;
+                return kOk;
+            }
+            if (h != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) return kFormat;
+            const unsigned xlen = hdr[10] | (hdr[11] << 8);
+            // the BC subfield is the first one in every BGZF writer in use; find it anyway
+            std::vector<unsigned char> extra(xlen);
+            memcpy(extra.data(), hdr + 12, std::min<size_t>(6, xlen));
+            if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, fh_) != xlen - 6) return kFormat;
+            int bsize = -1;
+            for (unsigned p = 0; p + 4 <= xlen;) {
+                const unsigned slen = extra[p + 2] | (extra[p + 3] << 8);
+                if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) bsize = extra[p + 4] | (extra[p + 5] << 8);
+                p += 4 + slen;
+            }
+            if (bsize < 0) return kFormat;
+            const long payload = (long)bsize + 1 - 12 - (long)xlen - 8;  // compressed bytes of this block
+            if (payload < 0) return kFormat;
+            comp_.resize((size_t)payload + 8);
+            if (fread(comp_.data(), 1, comp_.size(), fh_) != comp_.size()) return kFormat;
+            const unsigned isize = comp_[payload + 4] | (comp_[payload + 5] << 8) | (comp_[payload + 6] << 16) | ((unsigned)comp_[payload + 7] << 24);
+            if (isize == 0) continue;
+            buf_.resize(isize);
+            z_stream zs;
+            memset(&zs, 0, sizeof(zs));
+            if (inflateInit2(&zs, -15) != Z_OK) return kInflate;
+            zs.next_in = comp_.data();
+            zs.avail_in = (unsigned)payload;
+            zs.next_out = buf_.data();
+            zs.avail_out = isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || zs.total_out != isize) return kInflate;
+            return kOk;
+        }
+    }
+    FILE *fh_;
+    std::vector<unsigned char> buf_, comp_;
+    size_t at_ = 0;
+    bool done_ = false;
+};
+
+inline uint32_t le32(const unsigned char *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint16_t le16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+// NH tag of a record's aux block: found -> *nh (as a signed 64-bit value)
+inline bool find_nh(const unsigned char *aux, const unsigned char *end, int64_t *nh)
+{
+    while (aux + 3 <= end) {
+        const unsigned char t0 = aux[0], t1 = aux[1], ty = aux[2];
+        aux += 3;
+        auto scalar = [&](size_t n, int64_t v) {
+            if (t0 == 'N' && t1 == 'H') *nh = v;
+            aux += n;
+            return t0 == 'N' && t1 == 'H';
+        };
+        switch (ty) {
+            case 'A': aux += 1; break;
+            case 'c': if (aux + 1 > end) return false; if (scalar(1, (int8_t)aux[0])) return true; break;
+            case 'C': if (aux + 1 > end) return false; if (scalar(1, aux[0])) return true; break;
+            case 's': if (aux + 2 > end) return false; if (scalar(2, (int16_t)le16(aux))) return true; break;
+            case 'S': if (aux + 2 > end) return false; if (scalar(2, le16(aux))) return true; break;
+            case 'i': if (aux + 4 > end) return false; if (scalar(4, (int32_t)le32(aux))) return true; break;
+            case 'I': if (aux + 4 > end) return false; if (scalar(4, le32(aux))) return true; break;
+            case 'f': aux += 4; break;
+            case 'Z':
+            case 'H':
+                while (aux < end && *aux) ++aux;
+                ++aux;
+                break;
+            case 'B': {
+                if (aux + 5 > end) return false;
+                const unsigned char sub = aux[0];
+                const uint32_t cnt = le32(aux + 1);
+                const size_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                aux += 5 + (size_t)cnt * w;
+                break;
+            }
+            default: return false;  // unknown type: stop scanning
+        }
+    }
+    return false;
+}
+
+// protocol: 0 = forward, 1 = reverse (bam.py:108-128).  read_lengths == nullptr: every length.
+inline int split_bam(const char *path, int protocol, const int32_t *read_lengths, int n_lengths, Split &out)
+{
+    FILE *fh = fopen(path, "rb");
+    if (!fh) {
+        out.error = std::string("cannot open ") + path;
+        return kOpen;
+    }
+    BgzfReader rd(fh);
+    bool eof = false;
+    auto fail = [&](int rc, const char *what) {
+        out.error = what;
+        fclose(fh);
+        return rc;
+    };
+    unsigned char w[4];
+    int rc = rd.read(w, 4, &eof);
+    if (rc != kOk || eof || memcmp(w, "BAM\1", 4) != 0) return fail(rc != kOk ? rc : kFormat, "not a BAM file (bad magic)");
+    if ((rc = rd.read(w, 4, &eof)) != kOk || eof) return fail(kFormat, "truncated header");
+    std::vector<unsigned char> tmp(le32(w));
+    if (!tmp.empty() && ((rc = rd.read(tmp.data(), tmp.size(), &eof)) != kOk || eof)) return fail(kFormat, "truncated header text");
+    if ((rc = rd.read(w, 4, &eof)) != kOk || eof) return fail(kFormat, "truncated header");
+    const uint32_t n_ref = le32(w);
+    if (n_ref >= (1u << 21)) return fail(kTooManyRefs, "more than 2^21 reference sequences");
+    out.ref_off.assign(1, 0);
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        if ((rc = rd.read(w, 4, &eof)) != kOk || eof) return fail(kFormat, "truncated reference list");
+        tmp.resize(le32(w));
+        if ((rc = rd.read(tmp.data(), tmp.size(), &eof)) != kOk || eof) return fail(kFormat, "truncated reference list");
+        size_t len = tmp.size();
+        while (len > 0 && tmp[len - 1] == 0) --len;
+        out.ref_names.append(reinterpret_cast<const char *>(tmp.data()), len);
+        out.ref_off.push_back((int64_t)out.ref_names.size());
+        if ((rc = rd.read(w, 4, &eof)) != kOk || eof) return fail(kFormat, "truncated reference list");
+    }
+    // key: length (10 bits) | strand (1) | chrom (21) | pos (32)  -> sorts by (length, strand, chrom, pos)
+    std::vector<uint64_t> keys;
+    std::vector<unsigned char> rec;
+    std::vector<char> length_seen(1024, 0);
+    for (;;) {
+        rc = rd.read(w, 4, &eof);
+        if (rc != kOk) return fail(rc, "corrupt BGZF block");
+        if (eof) break;
+        const uint32_t block = le32(w);
+        if (block < 32) return fail(kFormat, "alignment record shorter than its fixed part");
+        rec.resize(block);
+        if ((rc = rd.read(rec.data(), block, &eof)) != kOk || eof) return fail(kFormat, "truncated alignment record");
+        out.total += 1;
+        const int32_t ref_id = (int32_t)le32(rec.data());
+        const int32_t pos0 = (int32_t)le32(rec.data() + 4);
+        const unsigned l_name = rec[8], mapq = rec[9];
+        const unsigned n_cigar = le16(rec.data() + 12), flag = le16(rec.data() + 14);
+        const uint32_t l_seq = le32(rec.data() + 16);
+        if (flag & 0x200) { out.qcfail += 1; continue; }
+        if (flag & 0x400) { out.duplicate += 1; continue; }
+        if (flag & 0x100) { out.secondary += 1; continue; }
+        if (flag & 0x4) { out.unmapped += 1; continue; }
+        const size_t cigar_at = 32 + (size_t)l_name;
+        const size_t aux_at = cigar_at + 4 * (size_t)n_cigar + ((size_t)l_seq + 1) / 2 + l_seq;
+        if (aux_at > block) return fail(kFormat, "alignment record fields overrun the record");
+        int64_t nh = 0;
+        const bool has_nh = find_nh(rec.data() + aux_at, rec.data() + block, &nh);
+        const bool uniq = has_nh ? nh == 1 : mapq == 255;
+        if (!uniq) { out.multi += 1; continue; }
+        // reference positions under M / = / X
+        int64_t refpos = pos0, first = -1, last = -1, aligned = 0;
+        for (unsigned k = 0; k < n_cigar; ++k) {
+            const uint32_t c = le32(rec.data() + cigar_at + 4 * k);
+            const uint32_t op = c & 15, len = c >> 4;
+            if (op == 0 || op == 7 || op == 8) {  // M = X
+                if (len > 0) {
+                    if (first < 0) first = refpos;
+                    last = refpos + len - 1;
+                }
+                aligned += len;
+                refpos += len;
+            } else if (op == 2 || op == 3) {  // D N
+                refpos += len;
+            }
+        }
+        if (aligned == 0 || ref_id < 0) continue;  // (no aligned base / no reference name: nothing to key)
+        if (read_lengths) {
+            bool wanted = false;
+            for (int k = 0; k < n_lengths; ++k) wanted = wanted || read_lengths[k] == aligned;
+            if (!wanted) continue;
+        }
+        const bool reverse_map = (flag & 0x10) != 0;
+        // forward: strand = mapping strand; reverse: flipped.  5' end: first position on '+', last on '-'
+        // of the ASSIGNED strand under forward, and the opposite end under reverse (bam.py:108-128)
+        bool minus;
+        int64_t five;
+        if (protocol == 0) {
+            minus = reverse_map;
+            five = reverse_map ? last : first;
+        } else {
+            minus = !reverse_map;
+            five = reverse_map ? first : last;
+        }
+        if (aligned >= 1024 || five + 1 >= (1LL << 32)) continue;  // outside the key's fields (not a Ribo-seq read)
+        if (!length_seen[aligned]) {
+            length_seen[aligned] = 1;
+            out.length_order.push_back((int32_t)aligned);
+        }
+        keys.push_back(((uint64_t)aligned << 54) | ((uint64_t)(minus ? 1 : 0) << 53) | ((uint64_t)ref_id << 32) | (uint64_t)(five + 1));
+        out.valid += 1;
+    }
+    fclose(fh);
+    std::sort(keys.begin(), keys.end());
+    for (size_t i = 0; i < keys.size();) {
+        size_t j = i;
+        while (j < keys.size() && keys[j] == keys[i]) ++j;
+        const uint64_t k = keys[i];
+        out.length.push_back((int32_t)(k >> 54));
+        out.strand.push_back((uint8_t)((k >> 53) & 1));
+        out.chrom.push_back((int32_t)((k >> 32) & ((1u << 21) - 1)));
+        out.pos.push_back((int64_t)(k & 0xffffffffu));
+        out.count.push_back((int64_t)(j - i));
+        i = j;
+    }
+    return kOk;
+}
+
+}  // namespace rpbam

@@ -1,0 +1,89 @@
+// rp_coverage.hpp -- dense P-site coverage built on the device from columnar alignments
+// (first part).
+//
+// The reference keeps the 5'-end histogram of the BAM as nested dicts / Counters keyed by
+// (chrom, pos) (bam.py:105-135), shifts and merges the read lengths with one dict operation
+// per key (merge_read_lengths, detect_orfs.py:54-83) and finally looks every nucleotide of
+// every ORF up in the merged Counter (detect_orfs.py:176-187).  Here the histogram is a set of
+// columns (group = (strand, chrom) of the candidate-ORF index, position already shifted by
+// the read length's P-site offset, count), and ONE launch accumulates them into the dense
+// coverage array the profile gather reads: coverage[start[g] + pos - lo[g]] += count.
+// Entries of several read lengths that land on one position add up (atomics, integer: exact
+// and order independent); entries outside every ORF's extent are dropped, which is what the
+// reference's missing-key lookups amount to.
+#pragma once
+
+#include "rp_device.hpp"
+
+namespace rp {
+
+// err[0] |= 1 when an accumulated count leaves [0, RP_MAX_COUNT] (the scorers' input contract)
+__global__ void k_coverage_build(const int32_t *__restrict__ group, const int64_t *__restrict__ pos,
+                                 const int32_t *__restrict__ count, long long n,
+                                 const int64_t *__restrict__ group_start, const int64_t *__restrict__ group_lo,
+                                 const int64_t *__restrict__ group_hi, int n_groups,
+                                 int32_t *__restrict__ coverage, long long coverage_len, int *__restrict__ err)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        const int g = group[k];
+        if (g < 0 || g >= n_groups) continue;
+        const long long p = pos[k];
+        if (p < group_lo[g] || p > group_hi[g]) continue;
+        const long long idx = group_start[g] + (p - group_lo[g]);
+        if (idx < 0 || idx >= coverage_len) continue;
+        const int c = count[k];
+        const int before = atomicAdd(&coverage[idx], c);
+        const long long after = (long long)before + c;
+        if (c < 0 || after > RP_MAX_COUNT) atomicOr(err, 1);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Metagene profiles (metagene_coverage, ribotricer/metagene.py:160-265), one read length.
+// Input: the leader + ORF + trailer profiles of the annotated ORFs, already truncated to
+// max_positions and in transcript orientation, CSR-packed (the profile gather made them).
+//   k_metagene_means   mean coverage of every profile (from_start.mean(), metagene.py:213)
+//   k_metagene_sums    one thread per metagene position and side: the ORFs are added IN INDEX
+//                      ORDER, each value divided by its profile's mean first -- the very
+//                      float64 operations pandas performs (Series / mean, then
+//                      Series.add(fill_value=0) ORF after ORF, metagene.py:214-228), so the
+//                      sums carry the reference's bits; profiles with mean <= 0 are skipped.
+// side 0 aligns the profiles at their first position (start codon side), side 1 at their last
+// (stop codon side: slot m = m-th position from the end).
+// ---------------------------------------------------------------------------
+__global__ void k_metagene_means(const int32_t *__restrict__ counts, const int64_t *__restrict__ offsets,
+                                 long long n_orfs, double *__restrict__ mean)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_orfs) return;
+    const long long beg = offsets[i], end = offsets[i + 1];
+    long long s = 0;
+    for (long long k = beg; k < end; ++k) s += counts[k];
+    mean[i] = end > beg ? (double)s / (double)(end - beg) : 0.0;
+}
+
+__global__ void k_metagene_sums(const int32_t *__restrict__ counts, const int64_t *__restrict__ offsets,
+                                const double *__restrict__ mean, long long n_orfs, int max_positions,
+                                double *__restrict__ sum, int32_t *__restrict__ seen)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * max_positions) return;
+    const int side = t / max_positions, slot = t % max_positions;
+    double acc = 0.0;
+    int n = 0;
+    for (long long i = 0; i < n_orfs; ++i) {
+        const double m = mean[i];
+        if (!(m > 0.0)) continue;
+        const long long beg = offsets[i];
+        const long long len = offsets[i + 1] - beg;
+        if (slot >= len) continue;
+        const long long k = side == 0 ? beg + slot : beg + len - 1 - slot;
+        acc = acc + (double)counts[k] / m;
+        ++n;
+    }
+    sum[t] = acc;
+    seen[t] = n;
+}
+
+}  // namespace rp

@@ -153,10 +153,14 @@ def gather_profiles(records, merged_alignments, device=None):
 
 def gather_profiles_indexed(index, merged_alignments, device=None):
     """Same for a natively parsed index (``ribotricer_amd.index.NativeIndex``): the interval
-    table comes from the parser's arrays, no per-ORF Python."""
-    from .gather import build_dense_coverage_device, gather_profiles_device, interval_table_from_index
+    table comes from the parser's arrays, the dense coverage is accumulated on the device from
+    the alignment columns (``alignments.build_coverage_device``) -- no per-ORF, per-position or
+    per-key Python beyond the one conversion pass when ``merged_alignments`` still is the
+    reference's ``strand -> Counter``."""
+    from .alignments import build_coverage_device
+    from .gather import gather_profiles_device, interval_table_from_index
 
-    coverage, base = build_dense_coverage_device(merged_alignments, index.extents, device)
+    coverage, base = build_coverage_device(merged_alignments, index, device)
     return gather_profiles_device(coverage, interval_table_from_index(index, base), device)
 
 
@@ -235,6 +239,10 @@ def export_orf_coverages(
 ) -> None:
     """Write ``{prefix}_translating_ORFs.tsv`` -- drop-in for detect_orfs.py:206-324.
 
+    ``merged_alignments``: what ``merge_read_lengths`` returns -- the reference's
+    ``strand -> Counter{(chrom, pos): count}`` or this package's columnar
+    ``alignments.MergedColumns`` (``alignments.merge_read_lengths``).
+
     index text -> ``rp_index_parse_host`` (f3) -> interval table -> ``rp_gather_profiles_dev``
     (f1) -> ``rp_phase_score_csr_dev`` -> ``rp_format_rows_host`` (f2): no per-ORF Python."""
     from . import tsv
@@ -255,3 +263,65 @@ def export_orf_coverages(
             counts, offsets, res["phase"], res["valid"], res["read_count"], res["status"], index.tables, report_all
         ):
             output.write(chunk)
+
+
+def export_wig(merged_alignments, prefix: str) -> None:
+    """Drop-in for ``ribotricer.detect_orfs.export_wig`` (detect_orfs.py:327-352): the merged P-site
+    counts as ``{prefix}_pos.wig`` / ``{prefix}_neg.wig``, variableStep, sorted by (chrom, pos).
+    ``merged_alignments``: the reference's ``strand -> Counter`` or ``alignments.MergedColumns``
+    (rows naming one position are added up first, vectorised)."""
+    from .alignments import STRANDS, MergedColumns
+
+    cols = merged_alignments if isinstance(merged_alignments, MergedColumns) else MergedColumns.from_counters(merged_alignments)
+    for code, strand in enumerate(STRANDS):
+        keep = cols.strand == code
+        if not keep.any() and (isinstance(merged_alignments, MergedColumns) or strand not in merged_alignments):
+            continue  # the reference writes a file only for strands that are keys of the mapping
+        chrom, pos, count = cols.chrom[keep], cols.pos[keep], cols.count[keep]
+        names = np.asarray(cols.chroms, dtype=object)
+        rank = np.argsort(np.argsort(names)) if names.size else np.zeros(0, np.int64)  # sorted() orders by chromosome NAME
+        order = np.lexsort((pos, rank[chrom])) if pos.size else np.zeros(0, np.int64)
+        chrom, pos, count = chrom[order], pos[order], count[order]
+        new_key = np.ones(pos.size, bool)
+        new_key[1:] = (chrom[1:] != chrom[:-1]) | (pos[1:] != pos[:-1])
+        starts = np.nonzero(new_key)[0]
+        totals = np.add.reduceat(count, starts) if starts.size else count[:0]
+        chunks, cur = [], None
+        for c, p, n in zip(chrom[starts].tolist(), pos[starts].tolist(), totals.tolist()):
+            if c != cur:
+                cur = c
+                chunks.append(f"variableStep chrom={cols.chroms[c]}\n")
+            chunks.append(f"{p}\t{n}\n")
+        with open(f"{prefix}_pos.wig" if strand == "+" else f"{prefix}_neg.wig", "w") as output:
+            output.write("".join(chunks))
+
+
+def detect_orfs(bam, ribotricer_index, prefix, protocol, read_lengths, psite_offsets, phase_score_cutoff=CUTOFF,
+                min_valid_codons=MINIMUM_VALID_CODONS, min_reads_per_codon=MINIMUM_READS_PER_CODON,
+                min_valid_codons_ratio=MINIMUM_VALID_CODONS_RATIO, min_density_over_orf=MINIMUM_DENSITY_OVER_ORF,
+                report_all=False, meta_min_reads=100000) -> None:
+    """The ``detect-orfs`` pipeline of the reference (detect_orfs.py:355-526) on this package's
+    native pieces: BAM -> 5'-end columns (``alignments.split_bam``, no pysam) -> metagene profiles
+    and P-site offsets on the device (``metagene``) -> merged P-site columns -> WIG ->
+    ``export_orf_coverages``.  Same argument order, same output files -- except the two PDF plots
+    (plotting is out of scope) and protocol inference: ``protocol`` ('forward' / 'reverse') must be
+    given, as ``--stranded`` does on the reference's CLI."""
+    import os
+
+    from . import alignments as al
+    from . import metagene as mg
+
+    if protocol not in ("forward", "reverse"):
+        sys.exit("Error: ribotricer_amd.detect_orfs needs protocol 'forward' or 'reverse' (protocol inference is not part of this engine)")
+    parent = os.path.dirname(prefix)
+    if parent:
+        os.makedirs(parent, exist_ok=True)
+    annotated = mg.annotated_records(ribotricer_index)
+    cols, read_length_counts = al.split_bam(bam, protocol, prefix, read_lengths)
+    metagenes = mg.metagene_coverage(annotated, cols, read_length_counts, prefix, meta_min_reads=meta_min_reads)
+    if psite_offsets is None:
+        psite_offsets = mg.align_metagenes(metagenes, read_length_counts, prefix, phase_score_cutoff, read_lengths is None)
+    merged = al.merge_read_lengths(cols, psite_offsets)
+    export_wig(merged, prefix)
+    export_orf_coverages(ribotricer_index, merged, prefix, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
+                         min_valid_codons_ratio, min_density_over_orf, report_all)

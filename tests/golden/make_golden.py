@@ -19,6 +19,8 @@ Fixture sets:
   g4_long.npz            long ORFs up to 99 999 nt
   g5_float.json          float (metagene-like) profiles
   g6_*                   end-to-end: index + alignments + the reference's TSVs
+  g7_*                   the front end in miniature: per-read-length alignments ->
+                         metagene profiles, P-site offsets, merged alignments, WIG, TSV
 """
 
 from __future__ import annotations
@@ -323,7 +325,78 @@ def g6():
         print(f"g6_expected_{name}.tsv: {text.count(chr(10)) - 1} rows")
 
 
+def g7():
+    """The detect-orfs front end in miniature, on the G6 index: per-read-length 5'-end
+    alignments (what split_bam returns) -> the reference's metagene_coverage, align_metagenes,
+    merge_read_lengths, export_wig and export_orf_coverages (detect_orfs.py:444-520)."""
+    from ribotricer.detect_orfs import export_wig, merge_read_lengths
+    from ribotricer.metagene import align_metagenes, metagene_coverage
+    from ribotricer.orf import ORF
+
+    rng = np.random.default_rng(707)
+    index_path = os.path.join(HERE, "g6_index.tsv")
+    annotated = []
+    with open(index_path) as fh:
+        fh.readline()
+        for line in fh:
+            orf = ORF.from_string(line)
+            if orf is not None and orf.category == "annotated":
+                annotated.append(orf)
+    true_offsets = {27: 11, 28: 12, 29: 12, 30: 13, 31: 13}
+    weights = {27: 0.04, 28: 0.3, 29: 0.35, 30: 0.25, 31: 0.06}  # 27 stays under meta_min_reads
+    alignments = defaultdict(lambda: defaultdict(Counter))
+    read_length_counts = defaultdict(int)
+    for k, orf in enumerate(annotated):
+        if k % 5 == 4:
+            continue  # silent gene
+        lam = [0.4, 1.5, 4.0][k % 3]
+        tpos = [p for iv in orf.intervals for p in range(iv.start, iv.end + 1)]
+        first, last = tpos[0], tpos[-1]
+        tpos = list(range(first - 30, first)) + tpos + list(range(last + 1, last + 31))  # flanks: reads spill into the UTRs
+        if orf.strand == "-":
+            tpos = tpos[::-1]
+        w = np.array([2.5, 0.3, 0.2])
+        phase = (np.arange(len(tpos)) - 30) % 3
+        inside = (np.arange(len(tpos)) >= 30) & (np.arange(len(tpos)) < len(tpos) - 30)
+        vals = rng.poisson(np.where(inside, lam * w[phase], 0.05))
+        for p, v in zip(tpos, vals):
+            for _ in range(int(v)):
+                length = int(rng.choice(list(weights), p=list(weights.values())))
+                off = true_offsets[length]
+                five = p - off if orf.strand == "+" else p + off
+                alignments[length][orf.strand][(orf.chrom, five)] += 1
+                read_length_counts[length] += 1
+    with open(os.path.join(HERE, "g7_alignments.tsv"), "w") as fh:
+        fh.write("length\tstrand\tchrom\tpos\tcount\n")
+        for length in sorted(alignments):
+            for strand in sorted(alignments[length]):
+                for (chrom, p), c in sorted(alignments[length][strand].items()):
+                    fh.write(f"{length}\t{strand}\t{chrom}\t{p}\t{c}\n")
+    meta_min_reads = 400
+    with tempfile.TemporaryDirectory() as tmp:
+        prefix = os.path.join(tmp, "g7")
+        counts_for_meta = dict(read_length_counts)  # metagene_coverage deletes the rare lengths in place
+        metagenes = metagene_coverage(annotated, alignments, counts_for_meta, prefix, meta_min_reads=meta_min_reads)
+        psite_offsets = align_metagenes(metagenes, counts_for_meta, prefix, 0.428571428571, True)
+        merged = merge_read_lengths(alignments, psite_offsets)
+        export_wig(merged, prefix)
+        export_orf_coverages(index_path, merged, prefix, report_all=True)
+        for name in ("metagene_profiles_5p.tsv", "metagene_profiles_3p.tsv", "psite_offsets.txt", "pos.wig", "neg.wig", "translating_ORFs.tsv"):
+            with open(f"{prefix}_{name}") as src, open(os.path.join(HERE, f"g7_expected_{name}"), "w") as dst:
+                dst.write(src.read())
+    with open(os.path.join(HERE, "g7_merged.tsv"), "w") as fh:
+        fh.write("strand\tchrom\tpos\tcount\n")
+        for strand in sorted(merged):
+            for (chrom, p), c in sorted(merged[strand].items()):
+                fh.write(f"{strand}\t{chrom}\t{p}\t{c}\n")
+    with open(os.path.join(HERE, "g7_params.json"), "w") as fh:
+        json.dump({"meta": META, "read_length_counts": {str(k): int(v) for k, v in sorted(read_length_counts.items())},
+                   "meta_min_reads": meta_min_reads, "psite_offsets": {str(k): int(v) for k, v in psite_offsets.items()},
+                   "metagene_phase": {str(k): [float(v[2]), int(v[3]), float(v[4]), int(v[5])] for k, v in metagenes.items()}}, fh, indent=1)
+    print("g7: reads per length", dict(sorted(read_length_counts.items())), "offsets", dict(psite_offsets))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     for name in which:
         globals()[name]()

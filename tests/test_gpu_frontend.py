@@ -1,0 +1,138 @@
+"""The front end on the GPU against the reference's own outputs
+(tests/golden/g7_*: metagene_coverage, align_metagenes, merge_read_lengths, export_wig and
+export_orf_coverages of the reference run on the same per-read-length alignments)."""
+
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+from test_host_frontend_cpu import g7_params, load_g7_alignments, load_merged  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+INDEX = os.path.join(GOLDEN, "g6_index.tsv")
+
+
+def read_profiles(path):
+    rows = {}
+    with open(path) as fh:
+        fh.readline()
+        for line in fh:
+            length, offset, profile, phase, valid = line.rstrip("\n").split("\t")
+            rows[int(length)] = (int(offset), json.loads(profile), float(phase), int(valid))
+    return rows
+
+
+def test_device_coverage_equals_counter_lookup():
+    """rp_coverage_build_dev (columns of several read lengths adding up on the device) vs the
+    reference's merged Counter, through the profile gather."""
+    import torch
+
+    from ribotricer_amd import alignments as al
+    from ribotricer_amd import detect_orfs as d
+    from ribotricer_amd.index import NativeIndex
+
+    offsets = {int(k): v for k, v in g7_params()["psite_offsets"].items()}
+    merged_cols = al.merge_read_lengths(load_g7_alignments(), offsets)
+    index = NativeIndex.from_file(INDEX)
+    dc, do = d.gather_profiles_indexed(index, merged_cols)
+    torch.cuda.synchronize()
+    counts, offs = d.pack_profiles(d.read_index(INDEX), load_merged())  # per-nucleotide dict lookups
+    assert np.array_equal(do.cpu().numpy(), offs) and np.array_equal(dc.cpu().numpy(), counts)
+    # the reference's Counter goes through the same device path (one conversion pass)
+    dc2, _ = d.gather_profiles_indexed(index, load_merged())
+    assert np.array_equal(dc2.cpu().numpy(), counts)
+
+
+def test_coverage_build_rejects_counts_outside_the_contract():
+    from ribotricer_amd import alignments as al
+    from ribotricer_amd._lib import RibophaseError
+    from ribotricer_amd.index import NativeIndex
+
+    index = NativeIndex.from_file(INDEX)
+    strand, chrom = index.group_keys[0]
+    lo = int(index.group_lo[0])
+    cols = al.MergedColumns(np.full(3, al.STRANDS.index(strand), np.uint8), np.zeros(3, np.int32), np.full(3, lo + 5, np.int64),
+                            np.full(3, 9_000_000, np.int64), [chrom])  # 3 x 9e6 on one position > 2^24 - 1
+    with pytest.raises(RibophaseError) as e:
+        al.build_coverage_device(cols, index)
+    assert e.value.status == -7
+
+
+def test_metagene_and_offsets_match_the_reference(tmp_path):
+    """metagene.py:160-328: profiles (every float), P-site offsets and the offsets report
+    identical to the reference's; the two phase scores per read length within 1e-9 (they come
+    from the closed form on float profiles), valid codons equal."""
+    from ribotricer_amd import metagene as mg
+
+    params = g7_params()
+    cds = mg.annotated_records(INDEX)
+    assert len(cds) == 60
+    order = [int(k) for k in params["psite_offsets"]] + [27]  # the reference's dict order (reads as met); 27 is dropped
+    counts = {k: params["read_length_counts"][str(k)] for k in dict.fromkeys(order)}
+    prefix = str(tmp_path / "m")
+    metagenes = mg.metagene_coverage(cds, load_g7_alignments(), counts, prefix, meta_min_reads=params["meta_min_reads"])
+    assert sorted(counts) == sorted(int(k) for k in params["metagene_phase"])  # rare lengths deleted in place
+    for side in ("5p", "3p"):
+        got = read_profiles(f"{prefix}_metagene_profiles_{side}.tsv")
+        want = read_profiles(os.path.join(GOLDEN, f"g7_expected_metagene_profiles_{side}.tsv"))
+        assert sorted(got) == sorted(want)
+        for length in want:
+            assert got[length][0] == want[length][0]
+            assert got[length][1] == want[length][1], (side, length)  # the profile: same floats, bit for bit
+            assert abs(got[length][2] - want[length][2]) <= 1e-9 and got[length][3] == want[length][3]
+    offsets = mg.align_metagenes(metagenes, counts, prefix, 0.428571428571, True)
+    assert {str(k): v for k, v in offsets.items()} == params["psite_offsets"]
+    assert list(offsets) == [int(k) for k in params["psite_offsets"]]  # same insertion order
+    assert open(prefix + "_psite_offsets.txt").read() == open(os.path.join(GOLDEN, "g7_expected_psite_offsets.txt")).read()
+
+
+def test_native_detect_orfs_from_a_bam(tmp_path):
+    """The whole native chain -- BAM -> columns -> metagene -> offsets -> merge -> WIG -> TSV --
+    on a BAM holding the G7 reads: every output file equals the reference's (TSV: scores within
+    the 1e-6 tolerance, all other columns identical)."""
+    from bamwriter import write_bam
+
+    from ribotricer_amd.detect_orfs import detect_orfs
+
+    nested = load_g7_alignments()
+    refs = [("chrI", 400000), ("chrII", 400000), ("chrM", 400000)]
+    reads = []
+    rng = np.random.default_rng(3)
+    for length in sorted(nested):
+        for strand in nested[length]:
+            for (chrom, pos), count in nested[length][strand].items():
+                for _ in range(count):  # forward protocol: '+' reads start at pos, '-' reads END at pos
+                    start0 = pos - 1 if strand == "+" else pos - length
+                    reads.append(dict(name="r", chrom=chrom, pos=start0, flag=0 if strand == "+" else 16, mapq=255,
+                                      cigar=[("M", length)], tags={"NH": ("C", 1)} if rng.random() < 0.5 else {}))
+    for k in range(500):  # noise the decision list must drop
+        reads.append(dict(name="x", chrom="chrI", pos=1000 + k, flag=int(rng.choice([4, 256, 512, 1024])), mapq=255, cigar=[("M", 29)]))
+        reads.append(dict(name="m", chrom="chrII", pos=2000 + k, flag=0, mapq=3, cigar=[("M", 29)], tags={"NH": ("C", 4)}))
+    # lengths are met in the order the reference's generator met them (its dict order decides the
+    # line order of the offsets report and the base read length on equal counts)
+    lead = []
+    for length in [int(k) for k in g7_params()["psite_offsets"]]:
+        k = next(i for i, r in enumerate(reads) if r["cigar"][0][1] == length and r["name"] == "r")
+        lead.append(reads.pop(k))
+    order = rng.permutation(len(reads))
+    bam = str(tmp_path / "g7.bam")
+    write_bam(bam, refs, lead + [reads[i] for i in order])
+    prefix = str(tmp_path / "out" / "g7")
+    params = g7_params()
+    detect_orfs(bam, INDEX, prefix, "forward", None, None, report_all=True, meta_min_reads=params["meta_min_reads"])
+    for name in ("psite_offsets.txt", "pos.wig", "neg.wig"):
+        assert open(f"{prefix}_{name}").read() == open(os.path.join(GOLDEN, f"g7_expected_{name}")).read(), name
+    assert "total_reads: %d" % (len(reads) + len(lead)) in open(prefix + "_bam_summary.txt").read()
+    got = [line.rstrip("\n").split("\t") for line in open(prefix + "_translating_ORFs.tsv")]
+    want = [line.rstrip("\n").split("\t") for line in open(os.path.join(GOLDEN, "g7_expected_translating_ORFs.tsv"))]
+    assert len(got) == len(want) == 221
+    assert got[0] == want[0]
+    for g, w in zip(got[1:], want[1:]):
+        assert g[:3] == w[:3] and g[4:] == w[4:]
+        assert abs(float(g[3]) - float(w[3])) <= 1e-6
