@@ -54,11 +54,24 @@ def parse_args():
                     help="strong: one set sharded over the GPUs (configs[3]); weak: --orfs ORFs on every GPU")
     ap.add_argument("--algo", default="auto", choices=["auto", "wave", "tile"])
     ap.add_argument("--no-plan", action="store_true", help="rebuild the tile index inside every step")
-    ap.add_argument("--cpu-sample", type=int, default=3000, help="ORFs per core for the CPU baseline (0 = skip)")
-    ap.add_argument("--cpu-cores", type=int, default=0, help="cores for the CPU baseline (default: all, at most 64)")
+    ap.add_argument("--cpu-sample", type=int, default=12000, help="ORFs per process for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="processes for the CPU baseline (default: the usable cores, at most 64)")
     ap.add_argument("--no-verify", action="store_true", help="skip the concat == whole check at N > 1")
     ap.add_argument("--seed", type=int, default=20260213)
     return ap.parse_args()
+
+
+def usable_cores():
+    """Cores this process may really use: the scheduler affinity, capped by the cgroup CPU quota
+    (the GPU boxes show 256 CPUs with a 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def cpu_baseline(pool, counts_host, offsets_host, per_core):
@@ -78,7 +91,7 @@ def cpu_baseline(pool, counts_host, offsets_host, per_core):
         "kind": "port",
         "sample": f"first {n_done} ORFs of the set ({int(offsets_host[n_done])} nt), {n_done // n_workers} per process, "
         f"oracle/phasescore_literal.py (python triplet loop + scipy.signal.coherence) on {n_workers} processes "
-        f"of a {os.cpu_count()}-core host, {wall:.1f} s wall",
+        f"of a host with {usable_cores()} usable cores ({os.cpu_count()} visible), {wall:.1f} s wall",
     }
     n1 = min(per_core, offsets_host.size - 1)
     profiles = [counts_host[offsets_host[i] : offsets_host[i + 1]].tolist() for i in range(n1)]
@@ -89,7 +102,7 @@ def cpu_baseline(pool, counts_host, offsets_host, per_core):
     one = {"value": n1 / dt, "unit": "ORFs/s", "cores": 1, "kind": "port",
            "sample": f"first {n1} ORFs, same code on one core, {dt:.1f} s"}
     # best-effort CPU: C closed form on all host cores over a larger sample
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     n_c = min(200_000, offsets_host.size - 1)
     c_oracle.build()
     c = np.ascontiguousarray(counts_host[: offsets_host[n_c]])
@@ -131,7 +144,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         from oracle.cpu_pool import CpuPool
 
-        pool = CpuPool(args.cpu_cores if args.cpu_cores > 0 else min(os.cpu_count() or 1, 64))
+        pool = CpuPool(args.cpu_cores if args.cpu_cores > 0 else min(usable_cores(), 64))
 
     import numpy as np
     import torch

@@ -164,15 +164,29 @@ def gather_profiles_indexed(index, merged_alignments, device=None):
     return gather_profiles_device(coverage, interval_table_from_index(index, base), device)
 
 
+def _devices_from_env():
+    """``RIBOTRICER_AMD_DEVICES="0,1,2,3"``: the GPUs ``export_orf_coverages`` shards the index over."""
+    import os
+
+    spec = os.environ.get("RIBOTRICER_AMD_DEVICES", "").strip()
+    return [int(x) for x in spec.split(",") if x.strip() != ""] if spec else None
+
+
 def score_profiles(counts, offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
-                   min_valid_codons_ratio, min_density_over_orf, device=None) -> dict:
-    """One launch for the whole batch; host numpy arrays back (24 B + 2 B per ORF)."""
+                   min_valid_codons_ratio, min_density_over_orf, device=None, devices=None) -> dict:
+    """One launch for the whole batch; host numpy arrays back (24 B + 2 B per ORF).  With
+    ``devices`` (several GPUs of this node): nt-balanced ORF-index slices, one per GPU, host
+    concat (``engine.score_sharded``)."""
     import torch
 
-    eng = get_engine(device)
     thresholds = make_filter(
         phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio, min_density_over_orf
     )
+    if devices is not None and len(devices) > 1:
+        from .engine import score_sharded
+
+        return score_sharded(counts, offsets, devices, thresholds=thresholds)
+    eng = get_engine(device if devices is None or not len(devices) else devices[0])
     res = eng.score(counts, offsets, thresholds=thresholds)
     torch.cuda.synchronize(eng.device)
     return res.cpu_numpy()
@@ -236,8 +250,13 @@ def export_orf_coverages(
     min_valid_codons_ratio: float = MINIMUM_VALID_CODONS_RATIO,
     min_density_over_orf: float = MINIMUM_DENSITY_OVER_ORF,
     report_all: bool = False,
+    devices=None,
 ) -> None:
     """Write ``{prefix}_translating_ORFs.tsv`` -- drop-in for detect_orfs.py:206-324.
+
+    ``devices`` (beyond the reference's signature; default: ``RIBOTRICER_AMD_DEVICES`` or the
+    current GPU): the GPUs to shard the candidate ORFs over -- contiguous nt-balanced slices of
+    the index, one per GPU, results concatenated on the host; no collective (BASELINE configs[3]).
 
     ``merged_alignments``: what ``merge_read_lengths`` returns -- the reference's
     ``strand -> Counter{(chrom, pos): count}`` or this package's columnar
@@ -250,10 +269,12 @@ def export_orf_coverages(
 
     index = NativeIndex.from_file(ribotricer_index)
     # profiles are gathered and scored on the GPU; they come back once for the profile column
-    d_counts, d_offsets = gather_profiles_indexed(index, merged_alignments)
+    if devices is None:
+        devices = _devices_from_env()
+    d_counts, d_offsets = gather_profiles_indexed(index, merged_alignments, None if not devices else f"cuda:{int(devices[0])}")
     res = score_profiles(
         d_counts, d_offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
-        min_valid_codons_ratio, min_density_over_orf,
+        min_valid_codons_ratio, min_density_over_orf, devices=devices,
     )
     counts = d_counts.cpu().numpy()
     offsets = d_offsets.cpu().numpy()

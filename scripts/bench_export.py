@@ -15,7 +15,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ribotricer_amd import detect_orfs as d  # noqa: E402
 from ribotricer_amd import tsv  # noqa: E402
-from ribotricer_amd.gather import build_dense_coverage_device, gather_profiles_device, interval_table_from_index  # noqa: E402
+from ribotricer_amd.alignments import MergedColumns, build_coverage_device  # noqa: E402
+from ribotricer_amd.gather import gather_profiles_device, interval_table_from_index  # noqa: E402
 from ribotricer_amd.index import NativeIndex  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
@@ -59,7 +60,12 @@ def lap(name, t0):
 
 t = time.perf_counter()
 index = NativeIndex.from_file(index_path); t = lap("parse_index_f3", t)
-coverage, base = build_dense_coverage_device(align, index.extents); t = lap("counter_to_device_coverage", t)
+coverage, base = build_coverage_device(align, index); t = lap("counter_shim_to_device_coverage", t)
+cols = MergedColumns.from_counters(align)  # what the native front end (split_bam + merge_read_lengths) hands over
+t = time.perf_counter()
+coverage2, _ = build_coverage_device(cols, index); T_cols = time.perf_counter() - t; torch.cuda.synchronize()
+assert torch.equal(coverage, coverage2)
+t = time.perf_counter()
 table = interval_table_from_index(index, base); t = lap("interval_table_numpy", t)
 d_counts, d_offsets = gather_profiles_device(coverage, table); t = lap("table_h2d_plus_gather_f1", t)
 res = d.score_profiles(d_counts, d_offsets, 0.428571428571, 5, 0, 0, 0.0); t = lap("score_plus_d2h_outputs", t)
@@ -94,10 +100,17 @@ total = sum(T.values())
 t0 = time.perf_counter()
 d.export_orf_coverages(index_path, align, os.path.join(tmp, "x"))
 t_export = time.perf_counter() - t0
+t0 = time.perf_counter()
+d.export_orf_coverages(index_path, cols, os.path.join(tmp, "y"), report_all=True)
+t_export_cols_all = time.perf_counter() - t0
+t0 = time.perf_counter()
+d.export_orf_coverages(index_path, cols, os.path.join(tmp, "z"))
+t_export_cols = time.perf_counter() - t0
 print(json.dumps({
     "n_orfs": n, "total_nt": int(offsets[-1]), "reads": n_reads, "tsv_bytes_report_all": size,
     "seconds": {k: round(v, 4) for k, v in T.items()}, "total_s": round(total, 3), "orfs_per_s_report_all": round(n / total),
-    "export_orf_coverages_default_s": round(t_export, 3), "gather_kernel_ms": round(gather_ms, 4), "gather_GBps": round(8 * int(offsets[-1]) / gather_ms / 1e6), "translating": int(res["status"].sum()),
+    "export_orf_coverages_default_s": round(t_export, 3), "columns_to_device_coverage_s": round(T_cols, 4),
+    "export_orf_coverages_columns_report_all_s": round(t_export_cols_all, 3), "export_orf_coverages_columns_default_s": round(t_export_cols, 3), "gather_kernel_ms": round(gather_ms, 4), "gather_GBps": round(8 * int(offsets[-1]) / gather_ms / 1e6), "translating": int(res["status"].sum()),
 }))
 for f in os.listdir(tmp):
     os.remove(os.path.join(tmp, f))

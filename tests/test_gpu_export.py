@@ -140,3 +140,20 @@ def test_export_edge_indexes(tmp_path):
     assert f[0] == "tx_10_38_18" and f[2] == "nontranslating" and f[4:6] == ["5", "18"]
     # '-' strand: the profile is reversed (detect_orfs.py:201-202); position 12 is the 3rd of 10-18
     assert f[17] == str([0] * 9 + [0, 0, 0, 0, 0, 0, 5, 0, 0])
+
+
+def test_export_sharded_over_two_slices_equals_single(tmp_path):
+    """configs[3] through the product entry point: export_orf_coverages(devices=[0, 0]) cuts the
+    index into two nt-balanced slices (two streams of the one GPU here) and writes the same file."""
+    from ribotricer_amd.detect_orfs import export_orf_coverages
+
+    index = os.path.join(GOLDEN, "g6_index.tsv")
+    export_orf_coverages(index, load_alignments(), str(tmp_path / "one"), report_all=True)
+    export_orf_coverages(index, load_alignments(), str(tmp_path / "two"), report_all=True, devices=[0, 0])
+    os.environ["RIBOTRICER_AMD_DEVICES"] = "0,0,0"
+    try:
+        export_orf_coverages(index, load_alignments(), str(tmp_path / "env"), report_all=True)
+    finally:
+        del os.environ["RIBOTRICER_AMD_DEVICES"]
+    one = open(str(tmp_path / "one_translating_ORFs.tsv")).read()
+    assert one == open(str(tmp_path / "two_translating_ORFs.tsv")).read() == open(str(tmp_path / "env_translating_ORFs.tsv")).read()
