@@ -35,12 +35,15 @@ def one(cfg, n_orfs, calls):
         c, o = synth_csr_host(pn, seed=77, cfg=pc)
         ref = c_oracle.phase_score_csr(c, o, n_threads=8)
         r = eng.score(c, o, thresholds=make_filter(), algo="tile").cpu_numpy()
-        good = (np.abs(r["phase"] - ref.phase).max() <= 1e-6 and np.array_equal(r["valid"], ref.valid)
+        tie = (ref.flags & 1) != 0  # exact frame ties: the device replays the reference's float64 arithmetic
+        rep = c_oracle.replay_csr(c, o)
+        want_valid = np.where(tie, rep.valid, ref.valid)
+        good = (np.abs(r["phase"] - ref.phase).max() <= 1e-6 and np.array_equal(r["valid"], want_valid)
                 and np.array_equal(r["read_count"], ref.read_count) and np.array_equal(r["min_codon_cov"], ref.min_codon_cov)
                 and np.array_equal(r["flags"] & 1, ref.flags & 1))
         if not good:
             ok = False
-            msg += f"{pc}: dphase={np.abs(r['phase'] - ref.phase).max():.2e} valid_diff={(r['valid'] != ref.valid).sum()} "
+            msg += f"{pc}: dphase={np.abs(r['phase'] - ref.phase).max():.2e} valid_diff={(r['valid'] != want_valid).sum()} "
     counts, offsets = synth_csr_device(n_orfs, cfg=cfg, device="cuda:0")
     th = make_filter()
     for _ in range(10):
