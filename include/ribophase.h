@@ -70,7 +70,12 @@ typedef enum rp_status {
 #define RP_FLAG_REPLAY 0x08u   /* phase / valid_codons of this tie-flagged ORF come from the on-device
                                   replay of the reference's own float64 (numpy / scipy) arithmetic */
 
+/* two frame scores count as tied when they differ by no more than RP_TIE_RTOL * (the larger
+ * one) + RP_TIE_ATOL: relative, because the reference's own rounding noise is relative (~1e-15);
+ * the absolute floor covers the frames whose unit vectors cancel exactly (scores that are 0 in
+ * exact arithmetic and ~1e-32 in float64) */
 #define RP_TIE_RTOL 1e-9
+#define RP_TIE_ATOL 1e-24
 
 /* kernel family selector */
 typedef enum rp_algo {

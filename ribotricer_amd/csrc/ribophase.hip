@@ -295,6 +295,13 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
         hipLaunchKernelGGL(rp::k_orf_finish<rp::kTile>, dim3((unsigned)grid), dim3(block), 0, stream, d_counts,
                            d_offsets, (long long)n_orfs, plan, ws, out, fp);
         RP_HIP(hipGetLastError());
+        // 4. the long too-close-to-call ORFs it queued (usually none): a workgroup each
+        if (total_nt > rp::kLongWalk) {
+            const long long cap = rp::long_capacity(total_nt);
+            hipLaunchKernelGGL(rp::k_rewalk_long<rp::kTile>, dim3((unsigned)(cap < 512 ? cap : 512)), dim3(rp::kLongBlock), 0,
+                               stream, d_counts, d_offsets, plan, ws, out, fp);
+            RP_HIP(hipGetLastError());
+        }
     }
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[3], stream));
     return RP_OK;

@@ -229,7 +229,7 @@ __device__ __forceinline__ FrameScore frame_score(double p, double q, int n, int
 
 __device__ __forceinline__ double tie_tol(double best)
 {
-    return RP_TIE_RTOL * (best > 1.0 ? best : 1.0);
+    return __builtin_fma(RP_TIE_RTOL, best, RP_TIE_ATOL);
 }
 
 // statistics.py:64-66,94-95,109-115.  An empty frame resets; a later frame wins only
@@ -378,17 +378,21 @@ __device__ __forceinline__ void replay_tie_wave(const int32_t *__restrict__ v, l
     int n[3] = {0, 0, 0};
     const long long n_trip = len / 3;  // frame f has a codon at triplet j iff 3j + f + 2 < len
     const long long last = len > 0 ? len - 1 : 0;
+    auto load5 = [&](long long j, int (&w)[5]) {  // the five counts of triplet j (clamped reads, masked)
+        const long long p = 3 * j;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            int x = 0;
+            if (j < n_trip) x = v[p + k < last ? p + k : last];
+            w[k] = (j < n_trip && p + k < len) ? x : 0;
+        }
+    };
+    int w[5], wn[5];
+    load5(lane, w);
     for (long long j0 = 0; j0 < n_trip; j0 += kWave) {
         const long long j = j0 + lane;
         const long long p = 3 * j;
-        int w[5] = {0, 0, 0, 0, 0};
-        if (j < n_trip) {
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int x = v[p + k < last ? p + k : last];  // clamped, masked below
-                w[k] = p + k < len ? x : 0;
-            }
-        }
+        load5(j + kWave, wn);  // the next chunk is in flight while this one is folded
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
             const bool nz = j < n_trip && p + f + 2 < len && (w[f] | w[f + 1] | w[f + 2]) != 0;
@@ -411,6 +415,8 @@ __device__ __forceinline__ void replay_tie_wave(const int32_t *__restrict__ v, l
                 ++n[f];
             }
         }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) w[k] = wn[k];
     }
     double coh = 0.0;
     int val = -1;

@@ -102,13 +102,25 @@ constexpr int kHeadMapAt = 2 + kHeadSlots;    // 8-byte index where the lane map
 constexpr int kHeadRow = kHeadMapAt + 256 / 8;  // 8-byte entries per row (640 B per 31 KiB tile)
 static_assert(kTile / (3 * kRun) + kHeadSlots + 1 <= 256, "a head-row tile must fit one pass per wave");
 
+// Too-close-to-call ORFs longer than this are not re-walked by the one wave that finds them
+// (k_orf_finish) but queued for k_rewalk_long, where a 1024-thread workgroup takes each: a
+// single wave streams a 100 k-nt profile for a millisecond.
+constexpr long long kLongWalk = 4096;
+constexpr int kLongBlock = 1024;
+
 struct TileWorkspace {
     long long *tile_first;  // [n_tiles + 1] first ORF starting at/after each tile start
     seg_desc_t *head;       // [max_tiles][kHeadRow]
     seg_desc_t *desc;       // [n_rec]
     uint4 *rec;             // [3 * n_rec]
     long long n_rec;
+    int *long_count;        // number of queued long ORFs (zeroed by k_tile_score)
+    long long *long_list;   // [long_capacity]: at most one entry per ORF longer than kLongWalk
 };
+
+inline long long long_capacity(long long total_nt) { return total_nt / kLongWalk + 1; }
+
+inline size_t long_bytes(long long total_nt) { return 128 + (size_t)long_capacity(total_nt) * sizeof(long long); }
 
 inline long long max_tiles(long long total_nt, int tile) { return (total_nt + 3 + tile - 1) / tile + 1; }
 
@@ -151,7 +163,7 @@ inline size_t plan_bytes(long long n_orfs, long long total_nt, int tile)
 // per-call part: the segment records
 inline size_t record_bytes(long long n_orfs, long long total_nt, int tile)
 {
-    return (size_t)max_records(n_orfs, total_nt, tile) * kRecordBytes;
+    return (size_t)max_records(n_orfs, total_nt, tile) * kRecordBytes + long_bytes(total_nt);
 }
 
 inline size_t workspace_bytes(long long n_orfs, long long total_nt, int tile)
@@ -167,6 +179,9 @@ inline TileWorkspace carve_workspace(void *base, void *plan_base, long long n_or
     ws.n_rec = max_records(n_orfs, total_nt, tile);
     ws.rec = reinterpret_cast<uint4 *>(p);
     p += (size_t)ws.n_rec * kRecordBytes;
+    ws.long_count = reinterpret_cast<int *>(p);
+    ws.long_list = reinterpret_cast<long long *>(p + 128);
+    p += long_bytes(total_nt);
     char *q = plan_base ? reinterpret_cast<char *>(plan_base) : p;
     ws.tile_first = reinterpret_cast<long long *>(q);
     q += tile_index_bytes(total_nt, tile);
@@ -719,13 +734,10 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
                                                            TileWorkspace ws)
 {
     __shared__ __attribute__((aligned(16))) int s_counts[kLdsCounts];
-    __shared__ int s_qfirst[kSegChunk];   // LDS index of the first owned triplet
-    __shared__ int s_endq[kSegChunk];     // ORF end in LDS coordinates (clamped)
-    __shared__ int s_ntrip[kSegChunk];    // owned triplets
     __shared__ int s_live[kSegChunk];     // the slot holds a segment of this tile
     __shared__ int s_tail[kSegChunk];     // LDS index of an owned partial last codon | its length << 16, or -1
     __shared__ int s_vlstart[kSegChunk + 1];
-    __shared__ int s_owner[kMaxVl];       // segment+1 at the first lane of a segment / wave, else 0
+    __shared__ int s_owner[kTileBlock];   // short-ORF path: 64 private words per wave for the segment marks
     __shared__ RunRec s_rec[kMaxRecs];
     __shared__ SegInts s_ints[kSegChunk];
 
@@ -735,6 +747,7 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
     const long long b = blockIdx.x;
     const long long t0 = b * (long long)kTile - plan.mis;  // position of LDS index 0 (may be < 0 for b == 0)
 
+    if (blockIdx.x == 0 && tid == 0) *ws.long_count = 0;  // (k_orf_finish, next in the stream, appends)
     RP_STAMP_DECL
     RP_STAMP();  // 0: entry
     // The tile's head row first -- its [a0, a1) ORF range through the scalar unit, its segment
@@ -820,60 +833,75 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
         return;
     }
 
-    // ---- many short ORFs: > kHeadSlots segments, in chunks of 64 through a table in LDS --------
+    // ---- many short ORFs: > kHeadSlots segments, 64 slots at a time ------------------------------
+    // Same scheme, minus the head row and the lane map: every wave reads the chunk's descriptors
+    // from the per-segment array (slot L of chunk c = ORF a0 - 1 + 64 c + L) and finds its
+    // lanes' segments through 64 private words of LDS (marks at the segments' first lanes, then
+    // a max-scan); 64 segments need < 256 virtual lanes, so still one pass per wave.
+    const long long n_slots = a1 - a0 + 1;
+    seg_desc_t dc = 0;
+    {
+        const long long orf = a0 - 1 + lane;
+        if (orf >= 0 && orf < a1) dc = ws.desc[orf + b];  // chunk 0, in flight with the tile
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (long long c0 = a0 - 1; c0 < a1; c0 += kSegChunk) {
-        for (int k = tid; k < kMaxVl; k += kTileBlock) s_owner[k] = 0;
-        if (c0 != a0 - 1 && tid < kSegChunk) {
-            s_ints[tid].nn = 0;
-            s_ints[tid].mm = 0;
-            s_ints[tid].count = 0;
-            s_ints[tid].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
+    for (long long c0 = 0; c0 < n_slots; c0 += kSegChunk) {
+        if (c0 > 0) {
+            __syncthreads();  // the previous chunk's record stage is done with the tables
+            if (wave == 0) {
+                s_ints[lane].nn = 0;
+                s_ints[lane].mm = 0;
+                s_ints[lane].count = 0;
+                s_ints[lane].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
+            }
+            const long long orf = a0 - 1 + c0 + lane;
+            dc = orf < a1 ? ws.desc[orf + b] : 0;
         }
-        __syncthreads();  // previous chunk's readers are done, scratch is clear
-
-        // segment table + lane allocation (wave 0; from the plan's descriptors, not the tile)
-        if (wave == 0) {
-            const long long orf = c0 + lane;
-            const seg_desc_t dc = (orf >= 0 && orf < a1) ? ws.desc[orf + b] : 0;
-            const int lanes = (int)(dc >> 53) & 0xff;
+        const int lanes_i = (int)(dc >> 53) & 0xff;
+        const int incl = wave_add_scan(lanes_i);
+        const int vs_i = incl - lanes_i;
+        const int total_vl = __builtin_amdgcn_readlane(incl, kWave - 1);
+        const int vbase = wave * kWave;
+        const int vl = vbase + lane;
+        const bool pass = vbase < total_vl;  // wave-uniform
+        const bool active = vl < total_vl;
+        int q0 = 0, lim = 0, seg = 0;
+        if (pass) {
+            int *mk = s_owner + vbase;  // this wave's 64 words
+            mk[lane] = 0;
+            if (lanes_i > 0) {
+                const int tgt = vs_i - vbase;
+                if (tgt >= 0 && tgt < kWave)
+                    mk[tgt] = lane + 1;
+                else if (tgt < 0 && vs_i + lanes_i > vbase)
+                    mk[0] = lane + 1;  // the one segment that straddles into this pass
+            }
+            asm volatile("" ::: "memory");  // LDS operations of one wave complete in order
+            seg = wave_max_scan(mk[lane]) - 1;
+            if (seg < 0) seg = 0;  // (only on a malformed index: keep the lane fetches in range)
+            const unsigned dlo = (unsigned)__builtin_amdgcn_ds_bpermute(seg << 2, (int)(unsigned)dc);
+            const unsigned dhi = (unsigned)__builtin_amdgcn_ds_bpermute(seg << 2, (int)(unsigned)(dc >> 32));
+            const int vs_s = __builtin_amdgcn_ds_bpermute(seg << 2, vs_i);
+            const seg_desc_t ds = ((seg_desc_t)dhi << 32) | dlo;
+            const int r = vl - vs_s;
+            int n_run = ((int)(ds >> 26) & 0xfff) - r * kRun;
+            n_run = n_run > kRun ? kRun : n_run;
+            q0 = active ? ((int)ds & 0x1fff) + 3 * kRun * r : 0;
+            const int rem0 = ((int)(ds >> 13) & 0x1fff) - q0;
+            lim = rem0 - 2 < 3 * n_run ? rem0 - 2 : 3 * n_run;
+            if (!active) lim = 0;
+        }
+        if (wave == 0) {  // what the record stage needs, per slot
             const int part = (int)(dc >> 51) & 3;
-            s_qfirst[lane] = (int)dc & 0x1fff;
-            s_endq[lane] = (int)(dc >> 13) & 0x1fff;
-            s_ntrip[lane] = (int)(dc >> 26) & 0xfff;
+            s_vlstart[lane] = vs_i;
+            if (lane == kWave - 1) s_vlstart[kSegChunk] = incl;
             s_tail[lane] = part ? (((int)(dc >> 38) & 0x1fff) | (part << 16)) : -1;
             s_live[lane] = (int)(dc >> 63);
-            const int incl = wave_add_scan(lanes);
-            const int vs = incl - lanes;
-            s_vlstart[lane] = vs;
-            // (descriptors of a valid index never ask for more than kMaxVl lanes per chunk; an
-            // index with overlapping profiles could, and must not run the marks out of bounds)
-            if (lane == kWave - 1) s_vlstart[kSegChunk] = incl <= kMaxVl ? incl : 0;
-            if (lanes > 0 && incl <= kMaxVl) {
-                s_owner[vs] = lane + 1;
-                // every wave-pass must find its segment at its first lane
-                for (int w = (vs >> 6) + 1; (w << 6) < incl; ++w) s_owner[w << 6] = lane + 1;
-            }
         }
+        __syncthreads();  // tables and cleared accumulators are in place
+        if (pass) tile_pass(s_counts, s_ints, s_rec, q0, lim, active, seg, vl);
         __syncthreads();
-        const int total_vl = s_vlstart[kSegChunk];
-        for (int vbase = wave * kWave; vbase < total_vl; vbase += kTileBlock) {
-            const int vl = vbase + lane;
-            const bool active = vl < total_vl;
-            const int seg = wave_max_scan(s_owner[vl]) - 1;  // >= 0: lane 0 of the pass is marked
-            const int r = vl - s_vlstart[seg];
-            int n_run = s_ntrip[seg] - r * kRun;
-            n_run = n_run > kRun ? kRun : n_run;
-            const int q0 = active ? s_qfirst[seg] + 3 * kRun * r : 0;
-            const int rem0 = s_endq[seg] - q0;  // positions of the ORF from q0 on (clamped far end)
-            int lim = rem0 - 2 < 3 * n_run ? rem0 - 2 : 3 * n_run;
-            if (!active) lim = 0;
-            tile_pass(s_counts, s_ints, s_rec, q0, lim, active, seg, vl);
-        }
-        __syncthreads();
-        record_stage(s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, ws.rec, ws.n_rec, c0 + b, wave, lane);
-        // (the next chunk's clear of the scratch waits at its own barrier)
-        __syncthreads();
+        record_stage(s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, ws.rec, ws.n_rec, a0 - 1 + c0 + b, wave, lane);
     }
 }
 
@@ -951,6 +979,10 @@ __global__ __launch_bounds__(kFinishBlock) void k_orf_finish(const int32_t *__re
         const long long count_s = readlane64(count, l);
         const int min_s = __builtin_amdgcn_readlane(min_codon, l);
         const unsigned split_s = (unsigned)__builtin_amdgcn_readlane((int)split, l);
+        if (len_s > kLongWalk) {  // a whole workgroup takes it (k_rewalk_long)
+            if (lane == 0) ws.long_list[atomicAdd(ws.long_count, 1)] = orf_s;
+            continue;
+        }
         WalkResult<double> w;
         wave_walk<double>(counts + beg_s, len_s, lane, w);
         FrameScore fr2[3];
@@ -967,6 +999,82 @@ __global__ __launch_bounds__(kFinishBlock) void k_orf_finish(const int32_t *__re
         }
         if (lane == 0)
             store_orf(out, fp, orf_s, phase, valid, count_s, min_s, flags | split_s | RP_FLAG_RECHECK64, len_s);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// pass 4: the queued long too-close-to-call ORFs (rare: a handful per million), one
+// 1024-thread workgroup each -- float64 walk by all 16 waves, then, on an exact frame tie,
+// the replay of the reference's arithmetic by wave 0.  Grid-stride over the queue.
+// ---------------------------------------------------------------------------
+template <int TILE>
+__global__ __launch_bounds__(kLongBlock) void k_rewalk_long(const int32_t *__restrict__ counts,
+                                                            const int64_t *__restrict__ offsets, TilePlan plan,
+                                                            TileWorkspace ws, OrfOutputs out, FilterParams fp)
+{
+    constexpr int kWaves = kLongBlock / kWave;
+    __shared__ double s_part[kWaves][6];
+    __shared__ int s_parti[kWaves][7];
+    __shared__ long long s_partc[kWaves];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int n_long = *ws.long_count;
+    for (int e = blockIdx.x; e < n_long; e += gridDim.x) {  // workgroup-uniform
+        const long long orf = ws.long_list[e];
+        const long long beg = offsets[orf];
+        const long long len = (long long)offsets[orf + 1] - beg;
+        WalkResult<double> w;
+        wave_walk<double>(counts + beg, len, (int)threadIdx.x, w, kLongBlock);
+        // per-wave sums -> LDS -> every thread adds the partials in the same order
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const double ps = wave_sum(w.acc[f].p), qs = wave_sum(w.acc[f].q);
+            const int ns = wave_sum(w.acc[f].n), ms = wave_sum(w.acc[f].m);
+            if (lane == 0) {
+                s_part[wave][2 * f] = ps;
+                s_part[wave][2 * f + 1] = qs;
+                s_parti[wave][2 * f] = ns;
+                s_parti[wave][2 * f + 1] = ms;
+            }
+        }
+        const long long cs = wave_sum(w.count);
+        const int mins = wave_min(w.min_codon);
+        if (lane == 0) {
+            s_partc[wave] = cs;
+            s_parti[wave][6] = mins;
+        }
+        __syncthreads();
+        FrameScore fr[3];
+        long long count = 0;
+        int min_codon = RP_MIN_CODON_COV_EMPTY;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            double ps = 0.0, qs = 0.0;
+            int ns = 0, ms = 0;
+            for (int wv = 0; wv < kWaves; ++wv) {
+                ps += s_part[wv][2 * f];
+                qs += s_part[wv][2 * f + 1];
+                ns += s_parti[wv][2 * f];
+                ms += s_parti[wv][2 * f + 1];
+            }
+            fr[f] = frame_score(ps, qs, ns, ms);
+        }
+        for (int wv = 0; wv < kWaves; ++wv) {
+            count += s_partc[wv];
+            min_codon = min(min_codon, s_parti[wv][6]);
+        }
+        __syncthreads();  // the partial slots are reused by the next item
+        if (wave != 0) continue;
+        double phase;
+        int valid;
+        unsigned flags;
+        combine_frames(fr, phase, valid, flags);
+        if (flags & RP_FLAG_TIE) {
+            replay_tie_wave(counts + beg, len, lane, phase, valid);
+            flags |= RP_FLAG_REPLAY;
+        }
+        const unsigned split = (beg + plan.mis) / TILE != (beg + len - 1 + plan.mis) / TILE ? RP_FLAG_SPLIT : 0u;
+        if (lane == 0) store_orf(out, fp, orf, phase, valid, count, min_codon, flags | split | RP_FLAG_RECHECK64, len);
     }
 }
 
