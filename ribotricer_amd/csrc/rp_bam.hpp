@@ -190,6 +190,7 @@ inline int split_bam(const char *path, int protocol, const int32_t *read_lengths
     int rc = rd.read(w, 4, &eof);
     if (rc != kOk || eof || memcmp(w, "BAM\1", 4) != 0) return fail(rc != kOk ? rc : kFormat, "not a BAM file (bad magic)");
     if ((rc = rd.read(w, 4, &eof)) != kOk || eof) return fail(kFormat, "truncated header");
+    if (le32(w) > (1u << 30)) return fail(kFormat, "implausible header text length");
     std::vector<unsigned char> tmp(le32(w));
     if (!tmp.empty() && ((rc = rd.read(tmp.data(), tmp.size(), &eof)) != kOk || eof)) return fail(kFormat, "truncated header text");
     if ((rc = rd.read(w, 4, &eof)) != kOk || eof) return fail(kFormat, "truncated header");
@@ -198,6 +199,7 @@ inline int split_bam(const char *path, int protocol, const int32_t *read_lengths
     out.ref_off.assign(1, 0);
     for (uint32_t r = 0; r < n_ref; ++r) {
         if ((rc = rd.read(w, 4, &eof)) != kOk || eof) return fail(kFormat, "truncated reference list");
+        if (le32(w) == 0 || le32(w) > (1u << 16)) return fail(kFormat, "implausible reference name length");
         tmp.resize(le32(w));
         if ((rc = rd.read(tmp.data(), tmp.size(), &eof)) != kOk || eof) return fail(kFormat, "truncated reference list");
         size_t len = tmp.size();
@@ -216,6 +218,7 @@ inline int split_bam(const char *path, int protocol, const int32_t *read_lengths
         if (eof) break;
         const uint32_t block = le32(w);
         if (block < 32) return fail(kFormat, "alignment record shorter than its fixed part");
+        if (block > (1u << 28)) return fail(kFormat, "implausible alignment record length");
         rec.resize(block);
         if ((rc = rd.read(rec.data(), block, &eof)) != kOk || eof) return fail(kFormat, "truncated alignment record");
         out.total += 1;

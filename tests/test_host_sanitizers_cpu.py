@@ -1,4 +1,4 @@
-"""The host-side C++ of the library (index parser, TSV renderer) under AddressSanitizer and
+"""The host-side C++ of the library (index parser, TSV renderer, BAM reader) under AddressSanitizer and
 UBSan: GPU sanitizers are not available on the pool, so the CPU build is where memory errors
 in this code would show."""
 
@@ -25,3 +25,29 @@ def test_host_code_is_clean_under_asan_ubsan(tmp_path):
     run = subprocess.run([exe, os.path.join(GOLDEN, "g6_index.tsv")], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "parse rc=0 n=220" in run.stdout and "ok total=" in run.stdout
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_bam_reader_is_clean_under_asan_ubsan(tmp_path):
+    """rp_bam.hpp on a synthetic BAM and 1 500 truncated / corrupted copies of it."""
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(REPO, "tests", "tools"))
+    from bamwriter import write_bam
+    from test_host_frontend_cpu import make_reads
+
+    refs, reads = make_reads(np.random.default_rng(2), 1500)
+    bam = str(tmp_path / "t.bam")
+    write_bam(bam, refs, reads, block_bytes=5003)
+    exe = str(tmp_path / "san_bam")
+    build = subprocess.run(
+        ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+         "-I", os.path.join(REPO, "ribotricer_amd", "csrc"), os.path.join(REPO, "tests", "tools", "san_bam.cpp"), "-o", exe, "-lz"],
+        capture_output=True, text=True,
+    )
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([exe, bam, str(tmp_path / "mut.bam")], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "split rc=0" in run.stdout and "ok mutated:" in run.stdout
