@@ -491,30 +491,39 @@ __device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed
 // The lane run: <= kRun triplets = 3*kRun codon starts of ONE segment out of consecutive LDS
 // dwords (lane stride 3*kRun dwords, odd -> bank-conflict free), one codon of each reading
 // frame per position, fp32, no v_cmp / v_cndmask in the float part (statistics.py:67-91):
-//   d0 = a - b, d1 = b - c   exact (counts < 2^24);   q = d0^2 + d0 d1 + d1^2
+//   d0 = a - b, d1 = b - c   exact (counts < 2^24);   q = d0^2 + d0 d1 + d1^2 (+ dust, below)
 //   r  = rsq(q);   P += d0 r,  Q += d1 r          the unit vector in the oblique basis
-//   M += [q != 0],  E += [q == 0][a != 0]         N = M + E (codons that are not all-zero)
+//   S += r                                        the census of flat codons (a == b == c)
 //   frame 0 also sums the integer codon (read count, minimum codon coverage)
 // A run is walked in blocks of kRunBlock triplets, "ragged block first".  Only ONE block of a
 // lane can hold codon starts that are not the lane's to count -- the last one that holds any
 // (the run is short, or it ends the ORF and the last triplet's frame-1/2 codons reach past
-// it) -- so that block is processed FIRST, by every lane at once, with validity folded into
-// the arithmetic (vF = clamp(lim - c): r = min(rsq(q), vF), u = min(q, vF), ...; the mins
-// work on the float bit patterns).  The blocks below it are full by construction and are
+// it) -- so that block is processed FIRST, by every lane at once, with the roots of the
+// starts past `lim` multiplied by 0.  The blocks below it are full by construction and are
 // walked downwards with NO validity arithmetic at all (lanes with fewer blocks drop out
-// through EXEC): 12 VALU instructions per position + the integer codon sum, against 17 for a
-// fully masked walk.  The two look-ahead values of a block are the first two of the block
-// above it, kept in registers, so every count is read from LDS and converted exactly once.
+// through EXEC): 10 VALU instructions per position + the integer codon sum (12 in the masked
+// block).  The two look-ahead values of a block are the first two of the block above it, kept
+// in registers, so every count is read from LDS and converted exactly once.
 // ---------------------------------------------------------------------------------------
 struct RunAcc {
-    float P[3], Q[3], M[3], E[3];
-    float T[3];  // unmasked blocks: codons with q == 0 (flat, all-zero included); M = codons - T
+    float P[3], Q[3];
+    float S[3];  // sum of the reciprocal roots: the census of flat codons (see kDust*)
     unsigned cnt, mn;
 };
 
+// q is kept off zero by a "dust" folded into d0^2 that depends on the codon's first count a:
+// 2^-36 for a == 0, 2^-26 for a >= 1 (one v_med3 of the converted count).  Any q >= 1 absorbs
+// either exactly, and a flat codon (a == b == c, so d0 = d1 = 0 and its products with the root
+// vanish) gets a root that names its kind: 2^18 for an all-zero codon, 2^13 for a flat one with
+// reads.  Every other root is <= 1, so ONE running sum per frame S = 2^13 (E + 32 Z) + eps,
+// eps <= kRun, carries both counts of the lane (E, Z <= kRun < 32):  M = codons - Z - E,
+// N = codons - Z -- no per-position indicator arithmetic at all.
+constexpr float kDustZero = 0x1p-36f, kDustFlat = 0x1p-26f, kFlatUnit = 0x1p-13f;
+static_assert(kRun < 32, "the flat-codon census packs E into 5 bits per lane and frame");
+
 // One block of 3 * kRunBlock codon starts at s[0..]; (nf0, nf1) = the two values after the
-// block as floats.  MASKED: only the first `lim` starts count.  On return (nf0, nf1) are the
-// block's own first two values, for the block below.
+// block as floats.  MASKED: only the first `lim` starts count (their roots are multiplied by
+// 0 / 1).  On return (nf0, nf1) are the block's own first two values, for the block below.
 template <bool MASKED>
 __device__ __forceinline__ void run_block(const int *__restrict__ s, int lim, float &nf0, float &nf1, RunAcc &a)
 {
@@ -530,47 +539,26 @@ __device__ __forceinline__ void run_block(const int *__restrict__ s, int lim, fl
     float d[B + 1];
 #pragma unroll
     for (int c = 0; c <= B; ++c) d[c] = f[c] - f[c + 1];
-    const float limf = (float)lim;
-    if constexpr (MASKED) {
+    float sq[B];
 #pragma unroll
-        for (int c = 0; c < B; ++c) {
-            const int fr = c % 3;
-            const float qq = __builtin_fmaf(d[c], d[c] + d[c + 1], d[c + 1] * d[c + 1]);
-            const float vF = clamp01(limf - (float)c);
-            const float r = min_nonneg(__builtin_amdgcn_rsqf(qq), vF);
-            a.P[fr] = __builtin_fmaf(d[c], r, a.P[fr]);
-            a.Q[fr] = __builtin_fmaf(d[c + 1], r, a.Q[fr]);
-            const float u = min_nonneg(qq, vF);
-            a.M[fr] += u;
-            a.E[fr] = __builtin_fmaf(vF - u, min_nonneg(f[c], 1.0f), a.E[fr]);
-            if (fr == 0) {
-                const unsigned codon = (unsigned)(v[c] + v[c + 1] + v[c + 2]);
+    for (int c = 0; c < B; ++c) sq[c] = __builtin_fmaf(d[c], d[c], __builtin_amdgcn_fmed3f(f[c], kDustZero, kDustFlat));
+    const float limf = (float)lim;
+#pragma unroll
+    for (int c = 0; c < B; ++c) {
+        const int fr = c % 3;
+        const float qq = __builtin_fmaf(d[c + 1], f[c] - f[c + 2], sq[c]);  // d0^2 + d1 (d0 + d1)
+        float r = __builtin_amdgcn_rsqf(qq);  // <= 1 for q >= 1; 2^13 / 2^18 for a flat codon
+        if constexpr (MASKED) r *= clamp01(limf - (float)c);
+        a.P[fr] = __builtin_fmaf(d[c], r, a.P[fr]);
+        a.Q[fr] = __builtin_fmaf(d[c + 1], r, a.Q[fr]);
+        a.S[fr] += r;
+        if (fr == 0) {
+            const unsigned codon = (unsigned)(v[c] + v[c + 1] + v[c + 2]);
+            if constexpr (MASKED) {
                 const bool valid = c < lim;
                 a.cnt += valid ? codon : 0u;
                 a.mn = min(a.mn, valid ? codon : (unsigned)RP_MIN_CODON_COV_EMPTY);
-            }
-        }
-    } else {
-        // every codon start of the block counts: no validity arithmetic, and no clamp of the
-        // reciprocal root either -- q is kept off zero by a 2^-40 folded into d^2 (q >= 1 absorbs
-        // it exactly; for a == b == c it makes rsq finite, 2^20, and the products with d = 0
-        // vanish); that same root tells the flat codons apart: clamp(r - 2) is 1 for them, 0 else
-        constexpr float kDust = 0x1p-40f;
-        float sq[B + 1];
-#pragma unroll
-        for (int c = 0; c <= B; ++c) sq[c] = __builtin_fmaf(d[c], d[c], kDust);
-#pragma unroll
-        for (int c = 0; c < B; ++c) {
-            const int fr = c % 3;
-            const float qq = __builtin_fmaf(d[c + 1], f[c] - f[c + 2], sq[c]);  // d0^2 + d1 (d0 + d1)
-            const float r = __builtin_amdgcn_rsqf(qq);  // <= 1 for q >= 1, 2^20 for q == 0
-            a.P[fr] = __builtin_fmaf(d[c], r, a.P[fr]);
-            a.Q[fr] = __builtin_fmaf(d[c + 1], r, a.Q[fr]);
-            const float t = clamp01(r - 2.0f);          // 1 exactly for a flat codon (r = 2^20), else 0 (r <= 1)
-            a.T[fr] += t;
-            a.E[fr] = __builtin_fmaf(t, min_nonneg(f[c], 1.0f), a.E[fr]);
-            if (fr == 0) {
-                const unsigned codon = (unsigned)(v[c] + v[c + 1] + v[c + 2]);
+            } else {
                 a.cnt += codon;
                 a.mn = min(a.mn, codon);
             }
@@ -584,9 +572,10 @@ __device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, Lan
 {
     constexpr int B = 3 * kRunBlock;
     constexpr int kBlocks = (kRun + kRunBlock - 1) / kRunBlock;
+    lim = lim > 0 ? lim : 0;  // a run that starts in the last two positions of an ORF owns no codon start
     RunAcc a;
 #pragma unroll
-    for (int f = 0; f < 3; ++f) a.P[f] = a.Q[f] = a.M[f] = a.E[f] = a.T[f] = 0.f;
+    for (int f = 0; f < 3; ++f) a.P[f] = a.Q[f] = a.S[f] = 0.f;
     a.cnt = 0;
     a.mn = (unsigned)RP_MIN_CODON_COV_EMPTY;
     // last block holding a valid codon start (block 0 for an idle lane: lim == 0 masks it all)
@@ -601,21 +590,18 @@ __device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, Lan
         if (lb >= it)  // lanes whose run has fewer blocks sit this one out (EXEC)
             run_block<false>(lo + (kBlocks - 1 - it) * B, B, nf0, nf1, a);
     }
+    unsigned m[3], n[3];
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         o.p[f] = a.P[f];
         o.q[f] = a.Q[f];
+        const int k = (int)__builtin_fmaf(a.S[f], kFlatUnit, 0.5f);  // E + 32 Z
+        const int codons = ((lim + 2 - f) * 21846) >> 16;            // codon starts of frame f among the first lim (lim <= 3 kRun)
+        n[f] = (unsigned)(codons - (k >> 5));
+        m[f] = n[f] - (unsigned)(k & 31);
     }
-    // every codon of the lb unmasked blocks is a valid one: M = (masked block's M) + codons - T
-    const float full = (float)(lb * kRunBlock);
-#pragma unroll
-    for (int f = 0; f < 3; ++f) a.M[f] += full - a.T[f];
-    const unsigned m_lo = (unsigned)(int)__builtin_fmaf(a.M[1], 65536.0f, a.M[0]);
-    const unsigned m_hi = (unsigned)(int)a.M[2];
-    const unsigned n_lo = (unsigned)(int)__builtin_fmaf(a.M[1] + a.E[1], 65536.0f, a.M[0] + a.E[0]);
-    const unsigned n_hi = (unsigned)(int)(a.M[2] + a.E[2]);
-    o.mm = ((unsigned long long)m_hi << 32) | m_lo;
-    o.nn = ((unsigned long long)n_hi << 32) | n_lo;
+    o.mm = ((unsigned long long)m[2] << 32) | (m[1] << 16) | m[0];
+    o.nn = ((unsigned long long)n[2] << 32) | (n[1] << 16) | n[0];
     o.count = a.cnt;
     o.mn = a.mn;
 }
