@@ -57,7 +57,8 @@ typedef enum rp_status {
     RP_ERR_ARG = -8,       /* invalid enum / option value */
     RP_ERR_INDEX_COLUMNS = -9, /* index line without exactly 11 tab-separated fields (orf.py:143-152) */
     RP_ERR_INDEX_COORD = -10,  /* malformed "start-end,..." coordinate field */
-    RP_ERR_BAM = -11           /* BAM file cannot be opened / is not BGZF-compressed BAM / is truncated */
+    RP_ERR_BAM = -11,          /* BAM file cannot be opened / is not BGZF-compressed BAM / is truncated */
+    RP_ERR_INTERVALS = -12     /* interval table with an empty or off-array interval: no gather plan (use rp_gather_profiles_dev) */
 } rp_status;
 
 /* bits of the per-ORF flags byte */
@@ -215,6 +216,51 @@ int rp_gather_profiles_dev(int device, const int32_t *d_coverage, int64_t covera
                            const int64_t *d_orf_iv, const uint8_t *d_reverse,
                            const int64_t *d_offsets, int64_t n_orfs, int32_t *d_counts,
                            void *hip_stream);
+
+/*
+ * Gather plan (fused form): the profile space of a whole index -- every
+ * ORF's exon intervals in transcript order, '-' strand ORFs reversed (detect_orfs.py:134-203)
+ * -- as a sorted list of pieces of the dense coverage plus one fixed-stride row of clipped
+ * pieces per 7 936-position tile.  Depends on the index (interval table + the coverage layout
+ * derived from it) only: built once per index, reused for every sample.  Arguments as for
+ * rp_gather_profiles_dev; every interval must be non-empty and lie inside the coverage array
+ * (RP_ERR_INTERVALS otherwise -- rp_gather_profiles_dev handles such tables), the intervals of
+ * an ORF must add up to its profile length (RP_ERR_OFFSETS), coverage_len < 2^34.
+ * d_plan_mem: device memory of rp_gather_plan_bytes() bytes, 16-byte aligned, caller-owned,
+ * must outlive the plan.  Synchronous on hip_stream.
+ */
+typedef struct rp_gather_plan rp_gather_plan;
+int rp_gather_plan_bytes(int64_t n_orfs, int64_t n_intervals, int64_t total_nt, size_t *bytes);
+int rp_gather_plan_create_dev(int device, const int64_t *d_iv_start, const int32_t *d_iv_len,
+                              const int64_t *d_orf_iv, const uint8_t *d_reverse, const int64_t *d_offsets,
+                              int64_t n_orfs, int64_t n_intervals, int64_t total_nt, int64_t coverage_len,
+                              void *d_plan_mem, size_t plan_bytes, void *hip_stream, rp_gather_plan **out);
+void rp_gather_plan_free(rp_gather_plan *plan);
+
+/*
+ * rp_gather_profiles_dev through a gather plan: one workgroup per tile stages its positions
+ * from the coverage with LDS-DMA (64 consecutive positions of one piece per instruction) and
+ * writes them out 16 bytes per lane.  d_counts: int32[total_nt], 16-byte aligned.  Asynchronous.
+ */
+int rp_gather_profiles_plan_dev(const rp_gather_plan *plan, const int32_t *d_coverage, int64_t coverage_len,
+                                int32_t *d_counts, void *hip_stream);
+
+/*
+ * Fused gather + score (the default, non-report_all mode of detect_orfs.py:274-324, where only
+ * the translating minority's profiles are printed): rp_phase_score_csr_dev with the tiles
+ * staged straight from the dense coverage through the gather plan -- the CSR counts array is
+ * never written or read; the float64 re-walks and tie replays of the too-close-to-call ORFs
+ * read the coverage through the plan as well.  Results are bit-identical to
+ * rp_gather_profiles_dev + rp_phase_score_csr_plan_dev.  plan: the tile plan of d_offsets built
+ * with counts_phase 0 (may be NULL: built per call).  ms: NULL, or float[4] receiving HIP-event
+ * times {plan kernels, scoring kernel, finish, whole call} (then synchronous).
+ */
+int rp_phase_score_coverage_dev(int device, const int32_t *d_coverage, int64_t coverage_len,
+                                const int64_t *d_offsets, int64_t n_orfs, int64_t total_nt, double *d_phase,
+                                int32_t *d_valid, int64_t *d_read_count, int32_t *d_min_codon_cov,
+                                uint8_t *d_flags, uint8_t *d_status, const rp_filter_params *filter,
+                                void *d_workspace, size_t workspace_bytes, const rp_plan *plan,
+                                const rp_gather_plan *gather, void *hip_stream, float *ms);
 
 /*
  * Dense P-site coverage from columnar alignments: replaces the

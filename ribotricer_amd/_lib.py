@@ -25,6 +25,7 @@ FLAG_SPLIT = 0x04
 FLAG_REPLAY = 0x08
 MIN_CODON_COV_EMPTY = 2147483647
 MAX_COUNT = 16777215
+ERR_INTERVALS = -12
 
 
 class RibophaseError(RuntimeError):
@@ -69,6 +70,12 @@ SYMBOLS = {
     "rp_phase_score_frames_dev": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "rp_phase_score_f64_csr_dev": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "rp_gather_profiles_dev": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "rp_gather_plan_bytes": (_int, [_i64, _i64, _i64, ctypes.POINTER(ctypes.c_size_t)]),
+    "rp_gather_plan_create_dev": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp, ctypes.POINTER(_vp)]),
+    "rp_gather_plan_free": (None, [_vp]),
+    "rp_gather_profiles_plan_dev": (_int, [_vp, _vp, _i64, _vp, _vp]),
+    "rp_phase_score_coverage_dev": (_int, [_int, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(FilterParams),
+                                           _vp, ctypes.c_size_t, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_float * 4)]),
     "rp_validate_csr_dev": (_int, [_int, _vp, _vp, _i64, _i64, _vp]),
     "rp_metagene_dev": (_int, [_int, _vp, _vp, _i64, ctypes.c_int32, _vp, _vp, _vp, _vp]),
     "rp_coverage_build_dev": (_int, [_int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp]),
@@ -132,6 +139,12 @@ def filter_defaults() -> FilterParams:
 def plan_bytes(n_orfs: int, total_nt: int) -> int:
     out = ctypes.c_size_t(0)
     check(load().rp_plan_bytes(n_orfs, total_nt, ctypes.byref(out)))
+    return out.value
+
+
+def gather_plan_bytes(n_orfs: int, n_intervals: int, total_nt: int) -> int:
+    out = ctypes.c_size_t(0)
+    check(load().rp_gather_plan_bytes(n_orfs, n_intervals, total_nt, ctypes.byref(out)))
     return out.value
 
 

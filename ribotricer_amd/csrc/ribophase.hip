@@ -217,15 +217,28 @@ struct rp_plan {
     int *err;        // device, first word of d_plan_mem
 };
 
+// A gather plan: the profile space of an index as pieces of the dense coverage
+// (rp_pieces.hpp), built once per index from the interval table.
+struct rp_gather_plan {
+    int device;
+    long long n_orfs, n_pieces, total_nt, coverage_len, n_tiles;
+    rp::PiecePlanMem mem;  // device, caller-owned (inside d_plan_mem)
+};
+
 namespace {
 
 constexpr size_t kPlanHeader = 128;
+
+rp::PiecePlan piece_plan_of(const rp_gather_plan *g)
+{
+    return rp::PiecePlan{g->mem.start, g->mem.base, g->mem.orf_piece, g->mem.tile_piece0, g->mem.rows, g->n_pieces, g->coverage_len};
+}
 
 int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, int64_t n_orfs,
                int64_t total_nt, double *d_phase, int32_t *d_valid, int64_t *d_read_count,
                int32_t *d_min_codon_cov, uint8_t *d_flags, uint8_t *d_status,
                const rp_filter_params *filter, void *d_workspace, size_t workspace_bytes, int algo,
-               const rp_plan *plan_h, void *hip_stream, Timing *tm)
+               const rp_plan *plan_h, void *hip_stream, Timing *tm, const rp_gather_plan *gather = nullptr)
 {
     if (n_orfs < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "n_orfs=%lld total_nt=%lld must be >= 0", (long long)n_orfs, (long long)total_nt);
     if (!known_algo(algo)) return fail(RP_ERR_ARG, "unknown algo %d", algo);
@@ -247,6 +260,12 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     // AUTO: the flat-tile path, except for batches so small that its launches cost more than
     // the single wave-per-ORF launch (measured crossover ~3 M nt; scripts/bench_small.py)
     if (algo == RP_ALGO_AUTO) algo = (plan_h == nullptr && total_nt < kAutoWaveNt) ? RP_ALGO_WAVE : RP_ALGO_TILE;
+    if (gather != nullptr) {  // d_counts is the dense coverage: the tile path stages through the pieces
+        algo = RP_ALGO_TILE;
+        if (gather->device != device || gather->n_orfs != n_orfs || gather->total_nt != total_nt)
+            return fail(RP_ERR_ARG, "gather plan was built for device %d, %lld ORFs, %lld nt; called with device %d, %lld ORFs, %lld nt",
+                        gather->device, gather->n_orfs, gather->total_nt, device, (long long)n_orfs, (long long)total_nt);
+    }
 
     if (algo == RP_ALGO_WAVE) {
         if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[1], stream));
@@ -268,7 +287,7 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     if ((reinterpret_cast<uintptr_t>(d_workspace) & 15u) != 0)
         return fail(RP_ERR_WORKSPACE, "workspace must be 16-byte aligned");
     // RP_ALGO_TILE: plan tables (the caller's, or built here) -> scoring pass (segment records) -> per-ORF finish
-    const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt, rp::counts_phase(d_counts), rp::kTile);
+    const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt, gather ? 0 : rp::counts_phase(d_counts), rp::kTile);
     if (plan_h != nullptr) {
         if (plan_h->device != device || plan_h->n_orfs != n_orfs || plan_h->total_nt != total_nt)
             return fail(RP_ERR_ARG, "plan was built for device %d, %lld ORFs, %lld nt; called with device %d, %lld ORFs, %lld nt",
@@ -284,27 +303,63 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     }
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[1], stream));
     // 2. scoring pass over flat tiles: one record per (ORF, tile) segment
-    hipLaunchKernelGGL(rp::k_tile_score, dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
-                       d_counts, (long long)n_orfs, plan, ws);
+    if (gather != nullptr)
+        hipLaunchKernelGGL(rp::k_tile_score<true>, dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
+                           d_counts, (long long)n_orfs, plan, ws, piece_plan_of(gather));
+    else
+        hipLaunchKernelGGL(rp::k_tile_score<false>, dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
+                           d_counts, (long long)n_orfs, plan, ws, rp::PiecePlan{});
     RP_HIP(hipGetLastError());
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));
     // 3. one thread per ORF: add its records, score, filter, store
     {
         const int block = rp::kFinishBlock;
         const long long grid = (n_orfs + block - 1) / block;
-        hipLaunchKernelGGL(rp::k_orf_finish<rp::kTile>, dim3((unsigned)grid), dim3(block), 0, stream, d_counts,
-                           d_offsets, (long long)n_orfs, plan, ws, out, fp);
+        if (gather != nullptr)
+            hipLaunchKernelGGL((rp::k_orf_finish<rp::kTile, rp::CoverageSource>), dim3((unsigned)grid), dim3(block), 0, stream,
+                               rp::CoverageSource{d_counts, piece_plan_of(gather)}, d_offsets, (long long)n_orfs, plan, ws, out, fp);
+        else
+            hipLaunchKernelGGL((rp::k_orf_finish<rp::kTile, rp::CsrSource>), dim3((unsigned)grid), dim3(block), 0, stream,
+                               rp::CsrSource{d_counts}, d_offsets, (long long)n_orfs, plan, ws, out, fp);
         RP_HIP(hipGetLastError());
         // 4. the long too-close-to-call ORFs it queued (usually none): a workgroup each
         if (total_nt > rp::kLongWalk) {
             const long long cap = rp::long_capacity(total_nt);
-            hipLaunchKernelGGL(rp::k_rewalk_long<rp::kTile>, dim3((unsigned)(cap < 512 ? cap : 512)), dim3(rp::kLongBlock), 0,
-                               stream, d_counts, d_offsets, plan, ws, out, fp);
+            const dim3 lgrid((unsigned)(cap < 512 ? cap : 512));
+            if (gather != nullptr)
+                hipLaunchKernelGGL((rp::k_rewalk_long<rp::kTile, rp::CoverageSource>), lgrid, dim3(rp::kLongBlock), 0, stream,
+                                   rp::CoverageSource{d_counts, piece_plan_of(gather)}, d_offsets, plan, ws, out, fp);
+            else
+                hipLaunchKernelGGL((rp::k_rewalk_long<rp::kTile, rp::CsrSource>), lgrid, dim3(rp::kLongBlock), 0, stream,
+                                   rp::CsrSource{d_counts}, d_offsets, plan, ws, out, fp);
             RP_HIP(hipGetLastError());
         }
     }
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[3], stream));
     return RP_OK;
+}
+
+// score with HIP events around the phases: ms = {plan kernels, scoring kernel, finish, whole call}
+template <typename Call>
+int run_timed(int device, float ms[4], Call &&call)
+{
+    RP_ON_DEVICE(device);
+    Timing tm;
+    tm.on = true;
+    for (int k = 0; k < 4; ++k) RP_HIP(hipEventCreate(&tm.ev[k]));
+    int rc = call(&tm);
+    if (rc == RP_OK) {
+        hipError_t e = hipEventSynchronize(tm.ev[3]);
+        if (e != hipSuccess) rc = fail(RP_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
+    }
+    if (rc == RP_OK) {
+        (void)hipEventElapsedTime(&ms[0], tm.ev[0], tm.ev[1]);
+        (void)hipEventElapsedTime(&ms[1], tm.ev[1], tm.ev[2]);
+        (void)hipEventElapsedTime(&ms[2], tm.ev[2], tm.ev[3]);
+        (void)hipEventElapsedTime(&ms[3], tm.ev[0], tm.ev[3]);
+    }
+    for (int k = 0; k < 4; ++k) (void)hipEventDestroy(tm.ev[k]);
+    return rc;
 }
 
 }  // namespace
@@ -338,6 +393,7 @@ const char *rp_status_string(int status)
         case RP_ERR_INDEX_COLUMNS: return "index line: unexpected number of columns";
         case RP_ERR_INDEX_COORD: return "index line: malformed coordinate";
         case RP_ERR_BAM: return "unreadable BAM file";
+        case RP_ERR_INTERVALS: return "interval table cannot be planned";
         default: return "unknown status";
     }
 }
@@ -459,25 +515,11 @@ int rp_phase_score_csr_dev_timed(int device, const int32_t *d_counts, const int6
                                  void *hip_stream, float ms[4])
 {
     if (!ms) return fail(RP_ERR_NULL, "ms is null");
-    RP_ON_DEVICE(device);
-    Timing tm;
-    tm.on = true;
-    for (int k = 0; k < 4; ++k) RP_HIP(hipEventCreate(&tm.ev[k]));
-    int rc = score_impl(device, d_counts, d_offsets, n_orfs, total_nt, d_phase, d_valid, d_read_count,
-                        d_min_codon_cov, d_flags, d_status, filter, d_workspace, workspace_bytes, algo,
-                        plan, hip_stream, &tm);
-    if (rc == RP_OK) {
-        hipError_t e = hipEventSynchronize(tm.ev[3]);
-        if (e != hipSuccess) rc = fail(RP_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(e));
-    }
-    if (rc == RP_OK) {
-        (void)hipEventElapsedTime(&ms[0], tm.ev[0], tm.ev[1]);
-        (void)hipEventElapsedTime(&ms[1], tm.ev[1], tm.ev[2]);
-        (void)hipEventElapsedTime(&ms[2], tm.ev[2], tm.ev[3]);
-        (void)hipEventElapsedTime(&ms[3], tm.ev[0], tm.ev[3]);
-    }
-    for (int k = 0; k < 4; ++k) (void)hipEventDestroy(tm.ev[k]);
-    return rc;
+    return run_timed(device, ms, [&](Timing *tm) {
+        return score_impl(device, d_counts, d_offsets, n_orfs, total_nt, d_phase, d_valid, d_read_count,
+                          d_min_codon_cov, d_flags, d_status, filter, d_workspace, workspace_bytes, algo,
+                          plan, hip_stream, tm);
+    });
 }
 
 int rp_phase_score_frames_dev(int device, const int32_t *d_counts, const int64_t *d_offsets,
@@ -531,6 +573,102 @@ int rp_gather_profiles_dev(int device, const int32_t *d_coverage, int64_t covera
                        d_offsets, (long long)n_orfs, d_counts);
     RP_HIP(hipGetLastError());
     return RP_OK;
+}
+
+int rp_gather_plan_bytes(int64_t n_orfs, int64_t n_intervals, int64_t total_nt, size_t *bytes)
+{
+    if (!bytes) return fail(RP_ERR_NULL, "bytes is null");
+    if (n_orfs < 0 || n_intervals < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "negative size");
+    const rp::TilePlan tp = rp::make_tile_plan(n_orfs, total_nt, 0, rp::kTile);
+    *bytes = kPlanHeader + rp::piece_plan_bytes(n_orfs, n_intervals, tp.n_tiles);
+    return RP_OK;
+}
+
+int rp_gather_plan_create_dev(int device, const int64_t *d_iv_start, const int32_t *d_iv_len,
+                              const int64_t *d_orf_iv, const uint8_t *d_reverse, const int64_t *d_offsets,
+                              int64_t n_orfs, int64_t n_intervals, int64_t total_nt, int64_t coverage_len,
+                              void *d_plan_mem, size_t plan_bytes, void *hip_stream, rp_gather_plan **out)
+{
+    if (!out) return fail(RP_ERR_NULL, "out is null");
+    *out = nullptr;
+    if (n_orfs < 0 || n_intervals < 0 || total_nt < 0 || coverage_len < 0) return fail(RP_ERR_SIZE, "negative size");
+    if (coverage_len >= rp::kMaxCoverage) return fail(RP_ERR_SIZE, "coverage of %lld positions: the piece rows index at most 2^34", (long long)coverage_len);
+    if (!d_orf_iv || !d_offsets || !d_plan_mem || (n_orfs > 0 && !d_reverse) || (n_intervals > 0 && (!d_iv_start || !d_iv_len)))
+        return fail(RP_ERR_NULL, "interval table, strand flags, offsets and plan memory must be non-null");
+    size_t need = 0;
+    int rc = rp_gather_plan_bytes(n_orfs, n_intervals, total_nt, &need);
+    if (rc != RP_OK) return rc;
+    if (plan_bytes < need) return fail(RP_ERR_WORKSPACE, "gather plan memory of %zu bytes required, got %zu", need, plan_bytes);
+    if ((reinterpret_cast<uintptr_t>(d_plan_mem) & 15u) != 0) return fail(RP_ERR_WORKSPACE, "plan memory must be 16-byte aligned");
+    RP_ON_DEVICE(device);
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const rp::TilePlan tp = rp::make_tile_plan(n_orfs, total_nt, 0, rp::kTile);
+    int *d_err = reinterpret_cast<int *>(d_plan_mem);
+    const rp::PiecePlanMem mem = rp::carve_piece_plan(reinterpret_cast<char *>(d_plan_mem) + kPlanHeader, n_orfs, n_intervals, tp.n_tiles);
+    RP_HIP(hipMemsetAsync(d_err, 0, kPlanHeader, stream));
+    {
+        const int block = 256;
+        const long long grid = (n_orfs + 1 + block - 1) / block;
+        hipLaunchKernelGGL(rp::k_piece_build, dim3((unsigned)grid), dim3(block), 0, stream, d_iv_start, d_iv_len, d_orf_iv,
+                           d_reverse, d_offsets, (long long)n_orfs, (long long)n_intervals, (long long)total_nt,
+                           (long long)coverage_len, mem, d_err);
+        RP_HIP(hipGetLastError());
+    }
+    int h_err = 0;
+    RP_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    RP_HIP(hipStreamSynchronize(stream));
+    if (h_err & 1) return fail(RP_ERR_OFFSETS, "the intervals of an ORF do not add up to its profile length (or orf_iv is not a CSR index of the intervals)");
+    if (h_err & 2) return fail(RP_ERR_INTERVALS, "an interval is empty or reaches outside the coverage array: not plannable (rp_gather_profiles_dev reads such positions as 0)");
+    hipLaunchKernelGGL((rp::k_piece_rows<rp::kTile, rp::kHalo>), dim3((unsigned)tp.n_tiles), dim3(rp::kRowPieces), 0, stream, mem,
+                       (long long)n_intervals, (long long)total_nt);
+    RP_HIP(hipGetLastError());
+    RP_HIP(hipStreamSynchronize(stream));
+    rp_gather_plan *h = new (std::nothrow) rp_gather_plan;
+    if (!h) return fail(RP_ERR_SIZE, "out of memory");
+    h->device = device;
+    h->n_orfs = n_orfs;
+    h->n_pieces = n_intervals;
+    h->total_nt = total_nt;
+    h->coverage_len = coverage_len;
+    h->n_tiles = tp.n_tiles;
+    h->mem = mem;
+    *out = h;
+    return RP_OK;
+}
+
+void rp_gather_plan_free(rp_gather_plan *plan) { delete plan; }
+
+int rp_gather_profiles_plan_dev(const rp_gather_plan *plan, const int32_t *d_coverage, int64_t coverage_len,
+                                int32_t *d_counts, void *hip_stream)
+{
+    if (!plan) return fail(RP_ERR_NULL, "plan is null");
+    if (coverage_len != plan->coverage_len) return fail(RP_ERR_ARG, "plan was built for a coverage of %lld positions, got %lld", plan->coverage_len, (long long)coverage_len);
+    if (plan->total_nt == 0) return RP_OK;
+    if (!d_coverage || !d_counts) return fail(RP_ERR_NULL, "d_coverage / d_counts is null");
+    if ((reinterpret_cast<uintptr_t>(d_counts) & 15u) != 0) return fail(RP_ERR_ARG, "d_counts must be 16-byte aligned");
+    RP_ON_DEVICE(plan->device);
+    hipLaunchKernelGGL((rp::k_tile_gather<rp::kTile, rp::kHalo>), dim3((unsigned)plan->n_tiles), dim3(rp::kGatherTileBlock), 0,
+                       (hipStream_t)hip_stream, d_coverage, piece_plan_of(plan), plan->total_nt, d_counts);
+    RP_HIP(hipGetLastError());
+    return RP_OK;
+}
+
+int rp_phase_score_coverage_dev(int device, const int32_t *d_coverage, int64_t coverage_len,
+                                const int64_t *d_offsets, int64_t n_orfs, int64_t total_nt, double *d_phase,
+                                int32_t *d_valid, int64_t *d_read_count, int32_t *d_min_codon_cov,
+                                uint8_t *d_flags, uint8_t *d_status, const rp_filter_params *filter,
+                                void *d_workspace, size_t workspace_bytes, const rp_plan *plan,
+                                const rp_gather_plan *gather, void *hip_stream, float *ms)
+{
+    if (!gather) return fail(RP_ERR_NULL, "gather plan is null");
+    if (coverage_len != gather->coverage_len) return fail(RP_ERR_ARG, "gather plan was built for a coverage of %lld positions, got %lld", gather->coverage_len, (long long)coverage_len);
+    if (ms)
+        return run_timed(device, ms, [&](Timing *tm) {
+            return score_impl(device, d_coverage, d_offsets, n_orfs, total_nt, d_phase, d_valid, d_read_count, d_min_codon_cov,
+                              d_flags, d_status, filter, d_workspace, workspace_bytes, RP_ALGO_TILE, plan, hip_stream, tm, gather);
+        });
+    return score_impl(device, d_coverage, d_offsets, n_orfs, total_nt, d_phase, d_valid, d_read_count, d_min_codon_cov,
+                      d_flags, d_status, filter, d_workspace, workspace_bytes, RP_ALGO_TILE, plan, hip_stream, nullptr, gather);
 }
 
 int rp_coverage_build_dev(int device, const int32_t *d_group, const int64_t *d_pos, const int32_t *d_count,

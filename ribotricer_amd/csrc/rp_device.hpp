@@ -370,7 +370,8 @@ __device__ __forceinline__ void replay_codon_terms(int a, int b, int c, double &
 // One wave, one ORF.  Lane t takes triplets t, t + 64, ...: five counts give it one codon of
 // each reading frame (one pass over the profile for all three frames); the per-frame sums are
 // then folded in codon order, wave-uniform, exactly as numpy folds them.
-__device__ __forceinline__ void replay_tie_wave(const int32_t *__restrict__ v, long long len, int lane,
+template <typename Counts>
+__device__ __forceinline__ void replay_tie_wave(Counts v, long long len, int lane,
                                              double &phase, int &valid)
 {
     constexpr double kPyySeg = 0x1.5555555555555p-1;

@@ -314,6 +314,10 @@ struct SegInts {
     unsigned pad;
 };
 
+}  // namespace rp
+#include "rp_pieces.hpp"
+namespace rp {
+
 // Stage positions [t0, t0 + kTile + kHalo) into LDS.  (counts + t0) is 16-byte aligned.
 // Interior tiles use the LDS-DMA form of global_load (no VGPR round trip, one instruction
 // per KiB row, rows dealt round-robin to the four waves); the first / last tile take the
@@ -715,9 +719,12 @@ __device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, c
     rec[wave * n_rec + id0 + seg] = out;
 }
 
+// FUSED: `counts` is the dense coverage and the tile is staged through the piece plan
+// (rp_pieces.hpp) -- the profiles never exist in HBM (plan.mis == 0 there).
+template <bool FUSED>
 __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const int32_t *__restrict__ counts,
                                                            long long n_orfs, TilePlan plan,
-                                                           TileWorkspace ws)
+                                                           TileWorkspace ws, PiecePlan pp)
 {
     __shared__ __attribute__((aligned(16))) int s_counts[kLdsCounts];
     __shared__ int s_live[kSegChunk];     // the slot holds a segment of this tile
@@ -752,7 +759,13 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
                      : "v"(src), "v"(msrc)
                      : "memory");
     }
-    load_tile_to_lds(counts, t0, plan.total_nt, s_counts, tid);
+    if constexpr (FUSED) {
+        // every wave stages a quarter of the tile's pieces; the piece row arrives with the head row
+        const uint4 prow = *piece_row_ptr(pp, b, lane);
+        stage_tile<kTile, kHalo>(counts, pp, b, plan.total_nt, prow, s_counts, lane, wave);
+    } else {
+        load_tile_to_lds(counts, t0, plan.total_nt, s_counts, tid);
+    }
     if (wave == 0) {  // the integer accumulators of the 64 slots (before anyone's atomics: barrier 1)
         s_ints[lane].nn = 0;
         s_ints[lane].mm = 0;
@@ -900,8 +913,8 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
 // ---------------------------------------------------------------------------
 constexpr int kFinishBlock = kWave;  // one wave per workgroup: a re-walk holds up nobody else
 
-template <int TILE>
-__global__ __launch_bounds__(kFinishBlock) void k_orf_finish(const int32_t *__restrict__ counts,
+template <int TILE, typename Source>
+__global__ __launch_bounds__(kFinishBlock) void k_orf_finish(Source source,
                                                              const int64_t *__restrict__ offsets,
                                                              long long n_orfs, TilePlan plan,
                                                              TileWorkspace ws, OrfOutputs out,
@@ -970,7 +983,7 @@ __global__ __launch_bounds__(kFinishBlock) void k_orf_finish(const int32_t *__re
             continue;
         }
         WalkResult<double> w;
-        wave_walk<double>(counts + beg_s, len_s, lane, w);
+        wave_walk<double>(source.orf(orf_s, beg_s), len_s, lane, w);
         FrameScore fr2[3];
 #pragma unroll
         for (int f = 0; f < 3; ++f)
@@ -980,7 +993,7 @@ __global__ __launch_bounds__(kFinishBlock) void k_orf_finish(const int32_t *__re
         unsigned flags;
         combine_frames(fr2, phase, valid, flags);
         if (flags & RP_FLAG_TIE) {
-            replay_tie_wave(counts + beg_s, len_s, lane, phase, valid);
+            replay_tie_wave(source.orf(orf_s, beg_s), len_s, lane, phase, valid);
             flags |= RP_FLAG_REPLAY;
         }
         if (lane == 0)
@@ -993,8 +1006,8 @@ __global__ __launch_bounds__(kFinishBlock) void k_orf_finish(const int32_t *__re
 // 1024-thread workgroup each -- float64 walk by all 16 waves, then, on an exact frame tie,
 // the replay of the reference's arithmetic by wave 0.  Grid-stride over the queue.
 // ---------------------------------------------------------------------------
-template <int TILE>
-__global__ __launch_bounds__(kLongBlock) void k_rewalk_long(const int32_t *__restrict__ counts,
+template <int TILE, typename Source>
+__global__ __launch_bounds__(kLongBlock) void k_rewalk_long(Source source,
                                                             const int64_t *__restrict__ offsets, TilePlan plan,
                                                             TileWorkspace ws, OrfOutputs out, FilterParams fp)
 {
@@ -1010,7 +1023,7 @@ __global__ __launch_bounds__(kLongBlock) void k_rewalk_long(const int32_t *__res
         const long long beg = offsets[orf];
         const long long len = (long long)offsets[orf + 1] - beg;
         WalkResult<double> w;
-        wave_walk<double>(counts + beg, len, (int)threadIdx.x, w, kLongBlock);
+        wave_walk<double>(source.orf(orf, beg), len, (int)threadIdx.x, w, kLongBlock);
         // per-wave sums -> LDS -> every thread adds the partials in the same order
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
@@ -1056,7 +1069,7 @@ __global__ __launch_bounds__(kLongBlock) void k_rewalk_long(const int32_t *__res
         unsigned flags;
         combine_frames(fr, phase, valid, flags);
         if (flags & RP_FLAG_TIE) {
-            replay_tie_wave(counts + beg, len, lane, phase, valid);
+            replay_tie_wave(source.orf(orf, beg), len, lane, phase, valid);
             flags |= RP_FLAG_REPLAY;
         }
         const unsigned split = (beg + plan.mis) / TILE != (beg + len - 1 + plan.mis) / TILE ? RP_FLAG_SPLIT : 0u;

@@ -23,8 +23,9 @@ struct WalkResult {
 
 // Walk ORF [v, v+len): this thread takes triplets first, first + stride, ...  (a wave
 // passes lane / 64, a whole workgroup tid / 256); int32 counts.
-template <typename Real>
-__device__ __forceinline__ void wave_walk(const int32_t *v, long long len, int first,
+// (`v` is anything indexable by ORF position: the CSR pointer, or a view of the coverage.)
+template <typename Real, typename Counts>
+__device__ __forceinline__ void wave_walk(Counts v, long long len, int first,
                                           WalkResult<Real> &w, int stride = kWave)
 {
     acc_clear(w.acc);

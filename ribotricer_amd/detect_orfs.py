@@ -158,10 +158,11 @@ def gather_profiles_indexed(index, merged_alignments, device=None):
     per-key Python beyond the one conversion pass when ``merged_alignments`` still is the
     reference's ``strand -> Counter``."""
     from .alignments import build_coverage_device
-    from .gather import gather_profiles_device, interval_table_from_index
+    from .gather import gather_profiles_device, interval_table_from_index, make_gather_plan
 
     coverage, base = build_coverage_device(merged_alignments, index, device)
-    return gather_profiles_device(coverage, interval_table_from_index(index, base), device)
+    table = interval_table_from_index(index, base)
+    return gather_profiles_device(coverage, table, device, plan=make_gather_plan(table, coverage.numel(), device))
 
 
 def _devices_from_env():
@@ -262,28 +263,69 @@ def export_orf_coverages(
     ``strand -> Counter{(chrom, pos): count}`` or this package's columnar
     ``alignments.MergedColumns`` (``alignments.merge_read_lengths``).
 
-    index text -> ``rp_index_parse_host`` (f3) -> interval table -> ``rp_gather_profiles_dev``
-    (f1) -> ``rp_phase_score_csr_dev`` -> ``rp_format_rows_host`` (f2): no per-ORF Python."""
+    index text -> ``rp_index_parse_host`` (f3) -> interval table + gather plan -> (f1, fused:
+    :func:`score_index`) ``rp_phase_score_coverage_dev`` -> ``rp_format_rows_host`` (f2): no
+    per-ORF Python."""
     from . import tsv
     from .index import NativeIndex
 
     index = NativeIndex.from_file(ribotricer_index)
-    # profiles are gathered and scored on the GPU; they come back once for the profile column
     if devices is None:
         devices = _devices_from_env()
-    d_counts, d_offsets = gather_profiles_indexed(index, merged_alignments, None if not devices else f"cuda:{int(devices[0])}")
-    res = score_profiles(
-        d_counts, d_offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
-        min_valid_codons_ratio, min_density_over_orf, devices=devices,
+    counts, offsets, res = score_index(
+        index, merged_alignments, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
+        min_valid_codons_ratio, min_density_over_orf, report_all, devices,
     )
-    counts = d_counts.cpu().numpy()
-    offsets = d_offsets.cpu().numpy()
     with open(f"{prefix}_translating_ORFs.tsv", "wb") as output:
         output.write(("\t".join(COLUMNS) + "\n").encode("utf-8"))
         for chunk in tsv.format_rows_native(
             counts, offsets, res["phase"], res["valid"], res["read_count"], res["status"], index.tables, report_all
         ):
             output.write(chunk)
+
+
+def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
+                min_valid_codons_ratio, min_density_over_orf, report_all: bool, devices=None):
+    """Gather + score for a natively parsed index: ``(counts, offsets, results)`` as host arrays,
+    ready for the row formatter.
+
+    ``report_all`` (every profile is printed, detect_orfs.py:301-324): the whole CSR counts array
+    is gathered (tile kernel through the index's gather plan), scored, copied back.  Default mode
+    (only the translating ORFs are printed): gather and score are FUSED -- the scorer stages its
+    tiles straight from the dense coverage (``rp_phase_score_coverage_dev``), the profiles are
+    never written to HBM -- and only the translating ORFs' profiles are gathered afterwards;
+    ``offsets`` then gives every other ORF an empty range."""
+    import numpy as np
+    import torch
+
+    from .alignments import build_coverage_device
+    from .gather import gather_profiles_device, interval_table_from_index, make_gather_plan, select_orfs
+
+    device = None if not devices else f"cuda:{int(devices[0])}"
+    coverage, base = build_coverage_device(merged_alignments, index, device)
+    table = interval_table_from_index(index, base)
+    plan = make_gather_plan(table, coverage.numel(), device)
+    sharded = devices is not None and len(devices) > 1
+    if plan is None or report_all or sharded:
+        d_counts, d_offsets = gather_profiles_device(coverage, table, device, plan=plan)
+        res = score_profiles(
+            d_counts, d_offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
+            min_valid_codons_ratio, min_density_over_orf, device=device, devices=devices,
+        )
+        return d_counts.cpu().numpy(), d_offsets.cpu().numpy(), res
+    eng = get_engine(device)
+    thresholds = make_filter(
+        phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio, min_density_over_orf
+    )
+    res = eng.score_coverage(coverage, plan, thresholds=thresholds)
+    torch.cuda.synchronize(eng.device)
+    res = res.cpu_numpy()
+    keep = res["status"] != 0
+    chosen = np.flatnonzero(keep)
+    d_counts, _ = gather_profiles_device(coverage, select_orfs(table, chosen), device)
+    offsets = np.zeros(index.n_orfs + 1, np.int64)
+    np.cumsum(np.where(keep, np.diff(table.offsets), 0), out=offsets[1:])
+    return d_counts.cpu().numpy(), offsets, res
 
 
 def export_wig(merged_alignments, prefix: str) -> None:

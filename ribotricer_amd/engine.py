@@ -276,6 +276,44 @@ class PhaseScoreEngine:
             _lib.check(lib.rp_phase_score_csr_dev(dev.index, _ptr(counts), _ptr(offsets), n, total_nt, *outputs, filt, *ws_args, algo_id, stream))
         return out
 
+    def score_coverage(
+        self,
+        coverage,
+        gather_plan,
+        thresholds: Optional[FilterParams] = None,
+        reuse_outputs: bool = False,
+        timings: Optional[list] = None,
+    ) -> PhaseScores:
+        """Fused gather + score (``rp_phase_score_coverage_dev``): every ORF of the index behind
+        ``gather_plan`` (:class:`ribotricer_amd.gather.GatherPlan`) scored straight from the dense
+        coverage -- the CSR counts array of detect_orfs.py:134-203 is never materialised.  Same
+        results, bit for bit, as ``gather_profiles_device`` + :meth:`score`."""
+        dev = self.device
+        if gather_plan.device != dev:
+            raise ValueError("gather plan belongs to another device")
+        coverage = _as_device(coverage, torch.int32, dev)
+        offsets = gather_plan.offsets
+        n, total_nt = gather_plan.n_orfs, gather_plan.total_nt
+        plan = self.plan_for(offsets, total_nt, 0) if n > 0 else None
+        stream_obj = torch.cuda.current_stream(dev)
+        stream_key = int(stream_obj.cuda_stream)
+        ws = self._get_workspace(_lib.workspace_bytes(n, total_nt, _lib.RP_ALGO_TILE), stream_key)
+        with_status = thresholds is not None
+        out = self._get_outputs(n, with_status, stream_key) if reuse_outputs else _alloc_outputs(dev, n, with_status)
+        outputs = [_ptr(out.phase), _ptr(out.valid), _ptr(out.read_count), _ptr(out.min_codon_cov), _ptr(out.flags), _ptr(out.status)]
+        filt = ctypes.byref(thresholds) if thresholds is not None else None
+        ms = (ctypes.c_float * 4)() if timings is not None else None
+        _lib.check(
+            _lib.load().rp_phase_score_coverage_dev(
+                dev.index, _ptr(coverage), coverage.numel(), _ptr(offsets), n, total_nt, *outputs, filt,
+                _ptr(ws), 0 if ws is None else ws.numel(), plan.handle if plan is not None else None,
+                gather_plan.handle, ctypes.c_void_p(stream_key), ctypes.byref(ms) if ms is not None else None,
+            )
+        )
+        if timings is not None:
+            timings.append([float(x) for x in ms])
+        return out
+
     def score_sharded(self, counts, offsets, devices, thresholds: Optional[FilterParams] = None, algo: str = "auto") -> dict:
         """See :func:`score_sharded` (this engine's device is not special)."""
         return score_sharded(counts, offsets, devices, thresholds=thresholds, algo=algo)

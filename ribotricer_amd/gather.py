@@ -172,8 +172,85 @@ def interval_table_from_index(index, base) -> IntervalTable:
     return IntervalTable(iv_start, iv_len, index.orf_iv.copy(), index.reverse.copy(), offsets)
 
 
-def gather_profiles_device(coverage, table: IntervalTable, device=None):
-    """Run the gather on the GPU: ``(counts int32 device tensor, offsets int64 device tensor)``."""
+class GatherPlan:
+    """A gather plan (``rp_gather_plan``): the profile space of an index as pieces of the dense
+    coverage, one fixed-stride row of clipped pieces per tile.  Depends on the interval table
+    (index + coverage layout) only -- built once per index, reused for every sample.  Owns its
+    device memory.  Raises ``RibophaseError`` with status ``_lib.ERR_INTERVALS`` for a table with
+    an empty or off-array interval (the per-ORF kernel behind :func:`gather_profiles_device`
+    handles those)."""
+
+    def __init__(self, table: IntervalTable, coverage_len: int, device=None):
+        dev = get_engine(device).device
+        self.device = dev
+        self.n_orfs = int(len(table.offsets) - 1)
+        self.n_intervals = int(len(table.iv_start))
+        self.total_nt = int(table.offsets[-1])
+        self.coverage_len = int(coverage_len)
+        self.offsets = _as_device(table.offsets, torch.int64, dev)
+        iv_start = _as_device(table.iv_start, torch.int64, dev)
+        iv_len = _as_device(table.iv_len, torch.int32, dev)
+        orf_iv = _as_device(table.orf_iv, torch.int64, dev)
+        reverse = _as_device(table.reverse, torch.uint8, dev)
+        self._mem = torch.empty(_lib.gather_plan_bytes(self.n_orfs, self.n_intervals, self.total_nt), dtype=torch.uint8, device=dev)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        handle = ctypes.c_void_p(0)
+        _lib.check(
+            _lib.load().rp_gather_plan_create_dev(
+                dev.index, _ptr(iv_start), _ptr(iv_len), _ptr(orf_iv), _ptr(reverse), _ptr(self.offsets), self.n_orfs,
+                self.n_intervals, self.total_nt, self.coverage_len, _ptr(self._mem), self._mem.numel(), stream,
+                ctypes.byref(handle),
+            )
+        )
+        self.handle = handle
+
+    def gather(self, coverage) -> torch.Tensor:
+        """The CSR counts array of the whole index (``rp_gather_profiles_plan_dev``)."""
+        cov = _as_device(coverage, torch.int32, self.device)
+        counts = torch.empty(self.total_nt, dtype=torch.int32, device=self.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(_lib.load().rp_gather_profiles_plan_dev(self.handle, _ptr(cov), cov.numel(), _ptr(counts), stream))
+        return counts
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                _lib.load().rp_gather_plan_free(h)
+            except Exception:  # pragma: no cover - interpreter shutdown
+                pass
+
+
+def make_gather_plan(table: IntervalTable, coverage_len: int, device=None):
+    """:class:`GatherPlan`, or None when the table cannot be planned (an interval hangs off the
+    coverage array: the per-ORF kernel reads such positions as 0)."""
+    try:
+        return GatherPlan(table, coverage_len, device)
+    except _lib.RibophaseError as e:
+        if e.status == _lib.ERR_INTERVALS:
+            return None
+        raise
+
+
+def select_orfs(table: IntervalTable, orf_ids: np.ndarray) -> IntervalTable:
+    """The interval table of a subset of the ORFs (in the given order), offsets re-packed."""
+    orf_ids = np.asarray(orf_ids, np.int64)
+    k0, k1 = table.orf_iv[orf_ids], table.orf_iv[orf_ids + 1]
+    nk = k1 - k0
+    orf_iv = np.zeros(orf_ids.size + 1, np.int64)
+    np.cumsum(nk, out=orf_iv[1:])
+    pick = np.repeat(k0 - orf_iv[:-1], nk) + np.arange(int(orf_iv[-1]), dtype=np.int64)
+    lengths = table.offsets[orf_ids + 1] - table.offsets[orf_ids]
+    offsets = np.zeros(orf_ids.size + 1, np.int64)
+    np.cumsum(lengths, out=offsets[1:])
+    return IntervalTable(table.iv_start[pick], table.iv_len[pick], orf_iv, table.reverse[orf_ids], offsets)
+
+
+def gather_profiles_device(coverage, table: IntervalTable, device=None, plan=None):
+    """Run the gather on the GPU: ``(counts int32 device tensor, offsets int64 device tensor)``.
+    With a :class:`GatherPlan` of the same table: the tile kernel; otherwise one wave per ORF."""
+    if plan is not None:
+        return plan.gather(coverage), plan.offsets
     eng = get_engine(device)
     dev = eng.device
     cov = _as_device(coverage, torch.int32, dev)

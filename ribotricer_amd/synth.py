@@ -7,6 +7,9 @@ cfg2  1 M ORFs, L = 3*k, k = max(20, round(lognormal(ln 80, 0.7)))  (mean ~300 n
 cfg3  11 M ORFs, sigma = 0.9, 1 % of the ORFs with L % 3 != 0 (incomplete CDS).
 cfg5  long-tail stress: lognormal body (mean ~100 codons) + Pareto(1.5) tail clipped
       at 33 333 codons (100 k nt).
+gencode  a candidate-index-like law (prepare_orfs.py:217 emits every uORF / dORF / overlapping
+      ORF >= --min_orf_length, cli.py:64-69): 60 % of the ORFs short, uniform 20..50 codons
+      (60-150 nt), the rest cfg3's lognormal with median 120 codons.
 
 Lengths always come from numpy (identical on every machine for a given seed).  Counts
 come from numpy on the host (tests: the oracle and the GPU must see the same bytes) or
@@ -21,6 +24,7 @@ CONFIGS = {
     "cfg2": dict(sigma=0.7, median_codons=80, frac_non_mult3=0.0, pareto_frac=0.0),
     "cfg3": dict(sigma=0.9, median_codons=80, frac_non_mult3=0.01, pareto_frac=0.0),
     "cfg5": dict(sigma=0.7, median_codons=78, frac_non_mult3=0.01, pareto_frac=0.02),
+    "gencode": dict(sigma=0.9, median_codons=120, frac_non_mult3=0.01, pareto_frac=0.0, short_frac=0.6),
 }
 LAMBDAS = np.array([0.0, 0.05, 0.3, 2.0])
 LAMBDA_P = np.array([0.2, 0.3, 0.3, 0.2])
@@ -34,6 +38,9 @@ def orf_lengths(n_orfs: int, seed: int, cfg: str = "cfg2") -> np.ndarray:
     if c["pareto_frac"] > 0:
         tail = rng.random(n_orfs) < c["pareto_frac"]
         k[tail] = 300.0 * (1.0 + rng.pareto(1.5, size=int(tail.sum())))
+    if c.get("short_frac", 0.0) > 0:
+        short = rng.random(n_orfs) < c["short_frac"]
+        k[short] = rng.integers(20, 51, size=int(short.sum()))
     k = np.clip(k, 20, MAX_CODONS).astype(np.int64)
     lengths = 3 * k
     if c["frac_non_mult3"] > 0:

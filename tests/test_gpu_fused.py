@@ -1,0 +1,145 @@
+"""The gather plan (rp_pieces.hpp): the tile gather against the per-ORF gather and a numpy
+restatement of orf_coverage (detect_orfs.py:134-203), and the fused gather + score against
+gather-then-score -- which must agree bit for bit, ties and float64 re-walks included."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def random_table(rng, n, cov_len, max_exons=6, exon_len=(1, 400), special=()):
+    """IntervalTable with every interval inside [0, cov_len)."""
+    from ribotricer_amd.gather import IntervalTable
+
+    n_iv = rng.integers(1, max_exons + 1, size=n)
+    for i, k in special:
+        n_iv[i] = k
+    orf_iv = np.concatenate([[0], np.cumsum(n_iv)]).astype(np.int64)
+    iv_len = rng.integers(exon_len[0], exon_len[1] + 1, size=int(orf_iv[-1])).astype(np.int32)
+    iv_start = rng.integers(0, cov_len - exon_len[1] - 1, size=int(orf_iv[-1])).astype(np.int64)
+    reverse = rng.integers(0, 2, size=n).astype(np.uint8)
+    lengths = np.add.reduceat(iv_len.astype(np.int64), orf_iv[:-1])
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    return IntervalTable(iv_start, iv_len, orf_iv, reverse, offsets)
+
+
+def numpy_gather(cov, t):
+    out = np.empty(int(t.offsets[-1]), np.int32)
+    for i in range(len(t.offsets) - 1):
+        parts = [cov[t.iv_start[k] : t.iv_start[k] + t.iv_len[k]] for k in range(t.orf_iv[i], t.orf_iv[i + 1])]
+        prof = np.concatenate(parts) if parts else np.zeros(0, np.int32)
+        out[t.offsets[i] : t.offsets[i + 1]] = prof[::-1] if t.reverse[i] else prof
+    return out
+
+
+CASES = {
+    "exons": dict(n=4000, max_exons=6, exon_len=(1, 400), special=((5, 150), (6, 64), (7, 65), (3999, 70))),
+    "tiny_exons": dict(n=3000, max_exons=40, exon_len=(1, 3)),       # > 128 pieces per tile: the overflow rounds
+    "single_long": dict(n=300, max_exons=1, exon_len=(5000, 30000)),  # pieces spanning several tiles
+    "short_orfs": dict(n=20000, max_exons=1, exon_len=(60, 150)),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_tile_gather(case):
+    import torch
+
+    from ribotricer_amd.gather import GatherPlan, gather_profiles_device
+
+    rng = np.random.default_rng(11)
+    cov = rng.poisson(0.7, size=400000).astype(np.int32)
+    t = random_table(rng, cov_len=cov.size, **CASES[case])
+    plan = GatherPlan(t, cov.size)
+    got, off = gather_profiles_device(cov, t, plan=plan)
+    legacy, _ = gather_profiles_device(cov, t)
+    torch.cuda.synchronize()
+    want = numpy_gather(cov, t)
+    assert np.array_equal(off.cpu().numpy(), t.offsets)
+    assert np.array_equal(legacy.cpu().numpy(), want)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_unplannable_tables():
+    from ribotricer_amd import _lib
+    from ribotricer_amd.gather import GatherPlan, IntervalTable, make_gather_plan
+
+    rng = np.random.default_rng(3)
+    t = random_table(rng, 50, 10000)
+    off_array = t._replace(iv_start=np.where(np.arange(t.iv_start.size) == 7, 10000 - 2, t.iv_start))
+    assert make_gather_plan(off_array, 10000) is None  # the per-ORF kernel reads those positions as 0
+    with pytest.raises(_lib.RibophaseError) as e:
+        GatherPlan(off_array, 10000)
+    assert e.value.status == _lib.ERR_INTERVALS
+    short = t._replace(offsets=t.offsets + np.arange(t.offsets.size))  # lengths no longer add up
+    with pytest.raises(_lib.RibophaseError) as e:
+        GatherPlan(IntervalTable(*short), 10000)
+    assert e.value.status == -3
+    empty = GatherPlan(IntervalTable(np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(1, np.int64), np.zeros(0, np.uint8), np.zeros(1, np.int64)), 100)
+    assert empty.gather(np.zeros(100, np.int32)).numel() == 0
+
+
+@pytest.mark.parametrize("lam", [0.01, 0.3, 3.0])
+@pytest.mark.parametrize("case", ["exons", "tiny_exons", "single_long", "short_orfs"])
+def test_fused_score_equals_gather_then_score(case, lam):
+    import torch
+
+    from helpers import assert_matches_oracle
+    from ribotricer_amd.engine import get_engine, make_filter
+    from ribotricer_amd.gather import GatherPlan
+
+    rng = np.random.default_rng(int(lam * 100) + 17)
+    cov = rng.poisson(lam, size=400000).astype(np.int32)
+    t = random_table(rng, cov_len=cov.size, **CASES[case])
+    eng = get_engine("cuda:0")
+    plan = GatherPlan(t, cov.size)
+    th = make_filter()
+    d_cov = torch.from_numpy(cov).cuda()
+    fused = eng.score_coverage(d_cov, plan, thresholds=th).cpu_numpy()
+    counts = plan.gather(d_cov)
+    plain = eng.score(counts, plan.offsets, thresholds=th, algo="tile").cpu_numpy()
+    for k in ("phase", "valid", "read_count", "min_codon_cov", "flags", "status"):
+        assert np.array_equal(fused[k], plain[k]), k  # phase: the same float64 bits
+    assert_matches_oracle(fused, counts.cpu().numpy(), t.offsets)
+    if lam < 0.1 and case != "single_long":  # (long ORFs hold too many reads to tie)
+        assert (fused["flags"] & 0x08).any()  # ties were replayed through the piece view
+
+
+def test_fused_long_rewalk_reads_through_the_plan():
+    """A cutoff placed on a long ORF's own phase score sends it to k_rewalk_long (float64,
+    a workgroup per ORF), which in fused mode reads the coverage through the piece view."""
+    import torch
+
+    from ribotricer_amd.engine import get_engine, make_filter
+    from ribotricer_amd.gather import GatherPlan
+
+    rng = np.random.default_rng(23)
+    cov = torch.from_numpy(rng.poisson(0.3, size=400000).astype(np.int32)).cuda()
+    t = random_table(rng, 200, 400000, max_exons=3, exon_len=(3000, 9000))
+    eng = get_engine("cuda:0")
+    plan = GatherPlan(t, 400000)
+    first = eng.score_coverage(cov, plan, thresholds=make_filter()).cpu_numpy()
+    pick = [7, 100, 199]
+    for i in pick:
+        th = make_filter(phase_score_cutoff=float(first["phase"][i]))
+        fused = eng.score_coverage(cov, plan, thresholds=th).cpu_numpy()
+        plain = eng.score(plan.gather(cov), plan.offsets, thresholds=th, algo="tile").cpu_numpy()
+        assert all(np.array_equal(fused[k], plain[k]) for k in fused)
+        assert fused["flags"][i] & 0x02, "the ORF on the cutoff was not re-walked in float64"
+
+
+def test_fused_score_repeats_and_reuses_the_plan():
+    import torch
+
+    from ribotricer_amd.engine import get_engine, make_filter
+    from ribotricer_amd.gather import GatherPlan
+
+    rng = np.random.default_rng(5)
+    t = random_table(rng, 5000, 300000)
+    plan = GatherPlan(t, 300000)
+    eng = get_engine("cuda:0")
+    for seed in (1, 2):  # two "samples" against one index
+        cov = torch.from_numpy(np.random.default_rng(seed).poisson(0.5, 300000).astype(np.int32)).cuda()
+        a = eng.score_coverage(cov, plan, thresholds=make_filter()).cpu_numpy()
+        b = eng.score(plan.gather(cov), plan.offsets, thresholds=make_filter(), algo="tile").cpu_numpy()
+        assert all(np.array_equal(a[k], b[k]) for k in a)

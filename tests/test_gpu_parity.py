@@ -103,7 +103,7 @@ def test_frame_diagnostics(eng, g2):
 
 # ------------------------------------------------------------------ oracle on seeded synthetic data
 @pytest.mark.parametrize("algo", ALGOS)
-@pytest.mark.parametrize("cfg,n", [("cfg2", 30000), ("cfg3", 30000), ("cfg5", 20000)])
+@pytest.mark.parametrize("cfg,n", [("cfg2", 30000), ("cfg3", 30000), ("cfg5", 20000), ("gencode", 30000)])
 def test_synthetic_vs_oracle(eng, algo, cfg, n):
     from ribotricer_amd.synth import synth_csr_host
 
