@@ -23,7 +23,7 @@ namespace rp {
 
 typedef unsigned long long piece_desc_t;
 
-constexpr int kRowPieces = 128;                    // clipped pieces in a tile's fixed-stride row
+constexpr int kRowPieces = 256;                    // clipped pieces in a tile's fixed-stride row (2 KiB per 31 KiB tile)
 constexpr unsigned long long kPieceNeg = 1ull << 63;  // start word: the piece runs down the coverage array
 constexpr long long kMaxCoverage = 1ll << 34;      // a clipped piece keeps its source index in 34 bits
 
@@ -32,7 +32,7 @@ constexpr long long kMaxCoverage = 1ll << 34;      // a clipped piece keeps its 
 //   bits 34-46  off    that position's index in the tile's LDS image
 //   bits 47-59  n      positions (1 .. kTile + kHalo)
 //   bit  60     neg    the source index falls as the position rises
-//   bit  61     more   (slot kRowPieces-1 only) the tile has further pieces: tile_piece0 + kRowPieces ...
+//   bit  61     more   (last slot of the row only) the tile has further pieces: tile_piece0 + kRowPieces ...
 constexpr int kPieceOffAt = 34, kPieceNAt = 47, kPieceNegAt = 60, kPieceMoreAt = 61;
 
 struct PiecePlan {
@@ -173,29 +173,62 @@ __global__ __launch_bounds__(kRowPieces) void k_piece_rows(PiecePlanMem plan, lo
 // a per-lane constant (lane * 4 going up the coverage array, (63 - lane) * 4 going down), so
 // a chunk costs one v_cmp for the ragged end and scalar arithmetic.  Not waited for here.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void stage_piece(const int32_t *__restrict__ cov, piece_desc_t d, int *s_counts, int lane)
+// One LDS-DMA instruction: lanes [0, live) load 4 bytes each from g + lane offset + OFF into
+// lds + OFF + 4 * lane (the instruction offset applies to both sides).
+template <int OFF>
+__device__ __forceinline__ void dma_chunk(const char *g, unsigned lane_off, int *lds)
 {
     typedef const __attribute__((address_space(1))) void *gptr_t;
     typedef __attribute__((address_space(3))) void *lptr_t;
+    __builtin_amdgcn_global_load_lds((gptr_t)(g + lane_off), (lptr_t)lds, 4, OFF, 0);
+}
+
+// up to 16 consecutive full chunks going UP the coverage array: one address, one M0, immediate offsets
+__device__ __forceinline__ void dma_run_up(const char *g, unsigned lane_off, int *lds, int chunks)
+{
+#define RP_UP(C) if (chunks > C) dma_chunk<256 * C>(g, lane_off, lds)
+    RP_UP(0); RP_UP(1); RP_UP(2); RP_UP(3); RP_UP(4); RP_UP(5); RP_UP(6); RP_UP(7);
+    RP_UP(8); RP_UP(9); RP_UP(10); RP_UP(11); RP_UP(12); RP_UP(13); RP_UP(14); RP_UP(15);
+#undef RP_UP
+}
+
+// going DOWN the coverage array the two sides move in opposite directions: the instruction
+// offset walks the global side (-256 per chunk), the LDS pointer makes up for it (+512)
+__device__ __forceinline__ void dma_run_down(const char *g, unsigned lane_off, int *lds, int chunks)
+{
+#define RP_DOWN(C) if (chunks > C) dma_chunk<-256 * C>(g, lane_off, lds + 128 * C)
+    RP_DOWN(0); RP_DOWN(1); RP_DOWN(2); RP_DOWN(3); RP_DOWN(4); RP_DOWN(5); RP_DOWN(6); RP_DOWN(7);
+    RP_DOWN(8); RP_DOWN(9); RP_DOWN(10); RP_DOWN(11); RP_DOWN(12); RP_DOWN(13); RP_DOWN(14); RP_DOWN(15);
+#undef RP_DOWN
+}
+
+__device__ __forceinline__ void stage_piece(const int32_t *__restrict__ cov, piece_desc_t d, int *s_counts, int lane)
+{
     const long long src = (long long)(d & ((1ull << kPieceOffAt) - 1));
     const int off = (int)(d >> kPieceOffAt) & 0x1fff;
     const int n = (int)(d >> kPieceNAt) & 0x1fff;
     const bool neg = ((d >> kPieceNegAt) & 1) != 0;
-    const unsigned up4 = (unsigned)lane * 4u, down4 = (unsigned)(63 - lane) * 4u;
+    int full = n >> 6;
+    const int rest = n & 63;
+    int *lds = s_counts + off;
     if (!neg) {
+        const unsigned up4 = (unsigned)lane * 4u;
         const char *g = reinterpret_cast<const char *>(cov + src);
-        for (int c0 = 0; c0 < n; c0 += 64) {  // wave-uniform
-            if (lane < n - c0)
-                __builtin_amdgcn_global_load_lds((gptr_t)(g + up4), (lptr_t)(s_counts + off + c0), 4, 0, 0);
-            g += 256;
+        while (full > 16) {  // (pieces of more than 1 024 positions)
+            dma_run_up(g, up4, lds, 16);
+            g += 4096, lds += 1024, full -= 16;
         }
+        dma_run_up(g, up4, lds, full);
+        if (lane < rest) dma_chunk<0>(g + 256 * full, up4, lds + 64 * full);
     } else {
+        const unsigned down4 = (unsigned)(63 - lane) * 4u;
         const char *g = reinterpret_cast<const char *>(cov + src - 63);
-        for (int c0 = 0; c0 < n; c0 += 64) {
-            if (lane < n - c0)
-                __builtin_amdgcn_global_load_lds((gptr_t)(g + down4), (lptr_t)(s_counts + off + c0), 4, 0, 0);
-            g -= 256;
+        while (full > 16) {
+            dma_run_down(g, down4, lds, 16);
+            g -= 4096, lds += 1024, full -= 16;
         }
+        dma_run_down(g, down4, lds, full);
+        if (lane < rest) dma_chunk<0>(g - 256 * full, down4, lds + 64 * full);
     }
 }
 
@@ -216,21 +249,27 @@ __device__ __forceinline__ void stage_round(const int32_t *__restrict__ cov, pie
     }
 }
 
-// Issue the row's two descriptor loads (lane l: slots 2l, 2l + 1).
-__device__ __forceinline__ const uint4 *piece_row_ptr(const PiecePlan &pp, long long b, int lane)
+// The row as two halves of 128 slots; lane l holds slots 2l, 2l + 1 of each half.
+__device__ __forceinline__ const uint4 *piece_row_ptr(const PiecePlan &pp, long long b, int lane, int half)
 {
-    return reinterpret_cast<const uint4 *>(pp.rows + b * kRowPieces) + lane;
+    return reinterpret_cast<const uint4 *>(pp.rows + b * kRowPieces + half * (kRowPieces / 2)) + lane;
 }
 
-// Stage tile b (positions [t0, min(t0 + TILE + HALO, total_nt))) given this lane's row word.
+__device__ __forceinline__ void stage_half(const int32_t *__restrict__ cov, uint4 h, int *s_counts, int lane, int wave)
+{
+    stage_round(cov, ((piece_desc_t)h.y << 32) | h.x, s_counts, lane, wave);
+    stage_round(cov, ((piece_desc_t)h.w << 32) | h.z, s_counts, lane, wave);
+}
+
+// Stage tile b (positions [t0, min(t0 + TILE + HALO, total_nt))) given this lane's row words.
 template <int TILE, int HALO>
 __device__ __forceinline__ void stage_tile(const int32_t *__restrict__ cov, const PiecePlan &pp, long long b,
-                                           long long total_nt, uint4 row, int *s_counts, int lane, int wave)
+                                           long long total_nt, uint4 lo, uint4 hi, int *s_counts, int lane, int wave)
 {
-    const piece_desc_t even = ((piece_desc_t)row.y << 32) | row.x, odd = ((piece_desc_t)row.w << 32) | row.z;
-    stage_round(cov, even, s_counts, lane, wave);
-    stage_round(cov, odd, s_counts, lane, wave);
-    const unsigned more = (unsigned)__builtin_amdgcn_readlane((int)(row.w >> (kPieceMoreAt - 32)) & 1, 63);
+    stage_half(cov, lo, s_counts, lane, wave);
+    if (__builtin_amdgcn_readlane((int)(hi.x | hi.y), 0) == 0) return;  // slots fill in order: <= 128 pieces
+    stage_half(cov, hi, s_counts, lane, wave);
+    const unsigned more = (unsigned)__builtin_amdgcn_readlane((int)(hi.w >> (kPieceMoreAt - 32)) & 1, 63);
     if (more) {  // rare: more than kRowPieces pieces in the tile (runs of very short exons / ORFs)
         const long long t0 = b * (long long)TILE;
         long long t_end = t0 + TILE + HALO;
@@ -291,8 +330,8 @@ __global__ __launch_bounds__(kGatherTileBlock) void k_tile_gather(const int32_t 
     __shared__ __attribute__((aligned(16))) int s_counts[TILE + HALO];  // the rows are clipped for the scorer: halo included
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long b = blockIdx.x;
-    const uint4 row = *piece_row_ptr(pp, b, lane);
-    stage_tile<TILE, HALO>(cov, pp, b, total_nt, row, s_counts, lane, wave);
+    const uint4 lo = *piece_row_ptr(pp, b, lane, 0), hi = *piece_row_ptr(pp, b, lane, 1);
+    stage_tile<TILE, HALO>(cov, pp, b, total_nt, lo, hi, s_counts, lane, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const long long t0 = b * (long long)TILE;

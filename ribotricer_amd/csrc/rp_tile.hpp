@@ -760,9 +760,19 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
                      : "memory");
     }
     if constexpr (FUSED) {
-        // every wave stages a quarter of the tile's pieces; the piece row arrives with the head row
-        const uint4 prow = *piece_row_ptr(pp, b, lane);
-        stage_tile<kTile, kHalo>(counts, pp, b, plan.total_nt, prow, s_counts, lane, wave);
+        // every wave stages a quarter of the tile's pieces; the piece row arrives with the head
+        // row (one wait for both, here: the DMA issued next must not sit in front of them)
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 pl, ph;
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"
+                     : "=&v"(pl), "=&v"(ph)
+                     : "v"(piece_row_ptr(pp, b, lane, 0)), "v"(piece_row_ptr(pp, b, lane, 1))
+                     : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(d), "+v"(vmap), "+v"(pl), "+v"(ph) : : "memory");
+        __builtin_amdgcn_s_setprio(3);  // scalar-heavy and on the critical path: ahead of the other workgroups' lane runs
+        stage_tile<kTile, kHalo>(counts, pp, b, plan.total_nt, make_uint4(pl.x, pl.y, pl.z, pl.w),
+                                 make_uint4(ph.x, ph.y, ph.z, ph.w), s_counts, lane, wave);
+        __builtin_amdgcn_s_setprio(0);
     } else {
         load_tile_to_lds(counts, t0, plan.total_nt, s_counts, tid);
     }
@@ -784,7 +794,7 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
         // vmcnt(0) in front of every LDS access of the DMA-issuing waves' code path, i.e. of all
         // waves); tying their registers to the wait keeps every use behind it.  Waves without DMA
         // in flight get their rows as soon as they arrive; the loader waves wait for the tile too.
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(d), "+v"(vmap) : : "memory");
+        if constexpr (!FUSED) asm volatile("s_waitcnt vmcnt(0)" : "+v"(d), "+v"(vmap) : : "memory");
         if (lane >= kHeadSlots) d = 0;
         RP_STAMP();  // 2: descriptors here
         const int lanes_i = (int)(d >> 53) & 0xff;

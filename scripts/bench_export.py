@@ -95,6 +95,41 @@ for _ in range(10):
 e1.record(); torch.cuda.synchronize()
 gather_ms = e0.elapsed_time(e1) / 10
 assert torch.equal(d_out, d_counts)
+# the gather plan: tile gather and fused gather + score against the two-step path (kernel times, HIP events)
+from ribotricer_amd.engine import get_engine, make_filter
+from ribotricer_amd.gather import GatherPlan
+t0 = time.perf_counter()
+gplan = GatherPlan(table, coverage.numel()); torch.cuda.synchronize()
+plan_s = time.perf_counter() - t0
+eng = get_engine("cuda:0")
+th = make_filter()
+def timed(fn, reps=10):
+    for _ in range(3):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+counts_buf = torch.empty_like(d_counts)
+def tile_gather():
+    _lib.check(_lib.load().rp_gather_profiles_plan_dev(gplan.handle, _ptr(coverage), coverage.numel(), _ptr(counts_buf), stream))
+tile_gather_ms = timed(tile_gather)
+assert torch.equal(counts_buf, d_counts)
+plain_ms = timed(lambda: eng.score(d_counts, gplan.offsets, thresholds=th, algo="tile", reuse_outputs=True))
+fused_ms = timed(lambda: eng.score_coverage(coverage, gplan, thresholds=th, reuse_outputs=True))
+tm = []
+for _ in range(5):
+    eng.score_coverage(coverage, gplan, thresholds=th, reuse_outputs=True, timings=tm)
+fused_kernel_ms = float(np.median([x[1] for x in tm]))
+tm = []
+for _ in range(5):
+    eng.score(d_counts, gplan.offsets, thresholds=th, algo="tile", reuse_outputs=True, timings=tm)
+plain_kernel_ms = float(np.median([x[1] for x in tm]))
+a = eng.score_coverage(coverage, gplan, thresholds=th).cpu_numpy()
+b = eng.score(d_counts, gplan.offsets, thresholds=th, algo="tile").cpu_numpy()
+assert all(np.array_equal(a[k], b[k]) for k in a)
 total = sum(T.values())
 # the whole thing once more through the public entry point (report_all=False, the CLI default)
 t0 = time.perf_counter()
@@ -110,7 +145,12 @@ print(json.dumps({
     "n_orfs": n, "total_nt": int(offsets[-1]), "reads": n_reads, "tsv_bytes_report_all": size,
     "seconds": {k: round(v, 4) for k, v in T.items()}, "total_s": round(total, 3), "orfs_per_s_report_all": round(n / total),
     "export_orf_coverages_default_s": round(t_export, 3), "columns_to_device_coverage_s": round(T_cols, 4),
-    "export_orf_coverages_columns_report_all_s": round(t_export_cols_all, 3), "export_orf_coverages_columns_default_s": round(t_export_cols, 3), "gather_kernel_ms": round(gather_ms, 4), "gather_GBps": round(8 * int(offsets[-1]) / gather_ms / 1e6), "translating": int(res["status"].sum()),
+    "export_orf_coverages_columns_report_all_s": round(t_export_cols_all, 3), "export_orf_coverages_columns_default_s": round(t_export_cols, 3), "gather_kernel_ms": round(gather_ms, 4), "gather_GBps": round(8 * int(offsets[-1]) / gather_ms / 1e6),
+    "gather_plan_build_s": round(plan_s, 4), "n_intervals": int(table.iv_start.size),
+    "tile_gather_ms": round(tile_gather_ms, 4), "tile_gather_GBps": round(8 * int(offsets[-1]) / tile_gather_ms / 1e6),
+    "score_step_ms": round(plain_ms, 4), "score_kernel_ms": round(plain_kernel_ms, 4),
+    "fused_step_ms": round(fused_ms, 4), "fused_kernel_ms": round(fused_kernel_ms, 4),
+    "gather_plus_score_ms": {"per_orf_gather_then_score": round(gather_ms + plain_ms, 4), "tile_gather_then_score": round(tile_gather_ms + plain_ms, 4), "fused": round(fused_ms, 4)}, "translating": int(res["status"].sum()),
 }))
 for f in os.listdir(tmp):
     os.remove(os.path.join(tmp, f))
