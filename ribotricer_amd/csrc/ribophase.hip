@@ -231,7 +231,7 @@ constexpr size_t kPlanHeader = 128;
 
 rp::PiecePlan piece_plan_of(const rp_gather_plan *g)
 {
-    return rp::PiecePlan{g->mem.start, g->mem.base, g->mem.orf_piece, g->mem.tile_piece0, g->mem.rows, g->n_pieces, g->coverage_len};
+    return rp::PiecePlan{g->mem.start, g->mem.base, g->mem.orf_piece, g->mem.tile_next, g->mem.rows, g->mem.tile_lo, g->n_pieces, g->coverage_len};
 }
 
 int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, int64_t n_orfs,

@@ -32,15 +32,21 @@ constexpr long long kMaxCoverage = 1ll << 34;      // a clipped piece keeps its 
 //   bits 34-46  off    that position's index in the tile's LDS image
 //   bits 47-59  n      positions (1 .. kTile + kHalo)
 //   bit  60     neg    the source index falls as the position rises
-//   bit  61     more   (last slot of the row only) the tile has further pieces: tile_piece0 + kRowPieces ...
+//   bit  61     more   (last slot of the row only) the tile has further pieces: tile_next + kRowPieces ...
 constexpr int kPieceOffAt = 34, kPieceNAt = 47, kPieceNegAt = 60, kPieceMoreAt = 61;
+
+// The fast staging path (stage_tile_chunks) cuts a tile's pieces into chunks of <= 64
+// positions, at most kMaxChunks of them, addressed with 32-bit byte offsets from one base.
+constexpr int kMaxChunks = 352;
+constexpr long long kTileSlow = INT64_MIN;  // tile_lo: the row is not eligible (too many pieces / chunks, > 4 GiB apart)
 
 struct PiecePlan {
     const unsigned long long *start;  // [n_pieces + 1] first profile position | kPieceNeg; sentinel total_nt
     const long long *base;            // [n_pieces + 1] coverage index = base + p, or base - p
     const long long *orf_piece;       // [n_orfs + 1]   pieces of ORF i: orf_piece[i] .. orf_piece[i+1]
-    const long long *tile_piece0;     // [n_tiles]      piece holding the tile's first position
+    const long long *tile_next;       // [n_tiles]      first piece of the tile that is not in its row
     const piece_desc_t *rows;         // [n_tiles][kRowPieces]
+    const long long *tile_lo;         // [n_tiles]      lowest coverage index the row reads, minus 64 (kTileSlow: see stage_tile)
     long long n_pieces;
     long long coverage_len;
 };
@@ -48,7 +54,7 @@ struct PiecePlan {
 inline size_t piece_plan_bytes(long long n_orfs, long long n_pieces, long long n_tiles)
 {
     auto up = [](size_t b) { return (b + 127) & ~(size_t)127; };
-    return up((size_t)(n_pieces + 1) * 8) * 2 + up((size_t)(n_orfs + 1) * 8) + up((size_t)n_tiles * 8) +
+    return up((size_t)(n_pieces + 1) * 8) * 2 + up((size_t)(n_orfs + 1) * 8) + up((size_t)n_tiles * 8) * 2 +
            (size_t)n_tiles * kRowPieces * sizeof(piece_desc_t);
 }
 
@@ -56,7 +62,8 @@ struct PiecePlanMem {
     unsigned long long *start;
     long long *base;
     long long *orf_piece;
-    long long *tile_piece0;
+    long long *tile_next;
+    long long *tile_lo;
     piece_desc_t *rows;
 };
 
@@ -71,7 +78,9 @@ inline PiecePlanMem carve_piece_plan(void *mem, long long n_orfs, long long n_pi
     p += up((size_t)(n_pieces + 1) * 8);
     m.orf_piece = reinterpret_cast<long long *>(p);
     p += up((size_t)(n_orfs + 1) * 8);
-    m.tile_piece0 = reinterpret_cast<long long *>(p);
+    m.tile_next = reinterpret_cast<long long *>(p);
+    p += up((size_t)n_tiles * 8);
+    m.tile_lo = reinterpret_cast<long long *>(p);
     p += up((size_t)n_tiles * 8);
     m.rows = reinterpret_cast<piece_desc_t *>(p);
     return m;
@@ -140,31 +149,80 @@ __device__ __forceinline__ piece_desc_t clip_piece(unsigned long long start_word
 }
 
 // One workgroup of kRowPieces threads per tile: find the piece that holds the tile's first
-// position, clip it and the next kRowPieces - 1 to [t0, t0 + TILE + HALO).
+// position, clip it and its successors to [t0, t0 + TILE + HALO) and lay them into the row --
+// long ones as several slots of <= kSlotPositions positions, so that no thread of the staging
+// code has more than 8 chunks to cut.  tile_next[b] = the first piece that did not fit.
+constexpr int kSlotPositions = 512;
+
 template <int TILE, int HALO>
 __global__ __launch_bounds__(kRowPieces) void k_piece_rows(PiecePlanMem plan, long long n_pieces, long long total_nt)
 {
-    __shared__ long long s_j0;
+    __shared__ long long s_j0, s_lo, s_hi;
+    __shared__ int s_chunks, s_fit, s_more;
+    __shared__ int s_slot[kRowPieces], s_nsub[kRowPieces];
+    const int t = threadIdx.x;
     const long long b = blockIdx.x;
     const long long t0 = b * (long long)TILE;
     long long t_end = t0 + TILE + HALO;
     if (t_end > total_nt) t_end = total_nt;
-    if (threadIdx.x == 0) {  // last j with start_j <= t0 (start_0 == 0 <= t0)
+    if (t == 0) {  // last j with start_j <= t0 (start_0 == 0 <= t0)
         long long lo = 0, hi = n_pieces;  // start[hi] (sentinel or later piece) > t0 unless t0 >= total_nt
         while (hi - lo > 1) {
             const long long mid = lo + (hi - lo) / 2;
             if ((long long)(plan.start[mid] & ~kPieceNeg) <= t0) lo = mid; else hi = mid;
         }
         s_j0 = lo;
-        plan.tile_piece0[b] = lo;
+        s_lo = INT64_MAX;
+        s_hi = INT64_MIN;
+        s_chunks = 0;
     }
     __syncthreads();
-    const long long j = s_j0 + threadIdx.x;
+    const long long j = s_j0 + t;
     piece_desc_t d = 0;
     if (j < n_pieces) d = clip_piece(plan.start[j], plan.start[j + 1], plan.base[j], t0, t_end);
-    if (threadIdx.x == kRowPieces - 1 && j + 1 < n_pieces && (long long)(plan.start[j + 1] & ~kPieceNeg) < t_end)
-        d |= (piece_desc_t)1 << kPieceMoreAt;
-    plan.rows[b * kRowPieces + threadIdx.x] = d;
+    const long long src = (long long)(d & ((1ull << kPieceOffAt) - 1));
+    const int off = (int)(d >> kPieceOffAt) & 0x1fff;
+    const int n = (int)(d >> kPieceNAt) & 0x1fff;
+    const bool neg = ((d >> kPieceNegAt) & 1) != 0;
+    const int nsub = (n + kSlotPositions - 1) / kSlotPositions;
+    s_nsub[t] = nsub;
+    plan.rows[b * kRowPieces + t] = 0;
+    __syncthreads();
+    if (t == 0) {  // slots of the pieces, in order; the first piece whose slots pass the row's end and all after it stay out
+        int acc = 0, fit = kRowPieces;
+        for (int k = 0; k < kRowPieces; ++k) {
+            s_slot[k] = acc;
+            acc += s_nsub[k];
+            if (acc > kRowPieces && fit == kRowPieces) fit = k;
+        }
+        int more = 0;
+        for (int k = fit; k < kRowPieces; ++k) more |= s_nsub[k];
+        const long long after = s_j0 + kRowPieces;  // the candidate pieces end here: does the tile go on?
+        if (after < n_pieces && (long long)(plan.start[after] & ~kPieceNeg) < t_end) more = 1;
+        s_fit = fit;
+        s_more = more != 0;
+        plan.tile_next[b] = s_j0 + fit;
+    }
+    __syncthreads();
+    if (t < s_fit && n > 0) {
+        for (int k = 0; k < nsub; ++k) {
+            const int nk = n - k * kSlotPositions < kSlotPositions ? n - k * kSlotPositions : kSlotPositions;
+            const long long sk = neg ? src - (long long)k * kSlotPositions : src + (long long)k * kSlotPositions;
+            plan.rows[b * kRowPieces + s_slot[t] + k] = (piece_desc_t)sk | ((piece_desc_t)(off + k * kSlotPositions) << kPieceOffAt) |
+                                                        ((piece_desc_t)nk << kPieceNAt) | ((piece_desc_t)(neg ? 1 : 0) << kPieceNegAt);
+        }
+        // eligibility for the chunk-table staging: the lowest / highest coverage index and the chunk count
+        atomicMin(&s_lo, neg ? src - (n - 1) : src);
+        atomicMax(&s_hi, neg ? src : src + n - 1);
+        atomicAdd(&s_chunks, (n + 63) >> 6);
+    }
+    __syncthreads();
+    if (t == 0) {
+        if (s_more) plan.rows[b * kRowPieces + kRowPieces - 1] |= (piece_desc_t)1 << kPieceMoreAt;
+        // (a slot boundary may add a chunk to a piece whose length is not a multiple of 64: none -- 512 is)
+        const bool fast = !s_more && s_chunks > 0 && s_chunks <= kMaxChunks && s_hi - s_lo < (1ll << 30) - 256;
+        plan.tile_lo[b] = fast ? s_lo - 64 : kTileSlow;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -267,14 +325,14 @@ __device__ __forceinline__ void stage_tile(const int32_t *__restrict__ cov, cons
                                            long long total_nt, uint4 lo, uint4 hi, int *s_counts, int lane, int wave)
 {
     stage_half(cov, lo, s_counts, lane, wave);
-    if (__builtin_amdgcn_readlane((int)(hi.x | hi.y), 0) == 0) return;  // slots fill in order: <= 128 pieces
-    stage_half(cov, hi, s_counts, lane, wave);
     const unsigned more = (unsigned)__builtin_amdgcn_readlane((int)(hi.w >> (kPieceMoreAt - 32)) & 1, 63);
+    if (!more && __builtin_amdgcn_readlane((int)(hi.x | hi.y), 0) == 0) return;  // slots fill in order: <= 128 of them
+    stage_half(cov, hi, s_counts, lane, wave);
     if (more) {  // rare: more than kRowPieces pieces in the tile (runs of very short exons / ORFs)
         const long long t0 = b * (long long)TILE;
         long long t_end = t0 + TILE + HALO;
         if (t_end > total_nt) t_end = total_nt;
-        long long j = pp.tile_piece0[b] + kRowPieces;
+        long long j = pp.tile_next[b];
         for (;;) {  // wave-uniform
             piece_desc_t d = 0;
             if (j + lane < pp.n_pieces) d = clip_piece(pp.start[j + lane], pp.start[j + lane + 1], pp.base[j + lane], t0, t_end);
@@ -282,6 +340,111 @@ __device__ __forceinline__ void stage_tile(const int32_t *__restrict__ cov, cons
             j += 64;
             if (__builtin_amdgcn_readlane((int)(d != 0), 63) == 0) break;  // the list ran past the tile
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The fast staging path.  The scalar loop above spends ~1 000 cycles per piece on a busy CU
+// (two lane reads, a decode and a branch chain per piece, at one instruction per ~10 cycles
+// next to three other workgroups' lane runs); here the per-piece work is done by the vector
+// unit, one piece per THREAD, and the DMA is issued from straight-line code:
+//   1. thread t cuts the row's piece t into chunks of <= 64 positions; a workgroup-wide prefix
+//      sum numbers them; each thread writes its chunks into a table in LDS:
+//         bits 0-31 byte offset of the chunk's lowest-lane element from cov + tile_lo
+//         bits 32-44 LDS index   45-50 64 - positions   51 the source index falls
+//   2. wave w, lane i takes chunk 4 i + w and keeps (offset, LDS address | shift << 16 | dir << 24)
+//      in two registers;
+//   3. 64 unrolled steps -- two lane reads, M0, the EXEC mask of the ragged end, two VALU for
+//      the lane's byte offset ((lane or 63 - lane) * 4 + chunk offset), one global_load_lds with
+//      a scalar base -- no branches but an exit test every 8 steps.  Lanes past the last chunk
+//      hold chunk 0 again (staging a chunk twice is harmless).
+// `s_tab`: kMaxChunks 8-byte words, `s_part`: 4 ints of LDS scratch, both dead afterwards.
+// ---------------------------------------------------------------------------------------
+#define RP_DMA_STEP(I)                                          \
+    "v_readlane_b32 %[so], %[w0], " #I "\n\t"                   \
+    "v_readlane_b32 %[s1], %[w1], " #I "\n\t"                   \
+    "s_and_b32 m0, %[s1], 0xffff\n\t"                           \
+    "s_lshr_b32 %[st], %[s1], 16\n\t"                           \
+    "s_lshr_b64 exec, -1, %[st]\n\t"                            \
+    "s_lshr_b32 %[sd], %[st], 8\n\t"                            \
+    "v_mad_i32_i24 %[vt], %[sd], %[vdelta], %[vup]\n\t"         \
+    "v_add_u32 %[vt], %[so], %[vt]\n\t"                         \
+    "global_load_lds_dword %[vt], %[base]\n\t"
+#define RP_DMA_STEP8(A, B, C, D, E, F, G, H, LIM)               \
+    RP_DMA_STEP(A) RP_DMA_STEP(B) RP_DMA_STEP(C) RP_DMA_STEP(D) \
+    RP_DMA_STEP(E) RP_DMA_STEP(F) RP_DMA_STEP(G) RP_DMA_STEP(H) \
+    "s_cmp_le_u32 %[steps], " #LIM "\n\t"                       \
+    "s_cbranch_scc1 1f\n\t"
+
+__device__ __forceinline__ void issue_chunks(const int32_t *base, unsigned w0, unsigned w1, int steps, int lane)
+{
+    const int vup = lane * 4, vdelta = (63 - 2 * lane) * 4;  // vup + vdelta = (63 - lane) * 4
+    unsigned so, s1, st, sd;
+    int vt;
+    asm volatile(
+        RP_DMA_STEP8(0, 1, 2, 3, 4, 5, 6, 7, 8)
+        RP_DMA_STEP8(8, 9, 10, 11, 12, 13, 14, 15, 16)
+        RP_DMA_STEP8(16, 17, 18, 19, 20, 21, 22, 23, 24)
+        RP_DMA_STEP8(24, 25, 26, 27, 28, 29, 30, 31, 32)
+        RP_DMA_STEP8(32, 33, 34, 35, 36, 37, 38, 39, 40)
+        RP_DMA_STEP8(40, 41, 42, 43, 44, 45, 46, 47, 48)
+        RP_DMA_STEP8(48, 49, 50, 51, 52, 53, 54, 55, 56)
+        RP_DMA_STEP8(56, 57, 58, 59, 60, 61, 62, 63, 64)
+        "1:\n\t"
+        "s_mov_b64 exec, -1"
+        : [so] "=&s"(so), [s1] "=&s"(s1), [st] "=&s"(st), [sd] "=&s"(sd), [vt] "=&v"(vt)
+        : [w0] "v"(w0), [w1] "v"(w1), [vdelta] "v"(vdelta), [vup] "v"(vup), [base] "s"(base), [steps] "s"(steps)
+        : "memory", "scc");
+}
+#undef RP_DMA_STEP8
+#undef RP_DMA_STEP
+
+// all kRowPieces threads of the workgroup; `mine` = the row's piece threadIdx.x
+__device__ __forceinline__ void stage_tile_chunks(const int32_t *__restrict__ cov, long long tile_lo, piece_desc_t mine,
+                                                  unsigned long long *s_tab, int *s_part, int *s_counts, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const long long src = (long long)(mine & ((1ull << kPieceOffAt) - 1));
+    const int off = (int)(mine >> kPieceOffAt) & 0x1fff;
+    const int n = (int)(mine >> kPieceNAt) & 0x1fff;
+    const unsigned neg = (unsigned)(mine >> kPieceNegAt) & 1u;
+    const int nch = (n + 63) >> 6;
+    // exclusive prefix of the chunk counts over the workgroup
+    int incl = nch;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    const int p0 = s_part[0], p1 = s_part[1], p2 = s_part[2], p3 = s_part[3];
+    const int total = p0 + p1 + p2 + p3;
+    const int c0 = (wave > 0 ? p0 : 0) + (wave > 1 ? p1 : 0) + (wave > 2 ? p2 : 0) + incl - nch;
+    const unsigned rel = (unsigned)(src - tile_lo);  // < 2^30 (k_piece_rows checked)
+    for (int k = 0; k < nch; ++k) {
+        const int left = n - 64 * k;
+        const unsigned cnt = left < 64 ? (unsigned)left : 64u;
+        const unsigned soff = (neg ? rel - 64u * k - 63u : rel + 64u * k) * 4u;
+        s_tab[c0 + k] = (unsigned long long)soff | ((unsigned long long)(unsigned)(off + 64 * k) << 32) |
+                        ((unsigned long long)(64u - cnt) << 45) | ((unsigned long long)neg << 51);
+    }
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) int *)s_counts;
+    const unsigned long long base_u = (unsigned long long)(cov + tile_lo);  // workgroup-uniform: pin it to scalar registers
+    const int32_t *base = reinterpret_cast<const int32_t *>(
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base_u >> 32)) << 32) |
+        (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base_u));
+    for (int r0 = 0; r0 < total; r0 += 4 * 64) {  // workgroup-uniform
+        const int c = r0 + 4 * lane + wave;
+        const unsigned long long e = s_tab[c < total ? c : 0];
+        const unsigned w0 = (unsigned)e;
+        const unsigned hi = (unsigned)(e >> 32);
+        const unsigned w1 = (lds0 + (hi & 0x1fffu) * 4u) | (((hi >> 13) & 0x3fu) << 16) | (((hi >> 19) & 1u) << 24);
+        int steps = (total - r0 - wave + 3) >> 2;  // chunks r0 + wave, r0 + wave + 4, ... < total
+        steps = __builtin_amdgcn_readfirstlane(steps > 64 ? 64 : steps);
+        if (steps > 0) issue_chunks(base, w0, w1, steps, lane);
     }
 }
 
@@ -327,11 +490,19 @@ template <int TILE, int HALO>
 __global__ __launch_bounds__(kGatherTileBlock) void k_tile_gather(const int32_t *__restrict__ cov, PiecePlan pp,
                                                                   long long total_nt, int32_t *__restrict__ counts)
 {
+    static_assert(kGatherTileBlock == kRowPieces, "one thread per row slot");
     __shared__ __attribute__((aligned(16))) int s_counts[TILE + HALO];  // the rows are clipped for the scorer: halo included
+    __shared__ unsigned long long s_tab[kMaxChunks];
+    __shared__ int s_part[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long b = blockIdx.x;
-    const uint4 lo = *piece_row_ptr(pp, b, lane, 0), hi = *piece_row_ptr(pp, b, lane, 1);
-    stage_tile<TILE, HALO>(cov, pp, b, total_nt, lo, hi, s_counts, lane, wave);
+    const long long tile_lo = pp.tile_lo[b];
+    if (tile_lo != kTileSlow) {
+        stage_tile_chunks(cov, tile_lo, pp.rows[b * kRowPieces + tid], s_tab, s_part, s_counts, tid);
+    } else {
+        const uint4 lo = *piece_row_ptr(pp, b, lane, 0), hi = *piece_row_ptr(pp, b, lane, 1);
+        stage_tile<TILE, HALO>(cov, pp, b, total_nt, lo, hi, s_counts, lane, wave);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const long long t0 = b * (long long)TILE;

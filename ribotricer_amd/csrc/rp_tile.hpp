@@ -760,19 +760,20 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
                      : "memory");
     }
     if constexpr (FUSED) {
-        // every wave stages a quarter of the tile's pieces; the piece row arrives with the head
-        // row (one wait for both, here: the DMA issued next must not sit in front of them)
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 pl, ph;
-        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"
-                     : "=&v"(pl), "=&v"(ph)
-                     : "v"(piece_row_ptr(pp, b, lane, 0)), "v"(piece_row_ptr(pp, b, lane, 1))
-                     : "memory");
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(d), "+v"(vmap), "+v"(pl), "+v"(ph) : : "memory");
-        __builtin_amdgcn_s_setprio(3);  // scalar-heavy and on the critical path: ahead of the other workgroups' lane runs
-        stage_tile<kTile, kHalo>(counts, pp, b, plan.total_nt, make_uint4(pl.x, pl.y, pl.z, pl.w),
-                                 make_uint4(ph.x, ph.y, ph.z, ph.w), s_counts, lane, wave);
-        __builtin_amdgcn_s_setprio(0);
+        // The tile's piece row (one piece per thread) arrives with the head row: one wait for both,
+        // here -- the DMA issued next must not sit in front of them.  Rows the chunk table cannot
+        // take (tile_lo == kTileSlow: rare) go through the scalar path.
+        static_assert(kTileBlock == kRowPieces && sizeof(s_rec) >= kMaxChunks * 8, "chunk table aliases s_rec");
+        const long long tile_lo = pp.tile_lo[b];
+        piece_desc_t mine;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(mine) : "v"(pp.rows + b * kRowPieces + tid) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(d), "+v"(vmap), "+v"(mine) : : "memory");
+        if (tile_lo != kTileSlow) {
+            stage_tile_chunks(counts, tile_lo, mine, reinterpret_cast<unsigned long long *>(s_rec), s_owner, s_counts, tid);
+        } else {
+            const uint4 lo = *piece_row_ptr(pp, b, lane, 0), hi = *piece_row_ptr(pp, b, lane, 1);
+            stage_tile<kTile, kHalo>(counts, pp, b, plan.total_nt, lo, hi, s_counts, lane, wave);
+        }
     } else {
         load_tile_to_lds(counts, t0, plan.total_nt, s_counts, tid);
     }
