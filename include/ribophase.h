@@ -225,7 +225,7 @@ int rp_gather_profiles_dev(int device, const int32_t *d_coverage, int64_t covera
  * derived from it) only: built once per index, reused for every sample.  Arguments as for
  * rp_gather_profiles_dev; every interval must be non-empty and lie inside the coverage array
  * (RP_ERR_INTERVALS otherwise -- rp_gather_profiles_dev handles such tables), the intervals of
- * an ORF must add up to its profile length (RP_ERR_OFFSETS), coverage_len < 2^34.
+ * an ORF must add up to its profile length (RP_ERR_OFFSETS).
  * d_plan_mem: device memory of rp_gather_plan_bytes() bytes, 16-byte aligned, caller-owned,
  * must outlive the plan.  Synchronous on hip_stream.
  */

@@ -231,7 +231,7 @@ constexpr size_t kPlanHeader = 128;
 
 rp::PiecePlan piece_plan_of(const rp_gather_plan *g)
 {
-    return rp::PiecePlan{g->mem.start, g->mem.base, g->mem.orf_piece, g->mem.tile_next, g->mem.rows, g->mem.tile_lo, g->n_pieces, g->coverage_len};
+    return rp::PiecePlan{g->mem.start, g->mem.base, g->mem.orf_piece, g->mem.tile_piece0, g->mem.tile_lo, g->mem.rows, g->n_pieces, g->coverage_len};
 }
 
 int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, int64_t n_orfs,
@@ -592,7 +592,6 @@ int rp_gather_plan_create_dev(int device, const int64_t *d_iv_start, const int32
     if (!out) return fail(RP_ERR_NULL, "out is null");
     *out = nullptr;
     if (n_orfs < 0 || n_intervals < 0 || total_nt < 0 || coverage_len < 0) return fail(RP_ERR_SIZE, "negative size");
-    if (coverage_len >= rp::kMaxCoverage) return fail(RP_ERR_SIZE, "coverage of %lld positions: the piece rows index at most 2^34", (long long)coverage_len);
     if (!d_orf_iv || !d_offsets || !d_plan_mem || (n_orfs > 0 && !d_reverse) || (n_intervals > 0 && (!d_iv_start || !d_iv_len)))
         return fail(RP_ERR_NULL, "interval table, strand flags, offsets and plan memory must be non-null");
     size_t need = 0;
@@ -619,7 +618,7 @@ int rp_gather_plan_create_dev(int device, const int64_t *d_iv_start, const int32
     RP_HIP(hipStreamSynchronize(stream));
     if (h_err & 1) return fail(RP_ERR_OFFSETS, "the intervals of an ORF do not add up to its profile length (or orf_iv is not a CSR index of the intervals)");
     if (h_err & 2) return fail(RP_ERR_INTERVALS, "an interval is empty or reaches outside the coverage array: not plannable (rp_gather_profiles_dev reads such positions as 0)");
-    hipLaunchKernelGGL((rp::k_piece_rows<rp::kTile, rp::kHalo>), dim3((unsigned)tp.n_tiles), dim3(rp::kRowPieces), 0, stream, mem,
+    hipLaunchKernelGGL((rp::k_chunk_rows<rp::kTile, rp::kHalo>), dim3((unsigned)tp.n_tiles), dim3(rp::kRowBlock), 0, stream, mem,
                        (long long)n_intervals, (long long)total_nt);
     RP_HIP(hipGetLastError());
     RP_HIP(hipStreamSynchronize(stream));

@@ -5,9 +5,10 @@
 // profile space [0, total_nt) of a whole index is described once, from the interval table
 // alone, as a sorted list of pieces -- piece j covers profile positions [start_j, start_j+1)
 // and position p reads coverage[base_j + p] (forward) or coverage[base_j - p] ('-' strand) --
-// and every flat tile of the scorer (rp_tile.hpp) gets a fixed-stride row of its pieces,
-// clipped to the tile.  With that a workgroup stages its tile of counts straight from the
-// coverage arrays with LDS-DMA, 64 consecutive positions of one piece per instruction:
+// and every flat tile of the scorer (rp_tile.hpp) gets a fixed-stride row of CHUNKS: its
+// pieces clipped to the tile and cut into runs of <= 64 positions.  With that a workgroup
+// stages its tile of counts straight from the coverage arrays with LDS-DMA, one chunk per
+// instruction, issued from straight-line code:
 //   * k_tile_gather writes the staged tile out: the CSR `counts` array (report_all mode);
 //   * k_tile_score<true> scores it in place: the profiles are never written to HBM.
 // The plan depends on the index (and the coverage layout derived from it) only, so it is
@@ -21,32 +22,27 @@
 
 namespace rp {
 
-typedef unsigned long long piece_desc_t;
+typedef unsigned long long chunk_desc_t;
 
-constexpr int kRowPieces = 256;                    // clipped pieces in a tile's fixed-stride row (2 KiB per 31 KiB tile)
 constexpr unsigned long long kPieceNeg = 1ull << 63;  // start word: the piece runs down the coverage array
-constexpr long long kMaxCoverage = 1ll << 34;      // a clipped piece keeps its source index in 34 bits
+constexpr int kMaxChunks = 352;                    // chunks in a tile's fixed-stride row (2.75 KiB per 31 KiB tile)
+constexpr long long kTileSlow = INT64_MIN;         // tile_lo of a tile whose chunks do not fit its row
 
-// A clipped piece (8 bytes; 0 = empty slot):
-//   bits  0-33  src    coverage index of the piece's first position inside the tile
-//   bits 34-46  off    that position's index in the tile's LDS image
-//   bits 47-59  n      positions (1 .. kTile + kHalo)
-//   bit  60     neg    the source index falls as the position rises
-//   bit  61     more   (last slot of the row only) the tile has further pieces: tile_next + kRowPieces ...
-constexpr int kPieceOffAt = 34, kPieceNAt = 47, kPieceNegAt = 60, kPieceMoreAt = 61;
-
-// The fast staging path (stage_tile_chunks) cuts a tile's pieces into chunks of <= 64
-// positions, at most kMaxChunks of them, addressed with 32-bit byte offsets from one base.
-constexpr int kMaxChunks = 352;
-constexpr long long kTileSlow = INT64_MIN;  // tile_lo: the row is not eligible (too many pieces / chunks, > 4 GiB apart)
+// A chunk (8 bytes): <= 64 consecutive positions of one piece, inside one tile.
+//   bits  0-31  byte offset of the chunk's lowest-ADDRESS element from cov + tile_lo
+//   bits 32-44  LDS index of its first position
+//   bits 45-50  64 - positions
+//   bit  51     the source index falls as the position rises ('-' strand piece)
+// Unused slots of a row repeat the row's chunk 0 (staging a chunk twice is harmless), so the
+// issuing code never has to ask how many there are.
 
 struct PiecePlan {
     const unsigned long long *start;  // [n_pieces + 1] first profile position | kPieceNeg; sentinel total_nt
     const long long *base;            // [n_pieces + 1] coverage index = base + p, or base - p
     const long long *orf_piece;       // [n_orfs + 1]   pieces of ORF i: orf_piece[i] .. orf_piece[i+1]
-    const long long *tile_next;       // [n_tiles]      first piece of the tile that is not in its row
-    const piece_desc_t *rows;         // [n_tiles][kRowPieces]
-    const long long *tile_lo;         // [n_tiles]      lowest coverage index the row reads, minus 64 (kTileSlow: see stage_tile)
+    const long long *tile_piece0;     // [n_tiles]      piece holding the tile's first position
+    const long long *tile_lo;         // [2 * n_tiles]  {lowest coverage index the tile reads - 64 (or kTileSlow), chunks}
+    const chunk_desc_t *rows;         // [n_tiles][kMaxChunks]
     long long n_pieces;
     long long coverage_len;
 };
@@ -54,17 +50,17 @@ struct PiecePlan {
 inline size_t piece_plan_bytes(long long n_orfs, long long n_pieces, long long n_tiles)
 {
     auto up = [](size_t b) { return (b + 127) & ~(size_t)127; };
-    return up((size_t)(n_pieces + 1) * 8) * 2 + up((size_t)(n_orfs + 1) * 8) + up((size_t)n_tiles * 8) * 2 +
-           (size_t)n_tiles * kRowPieces * sizeof(piece_desc_t);
+    return up((size_t)(n_pieces + 1) * 8) * 2 + up((size_t)(n_orfs + 1) * 8) + up((size_t)n_tiles * 8) + up((size_t)n_tiles * 16) +
+           (size_t)n_tiles * kMaxChunks * sizeof(chunk_desc_t);
 }
 
 struct PiecePlanMem {
     unsigned long long *start;
     long long *base;
     long long *orf_piece;
-    long long *tile_next;
+    long long *tile_piece0;
     long long *tile_lo;
-    piece_desc_t *rows;
+    chunk_desc_t *rows;
 };
 
 inline PiecePlanMem carve_piece_plan(void *mem, long long n_orfs, long long n_pieces, long long n_tiles)
@@ -78,11 +74,11 @@ inline PiecePlanMem carve_piece_plan(void *mem, long long n_orfs, long long n_pi
     p += up((size_t)(n_pieces + 1) * 8);
     m.orf_piece = reinterpret_cast<long long *>(p);
     p += up((size_t)(n_orfs + 1) * 8);
-    m.tile_next = reinterpret_cast<long long *>(p);
+    m.tile_piece0 = reinterpret_cast<long long *>(p);
     p += up((size_t)n_tiles * 8);
     m.tile_lo = reinterpret_cast<long long *>(p);
-    p += up((size_t)n_tiles * 8);
-    m.rows = reinterpret_cast<piece_desc_t *>(p);
+    p += up((size_t)n_tiles * 16);
+    m.rows = reinterpret_cast<chunk_desc_t *>(p);
     return m;
 }
 
@@ -134,33 +130,51 @@ __global__ void k_piece_build(const int64_t *__restrict__ iv_start, const int32_
     if (bad) atomicOr(err, bad);
 }
 
-__device__ __forceinline__ piece_desc_t clip_piece(unsigned long long start_word, unsigned long long next_word,
-                                                   long long base, long long t0, long long t_end)
+// A piece clipped to [t0, t_end): first position (LDS index), positions, source index of the first.
+struct Clipped {
+    long long src;
+    int off, n;
+    bool neg;
+};
+
+__device__ __forceinline__ Clipped clip_piece(unsigned long long start_word, unsigned long long next_word,
+                                              long long base, long long t0, long long t_end)
 {
     const long long s = (long long)(start_word & ~kPieceNeg);
     const long long e = (long long)(next_word & ~kPieceNeg);
     const bool neg = (start_word & kPieceNeg) != 0;
     const long long a = s > t0 ? s : t0;
     const long long b = e < t_end ? e : t_end;
-    if (b <= a) return 0;
-    const long long src = neg ? base - a : base + a;
-    return (piece_desc_t)src | ((piece_desc_t)(a - t0) << kPieceOffAt) | ((piece_desc_t)(b - a) << kPieceNAt) |
-           ((piece_desc_t)(neg ? 1 : 0) << kPieceNegAt);
+    Clipped c;
+    c.neg = neg;
+    c.n = b > a ? (int)(b - a) : 0;
+    c.off = (int)(a - t0);
+    c.src = neg ? base - a : base + a;
+    return c;
 }
 
-// One workgroup of kRowPieces threads per tile: find the piece that holds the tile's first
-// position, clip it and its successors to [t0, t0 + TILE + HALO) and lay them into the row --
-// long ones as several slots of <= kSlotPositions positions, so that no thread of the staging
-// code has more than 8 chunks to cut.  tile_next[b] = the first piece that did not fit.
-constexpr int kSlotPositions = 512;
+__device__ __forceinline__ chunk_desc_t make_chunk(const Clipped &c, long long tile_lo, int k)
+{
+    const unsigned rel = (unsigned)(c.src - tile_lo);  // < 2^30 (checked by the caller)
+    const int left = c.n - 64 * k;
+    const unsigned cnt = left < 64 ? (unsigned)left : 64u;
+    const unsigned soff = (c.neg ? rel - 64u * k - 63u : rel + 64u * k) * 4u;
+    return (chunk_desc_t)soff | ((chunk_desc_t)(unsigned)(c.off + 64 * k) << 32) | ((chunk_desc_t)(64u - cnt) << 45) |
+           ((chunk_desc_t)(c.neg ? 1u : 0u) << 51);
+}
+
+// One workgroup per tile: find the piece that holds the tile's first position, clip the
+// tile's pieces to [t0, t0 + TILE + HALO), number their chunks and write the row.  A tile
+// with more than kMaxChunks chunks (or pieces > 4 GiB apart) is marked kTileSlow.
+constexpr int kRowBlock = 256;
 
 template <int TILE, int HALO>
-__global__ __launch_bounds__(kRowPieces) void k_piece_rows(PiecePlanMem plan, long long n_pieces, long long total_nt)
+__global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, long long n_pieces, long long total_nt)
 {
     __shared__ long long s_j0, s_lo, s_hi;
-    __shared__ int s_chunks, s_fit, s_more;
-    __shared__ int s_slot[kRowPieces], s_nsub[kRowPieces];
-    const int t = threadIdx.x;
+    __shared__ int s_total, s_base;
+    __shared__ int s_wave[kRowBlock / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const long long b = blockIdx.x;
     const long long t0 = b * (long long)TILE;
     long long t_end = t0 + TILE + HALO;
@@ -172,193 +186,76 @@ __global__ __launch_bounds__(kRowPieces) void k_piece_rows(PiecePlanMem plan, lo
             if ((long long)(plan.start[mid] & ~kPieceNeg) <= t0) lo = mid; else hi = mid;
         }
         s_j0 = lo;
+        plan.tile_piece0[b] = lo;
         s_lo = INT64_MAX;
         s_hi = INT64_MIN;
-        s_chunks = 0;
+        s_total = 0;
     }
     __syncthreads();
-    const long long j = s_j0 + t;
-    piece_desc_t d = 0;
-    if (j < n_pieces) d = clip_piece(plan.start[j], plan.start[j + 1], plan.base[j], t0, t_end);
-    const long long src = (long long)(d & ((1ull << kPieceOffAt) - 1));
-    const int off = (int)(d >> kPieceOffAt) & 0x1fff;
-    const int n = (int)(d >> kPieceNAt) & 0x1fff;
-    const bool neg = ((d >> kPieceNegAt) & 1) != 0;
-    const int nsub = (n + kSlotPositions - 1) / kSlotPositions;
-    s_nsub[t] = nsub;
-    plan.rows[b * kRowPieces + t] = 0;
-    __syncthreads();
-    if (t == 0) {  // slots of the pieces, in order; the first piece whose slots pass the row's end and all after it stay out
-        int acc = 0, fit = kRowPieces;
-        for (int k = 0; k < kRowPieces; ++k) {
-            s_slot[k] = acc;
-            acc += s_nsub[k];
-            if (acc > kRowPieces && fit == kRowPieces) fit = k;
+    // pass 1: extent and chunk count of ALL the tile's pieces (kRowBlock at a time)
+    for (long long j0 = s_j0;; j0 += kRowBlock) {  // workgroup-uniform
+        const long long j = j0 + t;
+        Clipped c{0, 0, 0, false};
+        if (j < n_pieces) c = clip_piece(plan.start[j], plan.start[j + 1], plan.base[j], t0, t_end);
+        if (c.n > 0) {
+            atomicMin(&s_lo, c.neg ? c.src - (c.n - 1) : c.src);
+            atomicMax(&s_hi, c.neg ? c.src : c.src + c.n - 1);
+            atomicAdd(&s_total, (c.n + 63) >> 6);
         }
-        int more = 0;
-        for (int k = fit; k < kRowPieces; ++k) more |= s_nsub[k];
-        const long long after = s_j0 + kRowPieces;  // the candidate pieces end here: does the tile go on?
-        if (after < n_pieces && (long long)(plan.start[after] & ~kPieceNeg) < t_end) more = 1;
-        s_fit = fit;
-        s_more = more != 0;
-        plan.tile_next[b] = s_j0 + fit;
+        const long long last = j0 + kRowBlock;  // does the tile go on past this batch?
+        if (!(last < n_pieces && (long long)(plan.start[last] & ~kPieceNeg) < t_end)) break;
     }
     __syncthreads();
-    if (t < s_fit && n > 0) {
-        for (int k = 0; k < nsub; ++k) {
-            const int nk = n - k * kSlotPositions < kSlotPositions ? n - k * kSlotPositions : kSlotPositions;
-            const long long sk = neg ? src - (long long)k * kSlotPositions : src + (long long)k * kSlotPositions;
-            plan.rows[b * kRowPieces + s_slot[t] + k] = (piece_desc_t)sk | ((piece_desc_t)(off + k * kSlotPositions) << kPieceOffAt) |
-                                                        ((piece_desc_t)nk << kPieceNAt) | ((piece_desc_t)(neg ? 1 : 0) << kPieceNegAt);
-        }
-        // eligibility for the chunk-table staging: the lowest / highest coverage index and the chunk count
-        atomicMin(&s_lo, neg ? src - (n - 1) : src);
-        atomicMax(&s_hi, neg ? src : src + n - 1);
-        atomicAdd(&s_chunks, (n + 63) >> 6);
-    }
-    __syncthreads();
+    const bool fast = s_total > 0 && s_total <= kMaxChunks && s_hi - s_lo < (1ll << 30) - 256;
+    const long long tile_lo = fast ? s_lo - 64 : kTileSlow;
     if (t == 0) {
-        if (s_more) plan.rows[b * kRowPieces + kRowPieces - 1] |= (piece_desc_t)1 << kPieceMoreAt;
-        // (a slot boundary may add a chunk to a piece whose length is not a multiple of 64: none -- 512 is)
-        const bool fast = !s_more && s_chunks > 0 && s_chunks <= kMaxChunks && s_hi - s_lo < (1ll << 30) - 256;
-        plan.tile_lo[b] = fast ? s_lo - 64 : kTileSlow;
+        plan.tile_lo[2 * b] = tile_lo;
+        plan.tile_lo[2 * b + 1] = s_total;
+        s_base = 0;
     }
+    if (!fast) return;  // (the row stays unwritten: never read)
+    // pass 2: the chunks, numbered by a prefix sum over the pieces
+    chunk_desc_t *row = plan.rows + b * kMaxChunks;
+    for (long long j0 = s_j0;; j0 += kRowBlock) {
+        const long long j = j0 + t;
+        Clipped c{0, 0, 0, false};
+        if (j < n_pieces) c = clip_piece(plan.start[j], plan.start[j + 1], plan.base[j], t0, t_end);
+        const int nch = (c.n + 63) >> 6;
+        int incl = nch;
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);
+        __syncthreads();  // (s_wave / s_base of the previous batch are consumed)
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int c0 = s_base + incl - nch;
+        for (int w = 0; w < wave; ++w) c0 += s_wave[w];
+        for (int k = 0; k < nch; ++k) row[c0 + k] = make_chunk(c, tile_lo, k);
+        __syncthreads();
+        if (t == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        const long long last = j0 + kRowBlock;
+        if (!(last < n_pieces && (long long)(plan.start[last] & ~kPieceNeg) < t_end)) break;
+    }
+    __syncthreads();
+    // pad: the slots past the last chunk repeat chunk 0 (written by the thread that owns position t0)
+    __threadfence_block();
+    const chunk_desc_t first = row[0];
+    for (int c = s_total + t; c < kMaxChunks; c += kRowBlock) row[c] = first;
 }
 
 // ---------------------------------------------------------------------------------------
-// Staging a tile: every wave takes the pieces held by the lanes l == wave (mod 4), one after
-// the other, 64 positions per LDS-DMA instruction.  The global address is a scalar base plus
-// a per-lane constant (lane * 4 going up the coverage array, (63 - lane) * 4 going down), so
-// a chunk costs one v_cmp for the ragged end and scalar arithmetic.  Not waited for here.
-// ---------------------------------------------------------------------------------------
-// One LDS-DMA instruction: lanes [0, live) load 4 bytes each from g + lane offset + OFF into
-// lds + OFF + 4 * lane (the instruction offset applies to both sides).
-template <int OFF>
-__device__ __forceinline__ void dma_chunk(const char *g, unsigned lane_off, int *lds)
-{
-    typedef const __attribute__((address_space(1))) void *gptr_t;
-    typedef __attribute__((address_space(3))) void *lptr_t;
-    __builtin_amdgcn_global_load_lds((gptr_t)(g + lane_off), (lptr_t)lds, 4, OFF, 0);
-}
-
-// up to 16 consecutive full chunks going UP the coverage array: one address, one M0, immediate offsets
-__device__ __forceinline__ void dma_run_up(const char *g, unsigned lane_off, int *lds, int chunks)
-{
-#define RP_UP(C) if (chunks > C) dma_chunk<256 * C>(g, lane_off, lds)
-    RP_UP(0); RP_UP(1); RP_UP(2); RP_UP(3); RP_UP(4); RP_UP(5); RP_UP(6); RP_UP(7);
-    RP_UP(8); RP_UP(9); RP_UP(10); RP_UP(11); RP_UP(12); RP_UP(13); RP_UP(14); RP_UP(15);
-#undef RP_UP
-}
-
-// going DOWN the coverage array the two sides move in opposite directions: the instruction
-// offset walks the global side (-256 per chunk), the LDS pointer makes up for it (+512)
-__device__ __forceinline__ void dma_run_down(const char *g, unsigned lane_off, int *lds, int chunks)
-{
-#define RP_DOWN(C) if (chunks > C) dma_chunk<-256 * C>(g, lane_off, lds + 128 * C)
-    RP_DOWN(0); RP_DOWN(1); RP_DOWN(2); RP_DOWN(3); RP_DOWN(4); RP_DOWN(5); RP_DOWN(6); RP_DOWN(7);
-    RP_DOWN(8); RP_DOWN(9); RP_DOWN(10); RP_DOWN(11); RP_DOWN(12); RP_DOWN(13); RP_DOWN(14); RP_DOWN(15);
-#undef RP_DOWN
-}
-
-__device__ __forceinline__ void stage_piece(const int32_t *__restrict__ cov, piece_desc_t d, int *s_counts, int lane)
-{
-    const long long src = (long long)(d & ((1ull << kPieceOffAt) - 1));
-    const int off = (int)(d >> kPieceOffAt) & 0x1fff;
-    const int n = (int)(d >> kPieceNAt) & 0x1fff;
-    const bool neg = ((d >> kPieceNegAt) & 1) != 0;
-    int full = n >> 6;
-    const int rest = n & 63;
-    int *lds = s_counts + off;
-    if (!neg) {
-        const unsigned up4 = (unsigned)lane * 4u;
-        const char *g = reinterpret_cast<const char *>(cov + src);
-        while (full > 16) {  // (pieces of more than 1 024 positions)
-            dma_run_up(g, up4, lds, 16);
-            g += 4096, lds += 1024, full -= 16;
-        }
-        dma_run_up(g, up4, lds, full);
-        if (lane < rest) dma_chunk<0>(g + 256 * full, up4, lds + 64 * full);
-    } else {
-        const unsigned down4 = (unsigned)(63 - lane) * 4u;
-        const char *g = reinterpret_cast<const char *>(cov + src - 63);
-        while (full > 16) {
-            dma_run_down(g, down4, lds, 16);
-            g -= 4096, lds += 1024, full -= 16;
-        }
-        dma_run_down(g, down4, lds, full);
-        if (lane < rest) dma_chunk<0>(g - 256 * full, down4, lds + 64 * full);
-    }
-}
-
-__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l)
-{
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
-    return ((unsigned long long)hi << 32) | lo;
-}
-
-// the descriptors one per lane -> this wave stages those of lanes wave, wave + 4, ...
-__device__ __forceinline__ void stage_round(const int32_t *__restrict__ cov, piece_desc_t mine, int *s_counts, int lane, int wave)
-{
-#pragma unroll 1
-    for (int l = wave; l < 64; l += 4) {
-        const piece_desc_t d = readlane_u64(mine, l);
-        if (d != 0) stage_piece(cov, d, s_counts, lane);
-    }
-}
-
-// The row as two halves of 128 slots; lane l holds slots 2l, 2l + 1 of each half.
-__device__ __forceinline__ const uint4 *piece_row_ptr(const PiecePlan &pp, long long b, int lane, int half)
-{
-    return reinterpret_cast<const uint4 *>(pp.rows + b * kRowPieces + half * (kRowPieces / 2)) + lane;
-}
-
-__device__ __forceinline__ void stage_half(const int32_t *__restrict__ cov, uint4 h, int *s_counts, int lane, int wave)
-{
-    stage_round(cov, ((piece_desc_t)h.y << 32) | h.x, s_counts, lane, wave);
-    stage_round(cov, ((piece_desc_t)h.w << 32) | h.z, s_counts, lane, wave);
-}
-
-// Stage tile b (positions [t0, min(t0 + TILE + HALO, total_nt))) given this lane's row words.
-template <int TILE, int HALO>
-__device__ __forceinline__ void stage_tile(const int32_t *__restrict__ cov, const PiecePlan &pp, long long b,
-                                           long long total_nt, uint4 lo, uint4 hi, int *s_counts, int lane, int wave)
-{
-    stage_half(cov, lo, s_counts, lane, wave);
-    const unsigned more = (unsigned)__builtin_amdgcn_readlane((int)(hi.w >> (kPieceMoreAt - 32)) & 1, 63);
-    if (!more && __builtin_amdgcn_readlane((int)(hi.x | hi.y), 0) == 0) return;  // slots fill in order: <= 128 of them
-    stage_half(cov, hi, s_counts, lane, wave);
-    if (more) {  // rare: more than kRowPieces pieces in the tile (runs of very short exons / ORFs)
-        const long long t0 = b * (long long)TILE;
-        long long t_end = t0 + TILE + HALO;
-        if (t_end > total_nt) t_end = total_nt;
-        long long j = pp.tile_next[b];
-        for (;;) {  // wave-uniform
-            piece_desc_t d = 0;
-            if (j + lane < pp.n_pieces) d = clip_piece(pp.start[j + lane], pp.start[j + lane + 1], pp.base[j + lane], t0, t_end);
-            stage_round(cov, d, s_counts, lane, wave);
-            j += 64;
-            if (__builtin_amdgcn_readlane((int)(d != 0), 63) == 0) break;  // the list ran past the tile
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// The fast staging path.  The scalar loop above spends ~1 000 cycles per piece on a busy CU
-// (two lane reads, a decode and a branch chain per piece, at one instruction per ~10 cycles
-// next to three other workgroups' lane runs); here the per-piece work is done by the vector
-// unit, one piece per THREAD, and the DMA is issued from straight-line code:
-//   1. thread t cuts the row's piece t into chunks of <= 64 positions; a workgroup-wide prefix
-//      sum numbers them; each thread writes its chunks into a table in LDS:
-//         bits 0-31 byte offset of the chunk's lowest-lane element from cov + tile_lo
-//         bits 32-44 LDS index   45-50 64 - positions   51 the source index falls
-//   2. wave w, lane i takes chunk 4 i + w and keeps (offset, LDS address | shift << 16 | dir << 24)
-//      in two registers;
-//   3. 64 unrolled steps -- two lane reads, M0, the EXEC mask of the ragged end, two VALU for
-//      the lane's byte offset ((lane or 63 - lane) * 4 + chunk offset), one global_load_lds with
-//      a scalar base -- no branches but an exit test every 8 steps.  Lanes past the last chunk
-//      hold chunk 0 again (staging a chunk twice is harmless).
-// `s_tab`: kMaxChunks 8-byte words, `s_part`: 4 ints of LDS scratch, both dead afterwards.
+// Staging a tile, the fast path.  Wave w, lane i takes chunk 4 i + w of the row (64 lanes x 4
+// waves = the first 256 chunks; a second round takes the rest) and keeps
+//   w0 = the chunk's byte offset, w1 = LDS address | (64 - positions) << 16 | dir << 24
+// in two registers; then 64 unrolled steps -- two lane reads, M0, the EXEC mask of the ragged
+// end, two VALU for the lane's byte offset ((lane or 63 - lane) * 4 + chunk offset), one
+// global_load_lds with a scalar base -- no branches but an exit test every 8 steps.  (A scalar
+// loop over pieces, with its decode and branch chain, was measured at ~1 000 cycles per piece
+// next to three other workgroups' lane runs: one instruction per ~10 cycles.)
+// Nothing is waited for here.
 // ---------------------------------------------------------------------------------------
 #define RP_DMA_STEP(I)                                          \
     "v_readlane_b32 %[so], %[w0], " #I "\n\t"                   \
@@ -399,52 +296,83 @@ __device__ __forceinline__ void issue_chunks(const int32_t *base, unsigned w0, u
 #undef RP_DMA_STEP8
 #undef RP_DMA_STEP
 
-// all kRowPieces threads of the workgroup; `mine` = the row's piece threadIdx.x
-__device__ __forceinline__ void stage_tile_chunks(const int32_t *__restrict__ cov, long long tile_lo, piece_desc_t mine,
-                                                  unsigned long long *s_tab, int *s_part, int *s_counts, int tid)
+// pin a workgroup-uniform pointer to scalar registers (an "s" asm operand alone does not)
+__device__ __forceinline__ const int32_t *scalar_ptr(const int32_t *p)
 {
-    const int lane = tid & 63, wave = tid >> 6;
-    const long long src = (long long)(mine & ((1ull << kPieceOffAt) - 1));
-    const int off = (int)(mine >> kPieceOffAt) & 0x1fff;
-    const int n = (int)(mine >> kPieceNAt) & 0x1fff;
-    const unsigned neg = (unsigned)(mine >> kPieceNegAt) & 1u;
-    const int nch = (n + 63) >> 6;
-    // exclusive prefix of the chunk counts over the workgroup
-    int incl = nch;
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);
-    if (lane == 63) s_part[wave] = incl;
-    __syncthreads();
-    const int p0 = s_part[0], p1 = s_part[1], p2 = s_part[2], p3 = s_part[3];
-    const int total = p0 + p1 + p2 + p3;
-    const int c0 = (wave > 0 ? p0 : 0) + (wave > 1 ? p1 : 0) + (wave > 2 ? p2 : 0) + incl - nch;
-    const unsigned rel = (unsigned)(src - tile_lo);  // < 2^30 (k_piece_rows checked)
-    for (int k = 0; k < nch; ++k) {
-        const int left = n - 64 * k;
-        const unsigned cnt = left < 64 ? (unsigned)left : 64u;
-        const unsigned soff = (neg ? rel - 64u * k - 63u : rel + 64u * k) * 4u;
-        s_tab[c0 + k] = (unsigned long long)soff | ((unsigned long long)(unsigned)(off + 64 * k) << 32) |
-                        ((unsigned long long)(64u - cnt) << 45) | ((unsigned long long)neg << 51);
-    }
-    __syncthreads();
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) int *)s_counts;
-    const unsigned long long base_u = (unsigned long long)(cov + tile_lo);  // workgroup-uniform: pin it to scalar registers
-    const int32_t *base = reinterpret_cast<const int32_t *>(
-        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base_u >> 32)) << 32) |
-        (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base_u));
-    for (int r0 = 0; r0 < total; r0 += 4 * 64) {  // workgroup-uniform
-        const int c = r0 + 4 * lane + wave;
-        const unsigned long long e = s_tab[c < total ? c : 0];
-        const unsigned w0 = (unsigned)e;
+    const unsigned long long u = (unsigned long long)p;
+    return reinterpret_cast<const int32_t *>(
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32)) << 32) |
+        (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u));
+}
+
+__device__ __forceinline__ unsigned lds_address(const int *p)
+{
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const int *)p;
+}
+
+// the row slot of round 0 that this thread keeps: chunk 4 * lane + wave
+__device__ __forceinline__ const chunk_desc_t *chunk_slot(const PiecePlan &pp, long long b, int lane, int wave)
+{
+    return pp.rows + b * kMaxChunks + 4 * lane + wave;
+}
+
+// `e`: the thread's round-0 chunk (already loaded); total: the tile's chunk count
+__device__ __forceinline__ void stage_tile_chunks(const int32_t *__restrict__ cov, const PiecePlan &pp, long long b,
+                                                  long long tile_lo, int total, chunk_desc_t e, int *s_counts, int lane, int wave)
+{
+    const unsigned lds0 = lds_address(s_counts);
+    const int32_t *base = scalar_ptr(cov + tile_lo);
+    for (int r0 = 0;; r0 += 256) {  // workgroup-uniform; one round unless the tile has > 256 chunks
         const unsigned hi = (unsigned)(e >> 32);
         const unsigned w1 = (lds0 + (hi & 0x1fffu) * 4u) | (((hi >> 13) & 0x3fu) << 16) | (((hi >> 19) & 1u) << 24);
         int steps = (total - r0 - wave + 3) >> 2;  // chunks r0 + wave, r0 + wave + 4, ... < total
         steps = __builtin_amdgcn_readfirstlane(steps > 64 ? 64 : steps);
-        if (steps > 0) issue_chunks(base, w0, w1, steps, lane);
+        if (steps > 0) issue_chunks(base, (unsigned)e, w1, steps, lane);
+        if (r0 + 256 >= total) break;
+        const int c = r0 + 256 + 4 * lane + wave;
+        e = pp.rows[b * kMaxChunks + (c < kMaxChunks ? c : 0)];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The slow path (a tile with more chunks than a row holds: runs of very short exons, or
+// pieces > 4 GiB apart): the pieces straight from the global list, 64 at a time, one lane
+// each; the wave then issues every piece's chunks from a scalar loop.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_piece_slow(const int32_t *__restrict__ cov, long long src, int off, int n, bool neg,
+                                                 int *s_counts, int lane)
+{
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    for (int c0 = 0; c0 < n; c0 += 64) {  // wave-uniform
+        if (lane < n - c0) {
+            const int32_t *g = neg ? cov + (src - c0 - lane) : cov + (src + c0 + lane);
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(s_counts + off + c0), 4, 0, 0);
+        }
+    }
+}
+
+template <int TILE, int HALO>
+__device__ __forceinline__ void stage_tile_slow(const int32_t *__restrict__ cov, const PiecePlan &pp, long long b,
+                                                long long total_nt, int *s_counts, int lane, int wave)
+{
+    const long long t0 = b * (long long)TILE;
+    long long t_end = t0 + TILE + HALO;
+    if (t_end > total_nt) t_end = total_nt;
+    long long j = pp.tile_piece0[b];
+    for (;;) {  // wave-uniform: every wave walks the whole list and takes the pieces of lanes wave, wave + 4, ...
+        Clipped c{0, 0, 0, false};
+        if (j + lane < pp.n_pieces) c = clip_piece(pp.start[j + lane], pp.start[j + lane + 1], pp.base[j + lane], t0, t_end);
+        for (int l = wave; l < 64; l += 4) {
+            const int n = __builtin_amdgcn_readlane(c.n, l);
+            if (n == 0) continue;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)c.src, l);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)c.src >> 32), l);
+            stage_piece_slow(cov, (long long)(((unsigned long long)hi << 32) | lo), __builtin_amdgcn_readlane(c.off, l), n,
+                             __builtin_amdgcn_readlane((int)c.neg, l) != 0, s_counts, lane);
+        }
+        j += 64;
+        if (!(j < pp.n_pieces && (long long)(pp.start[j] & ~kPieceNeg) < t_end)) break;  // the list ran past the tile
     }
 }
 
@@ -490,19 +418,14 @@ template <int TILE, int HALO>
 __global__ __launch_bounds__(kGatherTileBlock) void k_tile_gather(const int32_t *__restrict__ cov, PiecePlan pp,
                                                                   long long total_nt, int32_t *__restrict__ counts)
 {
-    static_assert(kGatherTileBlock == kRowPieces, "one thread per row slot");
     __shared__ __attribute__((aligned(16))) int s_counts[TILE + HALO];  // the rows are clipped for the scorer: halo included
-    __shared__ unsigned long long s_tab[kMaxChunks];
-    __shared__ int s_part[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long b = blockIdx.x;
-    const long long tile_lo = pp.tile_lo[b];
-    if (tile_lo != kTileSlow) {
-        stage_tile_chunks(cov, tile_lo, pp.rows[b * kRowPieces + tid], s_tab, s_part, s_counts, tid);
-    } else {
-        const uint4 lo = *piece_row_ptr(pp, b, lane, 0), hi = *piece_row_ptr(pp, b, lane, 1);
-        stage_tile<TILE, HALO>(cov, pp, b, total_nt, lo, hi, s_counts, lane, wave);
-    }
+    const long long tile_lo = pp.tile_lo[2 * b];
+    if (tile_lo != kTileSlow)
+        stage_tile_chunks(cov, pp, b, tile_lo, (int)pp.tile_lo[2 * b + 1], *chunk_slot(pp, b, lane, wave), s_counts, lane, wave);
+    else
+        stage_tile_slow<TILE, HALO>(cov, pp, b, total_nt, s_counts, lane, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const long long t0 = b * (long long)TILE;

@@ -760,20 +760,19 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
                      : "memory");
     }
     if constexpr (FUSED) {
-        // The tile's piece row (one piece per thread) arrives with the head row: one wait for both,
-        // here -- the DMA issued next must not sit in front of them.  Rows the chunk table cannot
-        // take (tile_lo == kTileSlow: rare) go through the scalar path.
-        static_assert(kTileBlock == kRowPieces && sizeof(s_rec) >= kMaxChunks * 8, "chunk table aliases s_rec");
-        const long long tile_lo = pp.tile_lo[b];
-        piece_desc_t mine;
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(mine) : "v"(pp.rows + b * kRowPieces + tid) : "memory");
+        // The thread's chunk of the tile's row (rp_pieces.hpp) arrives with the head row: one wait
+        // for both, here -- the DMA issued next must not sit in front of them.
+        const long long tile_lo = pp.tile_lo[2 * b];
+        const int n_chunks = (int)pp.tile_lo[2 * b + 1];
+        chunk_desc_t mine;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(mine) : "v"(chunk_slot(pp, b, lane, wave)) : "memory");
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(d), "+v"(vmap), "+v"(mine) : : "memory");
-        if (tile_lo != kTileSlow) {
-            stage_tile_chunks(counts, tile_lo, mine, reinterpret_cast<unsigned long long *>(s_rec), s_owner, s_counts, tid);
-        } else {
-            const uint4 lo = *piece_row_ptr(pp, b, lane, 0), hi = *piece_row_ptr(pp, b, lane, 1);
-            stage_tile<kTile, kHalo>(counts, pp, b, plan.total_nt, lo, hi, s_counts, lane, wave);
-        }
+        __builtin_amdgcn_s_setprio(3);  // scalar-heavy and on the critical path: ahead of the other workgroups' lane runs
+        if (tile_lo != kTileSlow)
+            stage_tile_chunks(counts, pp, b, tile_lo, n_chunks, mine, s_counts, lane, wave);
+        else
+            stage_tile_slow<kTile, kHalo>(counts, pp, b, plan.total_nt, s_counts, lane, wave);
+        __builtin_amdgcn_s_setprio(0);
     } else {
         load_tile_to_lds(counts, t0, plan.total_nt, s_counts, tid);
     }

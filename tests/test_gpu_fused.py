@@ -35,7 +35,8 @@ def numpy_gather(cov, t):
 
 CASES = {
     "exons": dict(n=4000, max_exons=6, exon_len=(1, 400), special=((5, 150), (6, 64), (7, 65), (3999, 70))),
-    "tiny_exons": dict(n=3000, max_exons=40, exon_len=(1, 3)),       # > 128 pieces per tile: the overflow rounds
+    "tiny_exons": dict(n=3000, max_exons=40, exon_len=(1, 3)),       # far more chunks than a row holds: the slow path
+    "small_exons": dict(n=6000, max_exons=12, exon_len=(8, 40)),      # rows near the 352-chunk limit: both paths, second round
     "single_long": dict(n=300, max_exons=1, exon_len=(5000, 30000)),  # pieces spanning several tiles
     "short_orfs": dict(n=20000, max_exons=1, exon_len=(60, 150)),
 }
@@ -80,7 +81,7 @@ def test_unplannable_tables():
 
 
 @pytest.mark.parametrize("lam", [0.01, 0.3, 3.0])
-@pytest.mark.parametrize("case", ["exons", "tiny_exons", "single_long", "short_orfs"])
+@pytest.mark.parametrize("case", list(CASES))
 def test_fused_score_equals_gather_then_score(case, lam):
     import torch
 
