@@ -10,6 +10,7 @@ cfg5  long-tail stress: lognormal body (mean ~100 codons) + Pareto(1.5) tail cli
 gencode  a candidate-index-like law (prepare_orfs.py:217 emits every uORF / dORF / overlapping
       ORF >= --min_orf_length, cli.py:64-69): 60 % of the ORFs short, uniform 20..50 codons
       (60-150 nt), the rest cfg3's lognormal with median 120 codons.
+orf60  every ORF 60 nt, the CLI minimum: the worst case for per-segment overheads.
 
 Lengths always come from numpy (identical on every machine for a given seed).  Counts
 come from numpy on the host (tests: the oracle and the GPU must see the same bytes) or
@@ -25,6 +26,7 @@ CONFIGS = {
     "cfg3": dict(sigma=0.9, median_codons=80, frac_non_mult3=0.01, pareto_frac=0.0),
     "cfg5": dict(sigma=0.7, median_codons=78, frac_non_mult3=0.01, pareto_frac=0.02),
     "gencode": dict(sigma=0.9, median_codons=120, frac_non_mult3=0.01, pareto_frac=0.0, short_frac=0.6),
+    "orf60": dict(sigma=0.9, median_codons=80, frac_non_mult3=0.0, pareto_frac=0.0, short_frac=1.0, short_codons=(20, 21)),
 }
 LAMBDAS = np.array([0.0, 0.05, 0.3, 2.0])
 LAMBDA_P = np.array([0.2, 0.3, 0.3, 0.2])
@@ -40,7 +42,8 @@ def orf_lengths(n_orfs: int, seed: int, cfg: str = "cfg2") -> np.ndarray:
         k[tail] = 300.0 * (1.0 + rng.pareto(1.5, size=int(tail.sum())))
     if c.get("short_frac", 0.0) > 0:
         short = rng.random(n_orfs) < c["short_frac"]
-        k[short] = rng.integers(20, 51, size=int(short.sum()))
+        lo, hi = c.get("short_codons", (20, 51))
+        k[short] = rng.integers(lo, hi, size=int(short.sum()))
     k = np.clip(k, 20, MAX_CODONS).astype(np.int64)
     lengths = 3 * k
     if c["frac_non_mult3"] > 0:
