@@ -294,7 +294,8 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     (only the translating ORFs are printed): gather and score are FUSED -- the scorer stages its
     tiles straight from the dense coverage (``rp_phase_score_coverage_dev``), the profiles are
     never written to HBM -- and only the translating ORFs' profiles are gathered afterwards;
-    ``offsets`` then gives every other ORF an empty range."""
+    ``offsets`` then gives every other ORF an empty range.  With several ``devices`` both modes
+    shard the ORFs (``engine.score_sharded`` / ``engine.score_coverage_sharded``)."""
     import numpy as np
     import torch
 
@@ -306,20 +307,26 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     table = interval_table_from_index(index, base)
     plan = make_gather_plan(table, coverage.numel(), device)
     sharded = devices is not None and len(devices) > 1
-    if plan is None or report_all or sharded:
+    if plan is None or report_all:
         d_counts, d_offsets = gather_profiles_device(coverage, table, device, plan=plan)
         res = score_profiles(
             d_counts, d_offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
             min_valid_codons_ratio, min_density_over_orf, device=device, devices=devices,
         )
         return d_counts.cpu().numpy(), d_offsets.cpu().numpy(), res
-    eng = get_engine(device)
     thresholds = make_filter(
         phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio, min_density_over_orf
     )
-    res = eng.score_coverage(coverage, plan, thresholds=thresholds)
-    torch.cuda.synchronize(eng.device)
-    res = res.cpu_numpy()
+    if sharded:
+        from .engine import score_coverage_sharded
+
+        del plan
+        res = score_coverage_sharded(coverage, table, devices, thresholds=thresholds)
+    else:
+        eng = get_engine(device)
+        res = eng.score_coverage(coverage, plan, thresholds=thresholds)
+        torch.cuda.synchronize(eng.device)
+        res = res.cpu_numpy()
     keep = res["status"] != 0
     chosen = np.flatnonzero(keep)
     d_counts, _ = gather_profiles_device(coverage, select_orfs(table, chosen), device)

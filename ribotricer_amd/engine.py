@@ -431,6 +431,42 @@ def score_sharded(counts, offsets, devices: Sequence, thresholds: Optional[Filte
     return concat_results(parts)
 
 
+def score_coverage_sharded(coverage, table, devices: Sequence, thresholds: Optional[FilterParams] = None) -> dict:
+    """The fused gather + score (:meth:`PhaseScoreEngine.score_coverage`) on several GPUs of this
+    node: ``table`` (``gather.IntervalTable``) is cut into nt-balanced contiguous ORF-index slices,
+    every device gets a copy of the dense coverage and the gather plan of ITS slice, results are
+    concatenated on the host.  No collective; the profiles exist on no device.  Raises
+    ``RibophaseError`` (status ``ERR_INTERVALS``) for a table that cannot be planned."""
+    from .gather import GatherPlan, select_orfs
+    from .sharding import concat_results, slice_bounds
+
+    devs = [torch.device(d) if not isinstance(d, int) else torch.device("cuda", d) for d in devices]
+    if not devs:
+        raise ValueError("score_coverage_sharded needs at least one device")
+    bounds = slice_bounds(np.asarray(table.offsets, np.int64), len(devs))
+
+    def work(k: int) -> dict:
+        dev = devs[k]
+        lo, hi = int(bounds[k]), int(bounds[k + 1])
+        eng = get_engine(dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                cov = _as_device(coverage, torch.int32, dev)
+                plan = GatherPlan(select_orfs(table, np.arange(lo, hi, dtype=np.int64)), cov.numel(), dev)
+                res = eng.score_coverage(cov, plan, thresholds=thresholds)
+                host = {k_: (None if v is None else v.cpu()) for k_, v in res._asdict().items()}
+            stream.synchronize()
+        return {k_: (None if v is None else v.numpy()) for k_, v in host.items()}
+
+    if len(devs) == 1:
+        parts = [work(0)]
+    else:
+        with ThreadPoolExecutor(max_workers=len(devs)) as pool:
+            parts = list(pool.map(work, range(len(devs))))
+    return concat_results(parts)
+
+
 def phase_score_csr(counts, offsets, thresholds: Optional[FilterParams] = None, algo: str = "auto", device=None) -> PhaseScores:
     """Functional form of :meth:`PhaseScoreEngine.score`."""
     return get_engine(device).score(counts, offsets, thresholds=thresholds, algo=algo)

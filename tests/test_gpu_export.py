@@ -157,3 +157,12 @@ def test_export_sharded_over_two_slices_equals_single(tmp_path):
         del os.environ["RIBOTRICER_AMD_DEVICES"]
     one = open(str(tmp_path / "one_translating_ORFs.tsv")).read()
     assert one == open(str(tmp_path / "two_translating_ORFs.tsv")).read() == open(str(tmp_path / "env_translating_ORFs.tsv")).read()
+    # default mode: the fused gather + score, sharded the same way (engine.score_coverage_sharded)
+    export_orf_coverages(index, load_alignments(), str(tmp_path / "d1"))
+    export_orf_coverages(index, load_alignments(), str(tmp_path / "d3"), devices=[0, 0, 0])
+    d1 = [line.split("\t") for line in open(str(tmp_path / "d1_translating_ORFs.tsv"))]
+    d3 = [line.split("\t") for line in open(str(tmp_path / "d3_translating_ORFs.tsv"))]
+    assert len(d1) == len(d3) == 64  # header + the 63 translating ORFs of the fixture
+    assert d1[0] == d3[0]
+    for a, b in zip(d1[1:], d3[1:]):  # the tile path: another slicing moves the fp32 partial sums by <= 2e-7
+        assert a[:3] == b[:3] and a[4:] == b[4:] and abs(float(a[3]) - float(b[3])) <= 1e-6
