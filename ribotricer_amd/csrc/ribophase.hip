@@ -819,7 +819,9 @@ int rp_index_parse_host(const char *text, size_t len, int skip_header, rp_index 
     if (!h) return fail(RP_ERR_SIZE, "out of memory");
     int rc = rpidx::kOk;
     try {
-        rc = rpidx::parse(text, len, skip_header != 0, h->ix);
+        // RIBOPHASE_INDEX_THREADS: parser threads (default: up to 8; 1 = one sequential pass)
+        const char *env = std::getenv("RIBOPHASE_INDEX_THREADS");
+        rc = rpidx::parse(text, len, skip_header != 0, h->ix, env ? std::atoi(env) : 0);
     } catch (const std::bad_alloc &) {
         delete h;
         return fail(RP_ERR_SIZE, "out of memory while parsing the index");

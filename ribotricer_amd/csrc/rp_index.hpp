@@ -22,6 +22,7 @@
 #include <cstring>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -102,7 +103,8 @@ inline std::string_view start_codon(std::string_view s)
 
 // Parse `text` (the whole file).  Lines end at '\n' (kept on the line, as Python's file
 // iteration does); `skip_header` drops the first line (detect_orfs.py:273).
-inline int parse(const char *text, size_t len, bool skip_header, Index &ix)
+// One contiguous run of whole lines (group ids are local to the run: order of first appearance).
+inline int parse_run(const char *text, size_t len, bool skip_header, Index &ix)
 {
     ix = Index();
     ix.orf_iv.push_back(0);
@@ -226,6 +228,119 @@ inline int parse(const char *text, size_t len, bool skip_header, Index &ix)
         }
         ix.tail.append(start_codon(f[9]));
         ix.tail_off.push_back((int64_t)ix.tail.size());
+    }
+    return kOk;
+}
+
+inline int64_t count_lines(const char *text, size_t len)
+{
+    int64_t n = 0;
+    for (const char *p = text, *e = text + len; p < e;) {
+        const char *nl = (const char *)std::memchr(p, '\n', (size_t)(e - p));
+        ++n;
+        if (!nl) break;
+        p = nl + 1;
+    }
+    return n;
+}
+
+template <typename T>
+inline void append_shifted(std::vector<T> &dst, const std::vector<T> &src, size_t skip, T shift)
+{
+    const size_t at = dst.size();
+    dst.resize(at + src.size() - skip);
+    for (size_t k = skip; k < src.size(); ++k) dst[at + k - skip] = src[k] + shift;
+}
+
+// The whole index text: cut into runs of whole lines, one per thread, parsed independently and
+// stitched together in file order -- same arrays, same group numbering (first appearance in the
+// file) and the same first malformed line as one sequential pass.
+inline int parse(const char *text, size_t len, bool skip_header, Index &ix, int threads = 0)
+{
+    if (threads <= 0) {
+        threads = (int)std::thread::hardware_concurrency();
+        threads = threads > 8 ? 8 : (threads < 1 ? 1 : threads);
+    }
+    const size_t min_run = (size_t)4 << 20;
+    if ((size_t)threads > len / min_run) threads = (int)(len / min_run);
+    if (threads <= 1) return parse_run(text, len, skip_header, ix);
+    std::vector<size_t> cut(threads + 1, len);
+    cut[0] = 0;
+    for (int t = 1; t < threads; ++t) {  // the first line start at or after t/threads of the text
+        size_t p = len / threads * t;
+        if (p < cut[t - 1]) p = cut[t - 1];
+        const char *nl = p == 0 ? nullptr : (const char *)std::memchr(text + p - 1, '\n', len - (p - 1));
+        cut[t] = p == 0 ? 0 : (nl ? (size_t)(nl - text) + 1 : len);
+    }
+    std::vector<Index> part(threads);
+    std::vector<int> rc(threads, kOk);
+    {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t)
+            pool.emplace_back([&, t] { rc[t] = parse_run(text + cut[t], cut[t + 1] - cut[t], skip_header && t == 0, part[t]); });
+        for (auto &th : pool) th.join();
+    }
+    ix = Index();
+    for (int t = 0; t < threads; ++t) {  // the first malformed line of the file
+        if (rc[t] != kOk) {
+            ix.error_line = count_lines(text, cut[t]) + part[t].error_line;
+            return rc[t];
+        }
+    }
+    size_t n = 0, n_iv = 0, n_head = 0, n_tail = 0;
+    for (const Index &p : part) {
+        n += p.length.size();
+        n_iv += p.iv_start.size();
+        n_head += p.head.size();
+        n_tail += p.tail.size();
+    }
+    ix.orf_iv.reserve(n + 1);
+    ix.length.reserve(n);
+    ix.group.reserve(n);
+    ix.reverse.reserve(n);
+    ix.iv_start.reserve(n_iv);
+    ix.iv_end.reserve(n_iv);
+    ix.head.reserve(n_head);
+    ix.tail.reserve(n_tail);
+    ix.head_off.reserve(n + 1);
+    ix.tail_off.reserve(n + 1);
+    ix.orf_iv.push_back(0);
+    ix.head_off.push_back(0);
+    ix.tail_off.push_back(0);
+    ix.group_off.push_back(0);
+    std::unordered_map<std::string, int32_t> groups;
+    for (Index &p : part) {
+        // this run's groups, in its order of first appearance, against the file-wide numbering
+        std::vector<int32_t> remap(p.group_lo.size());
+        for (size_t g = 0; g < remap.size(); ++g) {
+            const std::string key = p.group_names.substr((size_t)p.group_off[g], (size_t)(p.group_off[g + 1] - p.group_off[g]));
+            auto it = groups.find(key);
+            if (it == groups.end()) {
+                remap[g] = (int32_t)groups.size();
+                groups.emplace(key, remap[g]);
+                ix.group_names.append(key);
+                ix.group_off.push_back((int64_t)ix.group_names.size());
+                ix.group_lo.push_back(p.group_lo[g]);
+                ix.group_hi.push_back(p.group_hi[g]);
+            } else {
+                remap[g] = it->second;
+                ix.group_lo[remap[g]] = std::min(ix.group_lo[remap[g]], p.group_lo[g]);
+                ix.group_hi[remap[g]] = std::max(ix.group_hi[remap[g]], p.group_hi[g]);
+            }
+        }
+        append_shifted(ix.orf_iv, p.orf_iv, 1, (int64_t)ix.iv_start.size());
+        append_shifted(ix.head_off, p.head_off, 1, (int64_t)ix.head.size());
+        append_shifted(ix.tail_off, p.tail_off, 1, (int64_t)ix.tail.size());
+        ix.length.insert(ix.length.end(), p.length.begin(), p.length.end());
+        ix.reverse.insert(ix.reverse.end(), p.reverse.begin(), p.reverse.end());
+        ix.iv_start.insert(ix.iv_start.end(), p.iv_start.begin(), p.iv_start.end());
+        ix.iv_end.insert(ix.iv_end.end(), p.iv_end.begin(), p.iv_end.end());
+        ix.head.append(p.head);
+        ix.tail.append(p.tail);
+        const size_t at = ix.group.size();
+        ix.group.resize(at + p.group.size());
+        for (size_t k = 0; k < p.group.size(); ++k) ix.group[at + k] = remap[(size_t)p.group[k]];
+        p = Index();  // release the run's copy as soon as it is stitched in
     }
     return kOk;
 }

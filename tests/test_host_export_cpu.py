@@ -262,3 +262,52 @@ def test_native_rows_threaded_equal_serial(packed, threads):
         assert b"".join(tsv.format_rows_native(*args, True, threads=threads, chunk_bytes=chunk_bytes)) == serial
     part = b"".join(tsv.format_rows_native(*args, False, first=17, last=140, threads=threads, chunk_bytes=2048))
     assert part == b"".join(tsv.format_rows_native(*args, False, first=17, last=140, threads=1))
+
+
+def test_native_index_threaded_equals_sequential(monkeypatch):
+    """rp_index_parse_host cuts a large text into runs of whole lines, one per thread: same arrays,
+    same (strand, chrom) numbering by first appearance, same first malformed line."""
+    from ribotricer_amd._lib import RibophaseError
+    from ribotricer_amd.index import NativeIndex
+
+    rng = np.random.default_rng(12)
+    chroms = [f"chr{k}" for k in range(1, 40)]
+    lines = ["header line\n"]
+    n = 150_000
+    for i in range(n):
+        k = int(rng.integers(1, 5))
+        start = int(rng.integers(1, 10**8))
+        ivs = []
+        for _ in range(k):
+            ln = int(rng.integers(3, 400))
+            ivs.append((start, start + ln - 1))
+            start += ln + int(rng.integers(50, 500))
+        rng.shuffle(ivs)  # the parser sorts them (orf.py:100)
+        # chromosomes appear late in the file too: the numbering must follow the file, not the runs
+        chrom = chroms[min(len(chroms) - 1, int(rng.integers(0, 2 + i * len(chroms) // n)))]
+        lines.append(f"x\tuORF\tENST{i:011d}.{i % 7}\tprotein_coding\tENSG{i // 3:011d}\tGENE{i // 3}\tprotein_coding\t{chrom}\t{'+-'[i % 3 == 0]}\tATG\t"
+                     + ",".join(f"{a}-{b}" for a, b in ivs) + "\n")
+    text = "".join(lines).encode()
+    assert len(text) > 16 << 20  # several 4 MiB runs
+    monkeypatch.setenv("RIBOPHASE_INDEX_THREADS", "1")
+    one = NativeIndex(text)
+    for threads in ("3", "8"):
+        monkeypatch.setenv("RIBOPHASE_INDEX_THREADS", threads)
+        many = NativeIndex(text)
+        assert many.n_orfs == one.n_orfs == n and many.group_keys == one.group_keys and many.extents == one.extents
+        for name in ("orf_iv", "length", "group", "reverse", "iv_start", "iv_end"):
+            assert np.array_equal(getattr(many, name), getattr(one, name)), name
+        assert many.tables[0] == one.tables[0] and many.tables[2] == one.tables[2]
+        assert np.array_equal(many.tables[1], one.tables[1]) and np.array_equal(many.tables[3], one.tables[3])
+    # a malformed coordinate two thirds into the file: the same line number either way
+    bad_at = 100_000
+    lines[bad_at] = lines[bad_at].rsplit("\t", 1)[0] + "\t12-\n"
+    bad = "".join(lines).encode()
+    seen = []
+    for threads in ("1", "8"):
+        monkeypatch.setenv("RIBOPHASE_INDEX_THREADS", threads)
+        with pytest.raises(RibophaseError) as e:
+            NativeIndex(bad)
+        assert e.value.status == -10
+        seen.append(str(e.value))
+    assert seen[0] == seen[1] and f"line {bad_at + 1}:" in seen[0]

@@ -18,7 +18,7 @@ def test_host_code_is_clean_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "san_host")
     build = subprocess.run(
         ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-         "-I", os.path.join(REPO, "ribotricer_amd", "csrc"), os.path.join(REPO, "tests", "tools", "san_host.cpp"), "-o", exe],
+         "-I", os.path.join(REPO, "ribotricer_amd", "csrc"), os.path.join(REPO, "tests", "tools", "san_host.cpp"), "-o", exe, "-pthread"],
         capture_output=True, text=True,
     )
     assert build.returncode == 0, build.stderr
