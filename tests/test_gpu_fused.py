@@ -160,3 +160,46 @@ def test_fused_sharded_equals_single():
         for k in ("valid", "read_count", "min_codon_cov", "status"):
             assert np.array_equal(parts[k], whole[k]), (k, devices)
         assert np.abs(parts["phase"] - whole["phase"]).max() <= 1e-6  # another tiling moves fp32 sums by <= 2e-7
+
+
+def test_gather_plan_abi_errors():
+    """Argument checks of the gather-plan entry points: statuses, not crashes."""
+    import ctypes
+
+    import torch
+
+    from ribotricer_amd import _lib
+    from ribotricer_amd.engine import _ptr, get_engine, make_filter
+    from ribotricer_amd.gather import GatherPlan
+
+    rng = np.random.default_rng(2)
+    t = random_table(rng, 300, 50000)
+    plan = GatherPlan(t, 50000)
+    lib = _lib.load()
+    cov = torch.zeros(50000, dtype=torch.int32, device="cuda")
+    out = torch.empty(plan.total_nt + 4, dtype=torch.int32, device="cuda")
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.rp_gather_profiles_plan_dev(None, _ptr(cov), 50000, _ptr(out), stream) == -1
+    assert lib.rp_gather_profiles_plan_dev(plan.handle, _ptr(cov), 49999, _ptr(out), stream) == -8  # another coverage layout
+    assert lib.rp_gather_profiles_plan_dev(plan.handle, None, 50000, _ptr(out), stream) == -1
+    assert lib.rp_gather_profiles_plan_dev(plan.handle, _ptr(cov), 50000, ctypes.c_void_p(out.data_ptr() + 4), stream) == -8  # 16-byte alignment
+    assert b"aligned" in lib.rp_last_error()
+    need = ctypes.c_size_t(0)
+    assert lib.rp_gather_plan_bytes(-1, 0, 0, ctypes.byref(need)) == -2
+    assert lib.rp_gather_plan_bytes(300, len(t.iv_start), plan.total_nt, ctypes.byref(need)) == 0 and need.value > 0
+    handle = ctypes.c_void_p(0)
+    small = torch.empty(64, dtype=torch.uint8, device="cuda")
+    args = [_ptr(torch.from_numpy(a).cuda()) for a in (t.iv_start, t.iv_len, t.orf_iv, t.reverse, t.offsets)]
+    rc = lib.rp_gather_plan_create_dev(0, *args, 300, len(t.iv_start), plan.total_nt, 50000, _ptr(small), 64, stream, ctypes.byref(handle))
+    assert rc == -5 and not handle.value  # plan memory too small
+    # a plan of another index handed to the fused scorer
+    other = GatherPlan(random_table(rng, 200, 50000), 50000)
+    eng = get_engine("cuda:0")
+    with pytest.raises(_lib.RibophaseError) as e:
+        bad = GatherPlan(t, 50000)
+        bad.offsets = other.offsets  # mismatched offsets / plan
+        bad.n_orfs, bad.total_nt = other.n_orfs, other.total_nt
+        eng.score_coverage(cov, bad, thresholds=make_filter())
+    assert e.value.status == -8
+    with pytest.raises(_lib.RibophaseError):
+        eng.score_coverage(torch.zeros(10, dtype=torch.int32, device="cuda"), plan)  # coverage of another length
