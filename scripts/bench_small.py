@@ -1,6 +1,6 @@
 """Latency of one scoring call for small batches, tile vs wave path (run on the GPU box)."""
 import sys, time
-import numpy as np, torch
+import torch
 sys.path.insert(0, ".")
 from ribotricer_amd.engine import PhaseScoreEngine, make_filter
 from ribotricer_amd.synth import synth_csr_host

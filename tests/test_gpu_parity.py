@@ -9,7 +9,6 @@ every ORF not flagged as an exact frame tie.
 import numpy as np
 import pytest
 
-from conftest import split_csr
 from helpers import INT32_MAX, assert_matches_fixture, assert_matches_oracle, reference_status
 from oracle import c_oracle
 

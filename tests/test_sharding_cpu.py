@@ -5,7 +5,6 @@ there is no GPU -- the GPU twin of this test is test_gpu_parity.test_full_size_p
 import os
 
 import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
