@@ -311,3 +311,19 @@ def test_native_index_threaded_equals_sequential(monkeypatch):
         assert e.value.status == -10
         seen.append(str(e.value))
     assert seen[0] == seen[1] and f"line {bad_at + 1}:" in seen[0]
+
+
+def test_reference_orf_test_vectors():
+    """The index-line cases of the reference's own tests (tests/test_orf.py:73-85 `from_string`,
+    :87-104 a start codon shorter than three bases is None), through both parsers."""
+    from ribotricer_amd.index import NativeIndex
+
+    line = "tx1_100_200_101\tannotated\ttx1\tprotein_coding\tgene1\tGene1\tprotein_coding\tchr1\t+\tATG\t100-200"
+    short = line.replace("\tATG\t", "\tAT\t")
+    for text, codon in ((line, "ATG"), (short, None)):
+        r = d.parse_index_line(text)
+        n = NativeIndex(("header\n" + text + "\n").encode()).records()[0]
+        for rec in (r, n):
+            assert rec.tid == "tx1" and rec.category == "annotated" and rec.chrom == "chr1" and rec.strand == "+"
+            assert rec.gid == "gene1" and rec.gname == "Gene1" and rec.intervals == ((100, 200),)
+            assert rec.start_codon == codon and rec.oid == "tx1_100_200_101"
