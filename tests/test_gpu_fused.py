@@ -203,3 +203,32 @@ def test_gather_plan_abi_errors():
     assert e.value.status == -8
     with pytest.raises(_lib.RibophaseError):
         eng.score_coverage(torch.zeros(10, dtype=torch.int32, device="cuda"), plan)  # coverage of another length
+
+
+def test_fused_with_empty_orfs():
+    """ORFs without any interval (empty profiles) among ordinary ones, and an index of nothing else."""
+    import torch
+
+    from ribotricer_amd.engine import get_engine, make_filter
+    from ribotricer_amd.gather import GatherPlan, IntervalTable
+
+    rng = np.random.default_rng(31)
+    cov = rng.poisson(0.5, size=100000).astype(np.int32)
+    t = random_table(rng, 2000, cov.size)
+    # every third ORF loses its intervals
+    keep = np.arange(2000) % 3 != 0
+    nk = np.diff(t.orf_iv) * keep
+    orf_iv = np.concatenate([[0], np.cumsum(nk)]).astype(np.int64)
+    pick = np.concatenate([np.arange(t.orf_iv[i], t.orf_iv[i + 1]) for i in range(2000) if keep[i]])
+    lengths = np.diff(t.offsets) * keep
+    mixed = IntervalTable(t.iv_start[pick], t.iv_len[pick], orf_iv, t.reverse, np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64))
+    none = IntervalTable(np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(51, np.int64), np.zeros(50, np.uint8), np.zeros(51, np.int64))
+    eng = get_engine("cuda:0")
+    d_cov = torch.from_numpy(cov).cuda()
+    for table in (mixed, none):
+        plan = GatherPlan(table, cov.size)
+        fused = eng.score_coverage(d_cov, plan, thresholds=make_filter()).cpu_numpy()
+        plain = eng.score(plan.gather(d_cov), plan.offsets, thresholds=make_filter(), algo="tile").cpu_numpy()
+        assert all(np.array_equal(fused[k], plain[k]) for k in fused)
+        empty = np.diff(table.offsets) == 0
+        assert (fused["phase"][empty] == 0).all() and (fused["valid"][empty] == 0).all() and (fused["status"][empty] == 0).all()
