@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace rpbam {
@@ -47,10 +48,17 @@ struct Split {
     std::string error;
 };
 
-// ---- BGZF -> contiguous byte stream, block by block ------------------------------------------
+// ---- BGZF -> contiguous byte stream ------------------------------------------------------------
+// Blocks are read from the file in order, kBatch at a time, inflated on up to 8 threads (a BGZF
+// block is an independent raw-deflate stream of <= 64 KiB) and handed out in file order; an error
+// surfaces when the reader reaches the block it belongs to, exactly as a sequential reader's would.
 class BgzfReader {
 public:
-    explicit BgzfReader(FILE *fh) : fh_(fh) {}
+    explicit BgzfReader(FILE *fh) : fh_(fh)
+    {
+        threads_ = (int)std::thread::hardware_concurrency();
+        threads_ = threads_ > 8 ? 8 : (threads_ < 1 ? 1 : threads_);
+    }
     // read exactly n bytes of the uncompressed stream; false at a clean EOF before the first byte
     int read(void *dst, size_t n, bool *eof)
     {
@@ -58,10 +66,10 @@ public:
         size_t got = 0;
         *eof = false;
         while (got < n) {
-            if (at_ == buf_.size()) {
+            if (cur_ == nullptr || at_ == cur_->size()) {
                 const int rc = next_block();
                 if (rc != kOk) return rc;
-                if (buf_.empty() && done_) {
+                if (cur_ == nullptr) {  // end of file
                     if (got == 0) {
                         *eof = true;
                         return kOk;
@@ -70,63 +78,141 @@ public:
                 }
                 continue;
             }
-            const size_t take = std::min(n - got, buf_.size() - at_);
-            memcpy(out + got, buf_.data() + at_, take);
+            const size_t take = std::min(n - got, cur_->size() - at_);
+            memcpy(out + got, cur_->data() + at_, take);
             at_ += take;
             got += take;
         }
         return kOk;
     }
 
+    // n bytes of the stream WITHOUT a copy when they lie inside the current block (the common case
+    // for alignment records); nullptr otherwise -- then read() assembles them
+    const unsigned char *take(size_t n)
+    {
+        if (cur_ == nullptr || cur_->size() - at_ < n) return nullptr;
+        const unsigned char *p = cur_->data() + at_;
+        at_ += n;
+        return p;
+    }
+
 private:
+    static constexpr size_t kBatch = 128;  // blocks per refill (<= 8 MiB of text)
+    struct Block {
+        std::vector<unsigned char> comp, text;
+        unsigned isize = 0;
+        int rc = kOk;
+    };
+
+    // one block's header + payload from the file: kOk, or kFormat; *end = clean end of file
+    int fetch(Block &blk, bool *end)
+    {
+        *end = false;
+        unsigned char hdr[18];
+        const size_t h = fread(hdr, 1, 18, fh_);
+        if (h == 0) {
+            *end = true;
+            return kOk;
+        }
+        if (h != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) return kFormat;
+        const unsigned xlen = hdr[10] | (hdr[11] << 8);
+        // the BC subfield is the first one in every BGZF writer in use; find it anyway
+        std::vector<unsigned char> extra(xlen);
+        memcpy(extra.data(), hdr + 12, std::min<size_t>(6, xlen));
+        if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, fh_) != xlen - 6) return kFormat;
+        int bsize = -1;
+        for (unsigned p = 0; p + 4 <= xlen;) {
+            const unsigned slen = extra[p + 2] | (extra[p + 3] << 8);
+            if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) bsize = extra[p + 4] | (extra[p + 5] << 8);
+            p += 4 + slen;
+        }
+        if (bsize < 0) return kFormat;
+        const long payload = (long)bsize + 1 - 12 - (long)xlen - 8;  // compressed bytes of this block
+        if (payload < 0) return kFormat;
+        blk.comp.resize((size_t)payload + 8);
+        if (fread(blk.comp.data(), 1, blk.comp.size(), fh_) != blk.comp.size()) return kFormat;
+        const unsigned char *t = blk.comp.data() + payload;
+        blk.isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((unsigned)t[7] << 24);
+        return kOk;
+    }
+
+    static void inflate_block(Block &blk)
+    {
+        blk.text.resize(blk.isize);
+        if (blk.isize == 0) return;
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -15) != Z_OK) {
+            blk.rc = kInflate;
+            return;
+        }
+        zs.next_in = blk.comp.data();
+        zs.avail_in = (unsigned)(blk.comp.size() - 8);
+        zs.next_out = blk.text.data();
+        zs.avail_out = blk.isize;
+        const int rc = inflate(&zs, Z_FINISH);
+        inflateEnd(&zs);
+        if (rc != Z_STREAM_END || zs.total_out != blk.isize) blk.rc = kInflate;
+    }
+
+    // fill the batch: read until kBatch blocks, the end of the file, or a malformed block (kept as the batch's last)
+    void refill()
+    {
+        batch_.clear();
+        next_ = 0;
+        while (batch_.size() < kBatch && !done_) {
+            batch_.emplace_back();
+            bool end = false;
+            const int rc = fetch(batch_.back(), &end);
+            if (end) {
+                batch_.pop_back();
+                done_ = true;
+            } else if (rc != kOk) {
+                batch_.back().rc = rc;
+                done_ = true;
+            }
+        }
+        const size_t n = batch_.size();
+        const int workers = (int)std::min<size_t>((size_t)threads_, n / 4);  // a few blocks: not worth a thread
+        auto work = [&](size_t first, size_t step) {
+            for (size_t k = first; k < n; k += step)
+                if (batch_[k].rc == kOk) inflate_block(batch_[k]);
+        };
+        if (workers <= 1) {
+            work(0, 1);
+        } else {
+            std::vector<std::thread> pool;
+            for (int t = 1; t < workers; ++t) pool.emplace_back(work, (size_t)t, (size_t)workers);
+            work(0, (size_t)workers);
+            for (auto &th : pool) th.join();
+        }
+    }
+
+    // cur_ = the next non-empty block (the EOF marker is an empty one), or nullptr at the end of the file
     int next_block()
     {
-        buf_.clear();
+        cur_ = nullptr;
         at_ = 0;
-        for (;;) {  // skip empty blocks (the EOF marker is one)
-            unsigned char hdr[18];
-            const size_t h = fread(hdr, 1, 18, fh_);
-            if (h == 0) {
-                done_ = true;
-                return kOk;
+        for (;;) {
+            if (next_ == batch_.size()) {
+                if (done_) return kOk;
+                refill();
+                if (batch_.empty()) return kOk;
             }
-            if (h != 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) return kFormat;
-            const unsigned xlen = hdr[10] | (hdr[11] << 8);
-            // the BC subfield is the first one in every BGZF writer in use; find it anyway
-            std::vector<unsigned char> extra(xlen);
-            memcpy(extra.data(), hdr + 12, std::min<size_t>(6, xlen));
-            if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, fh_) != xlen - 6) return kFormat;
-            int bsize = -1;
-            for (unsigned p = 0; p + 4 <= xlen;) {
-                const unsigned slen = extra[p + 2] | (extra[p + 3] << 8);
-                if (extra[p] == 'B' && extra[p + 1] == 'C' && slen == 2 && p + 6 <= xlen) bsize = extra[p + 4] | (extra[p + 5] << 8);
-                p += 4 + slen;
-            }
-            if (bsize < 0) return kFormat;
-            const long payload = (long)bsize + 1 - 12 - (long)xlen - 8;  // compressed bytes of this block
-            if (payload < 0) return kFormat;
-            comp_.resize((size_t)payload + 8);
-            if (fread(comp_.data(), 1, comp_.size(), fh_) != comp_.size()) return kFormat;
-            const unsigned isize = comp_[payload + 4] | (comp_[payload + 5] << 8) | (comp_[payload + 6] << 16) | ((unsigned)comp_[payload + 7] << 24);
-            if (isize == 0) continue;
-            buf_.resize(isize);
-            z_stream zs;
-            memset(&zs, 0, sizeof(zs));
-            if (inflateInit2(&zs, -15) != Z_OK) return kInflate;
-            zs.next_in = comp_.data();
-            zs.avail_in = (unsigned)payload;
-            zs.next_out = buf_.data();
-            zs.avail_out = isize;
-            const int rc = inflate(&zs, Z_FINISH);
-            inflateEnd(&zs);
-            if (rc != Z_STREAM_END || zs.total_out != isize) return kInflate;
+            Block &blk = batch_[next_++];
+            if (blk.rc != kOk) return blk.rc;
+            if (blk.text.empty()) continue;
+            cur_ = &blk.text;
             return kOk;
         }
     }
     FILE *fh_;
-    std::vector<unsigned char> buf_, comp_;
+    std::vector<Block> batch_;
+    size_t next_ = 0;
+    const std::vector<unsigned char> *cur_ = nullptr;
     size_t at_ = 0;
     bool done_ = false;
+    int threads_ = 1;
 };
 
 inline uint32_t le32(const unsigned char *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
@@ -172,6 +258,37 @@ inline bool find_nh(const unsigned char *aux, const unsigned char *end, int64_t 
 }
 
 // protocol: 0 = forward, 1 = reverse (bam.py:108-128).  read_lengths == nullptr: every length.
+// ascending sort of the 64-bit keys: LSD radix, one pass per byte that differs somewhere
+inline void sort_keys(std::vector<uint64_t> &keys)
+{
+    if (keys.size() < 4096) {
+        std::sort(keys.begin(), keys.end());
+        return;
+    }
+    uint64_t all_or = 0, all_and = ~0ull;
+    for (uint64_t k : keys) {
+        all_or |= k;
+        all_and &= k;
+    }
+    const uint64_t varies = all_or ^ all_and;
+    std::vector<uint64_t> other(keys.size());
+    uint64_t *src = keys.data(), *dst = other.data();
+    for (int byte = 0; byte < 8; ++byte) {
+        if (((varies >> (8 * byte)) & 0xff) == 0) continue;
+        size_t count[256] = {0};
+        for (size_t i = 0; i < keys.size(); ++i) ++count[(src[i] >> (8 * byte)) & 0xff];
+        size_t at = 0;
+        for (int b = 0; b < 256; ++b) {
+            const size_t c = count[b];
+            count[b] = at;
+            at += c;
+        }
+        for (size_t i = 0; i < keys.size(); ++i) dst[count[(src[i] >> (8 * byte)) & 0xff]++] = src[i];
+        std::swap(src, dst);
+    }
+    if (src != keys.data()) memcpy(keys.data(), src, keys.size() * sizeof(uint64_t));
+}
+
 inline int split_bam(const char *path, int protocol, const int32_t *read_lengths, int n_lengths, Split &out)
 {
     FILE *fh = fopen(path, "rb");
@@ -219,14 +336,18 @@ inline int split_bam(const char *path, int protocol, const int32_t *read_lengths
         const uint32_t block = le32(w);
         if (block < 32) return fail(kFormat, "alignment record shorter than its fixed part");
         if (block > (1u << 28)) return fail(kFormat, "implausible alignment record length");
-        rec.resize(block);
-        if ((rc = rd.read(rec.data(), block, &eof)) != kOk || eof) return fail(kFormat, "truncated alignment record");
+        const unsigned char *r = rd.take(block);
+        if (r == nullptr) {  // the record straddles BGZF blocks
+            rec.resize(block);
+            if ((rc = rd.read(rec.data(), block, &eof)) != kOk || eof) return fail(kFormat, "truncated alignment record");
+            r = rec.data();
+        }
         out.total += 1;
-        const int32_t ref_id = (int32_t)le32(rec.data());
-        const int32_t pos0 = (int32_t)le32(rec.data() + 4);
-        const unsigned l_name = rec[8], mapq = rec[9];
-        const unsigned n_cigar = le16(rec.data() + 12), flag = le16(rec.data() + 14);
-        const uint32_t l_seq = le32(rec.data() + 16);
+        const int32_t ref_id = (int32_t)le32(r);
+        const int32_t pos0 = (int32_t)le32(r + 4);
+        const unsigned l_name = r[8], mapq = r[9];
+        const unsigned n_cigar = le16(r + 12), flag = le16(r + 14);
+        const uint32_t l_seq = le32(r + 16);
         if (flag & 0x200) { out.qcfail += 1; continue; }
         if (flag & 0x400) { out.duplicate += 1; continue; }
         if (flag & 0x100) { out.secondary += 1; continue; }
@@ -235,13 +356,13 @@ inline int split_bam(const char *path, int protocol, const int32_t *read_lengths
         const size_t aux_at = cigar_at + 4 * (size_t)n_cigar + ((size_t)l_seq + 1) / 2 + l_seq;
         if (aux_at > block) return fail(kFormat, "alignment record fields overrun the record");
         int64_t nh = 0;
-        const bool has_nh = find_nh(rec.data() + aux_at, rec.data() + block, &nh);
+        const bool has_nh = find_nh(r + aux_at, r + block, &nh);
         const bool uniq = has_nh ? nh == 1 : mapq == 255;
         if (!uniq) { out.multi += 1; continue; }
         // reference positions under M / = / X
         int64_t refpos = pos0, first = -1, last = -1, aligned = 0;
         for (unsigned k = 0; k < n_cigar; ++k) {
-            const uint32_t c = le32(rec.data() + cigar_at + 4 * k);
+            const uint32_t c = le32(r + cigar_at + 4 * k);
             const uint32_t op = c & 15, len = c >> 4;
             if (op == 0 || op == 7 || op == 8) {  // M = X
                 if (len > 0) {
@@ -281,7 +402,7 @@ inline int split_bam(const char *path, int protocol, const int32_t *read_lengths
         out.valid += 1;
     }
     fclose(fh);
-    std::sort(keys.begin(), keys.end());
+    sort_keys(keys);
     for (size_t i = 0; i < keys.size();) {
         size_t j = i;
         while (j < keys.size() && keys[j] == keys[i]) ++j;

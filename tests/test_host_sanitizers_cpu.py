@@ -29,7 +29,7 @@ def test_host_code_is_clean_under_asan_ubsan(tmp_path):
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
 def test_bam_reader_is_clean_under_asan_ubsan(tmp_path):
-    """rp_bam.hpp on a synthetic BAM and 1 500 truncated / corrupted copies of it."""
+    """rp_bam.hpp on a synthetic BAM and 600 truncated / corrupted copies of it."""
     import sys
 
     import numpy as np
@@ -44,7 +44,7 @@ def test_bam_reader_is_clean_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "san_bam")
     build = subprocess.run(
         ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-         "-I", os.path.join(REPO, "ribotricer_amd", "csrc"), os.path.join(REPO, "tests", "tools", "san_bam.cpp"), "-o", exe, "-lz"],
+         "-I", os.path.join(REPO, "ribotricer_amd", "csrc"), os.path.join(REPO, "tests", "tools", "san_bam.cpp"), "-o", exe, "-lz", "-pthread"],
         capture_output=True, text=True,
     )
     assert build.returncode == 0, build.stderr

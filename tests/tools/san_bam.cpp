@@ -18,7 +18,7 @@ int main(int argc, char **argv)
     std::mt19937 rng(11);
     const std::string tmp = std::string(argv[2]);
     int ok = 0, bad = 0;
-    for (int rep = 0; rep < 1500; ++rep) {
+    for (int rep = 0; rep < 600; ++rep) {
         std::string t = rep % 3 == 0 ? data.substr(0, rng() % (data.size() + 1)) : data;
         const int flips = rep % 3 == 1 ? 1 + rng() % 4 : (rep % 3 == 2 ? 40 : 0);
         for (int k = 0; k < flips && !t.empty(); ++k) t[rng() % t.size()] = (char)(rng() & 0xff);
