@@ -572,10 +572,12 @@ __device__ __forceinline__ void run_block(const int *__restrict__ s, int lim, fl
     nf1 = f[1];
 }
 
+template <int KRUN>
 __device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, LaneSums &o)
 {
+    static_assert(KRUN % 2 == 1 && KRUN <= kRun, "odd run lengths keep the LDS lane stride conflict free");
     constexpr int B = 3 * kRunBlock;
-    constexpr int kBlocks = (kRun + kRunBlock - 1) / kRunBlock;
+    constexpr int kBlocks = (KRUN + kRunBlock - 1) / kRunBlock;
     lim = lim > 0 ? lim : 0;  // a run that starts in the last two positions of an ORF owns no codon start
     RunAcc a;
 #pragma unroll
@@ -634,11 +636,12 @@ __device__ unsigned long long rp_dbg_stamps[kStampSlots][4][8];  // plain stores
 #define RP_STAMP_FLUSH() do {} while (0)
 #endif
 // One pass of a wave: every lane walks its run, then the per-segment reduction.
+template <int KRUN>
 __device__ __forceinline__ void tile_pass(const int *__restrict__ s_counts, SegInts *__restrict__ s_ints,
                                           RunRec *__restrict__ s_rec, int q0, int lim, bool active, int seg, int vl)
 {
     LaneSums sv;
-    lane_run(s_counts + q0, lim, sv);
+    lane_run<KRUN>(s_counts + q0, lim, sv);
 
     // integer sums: exact and order independent -> LDS atomics straight per segment
     if (active) {
@@ -717,6 +720,61 @@ __device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, c
         out = make_uint4((unsigned)nn, (unsigned)(nn >> 32) | ((unsigned)mm << 16), (unsigned)(mm >> 16), min_codon);
     }
     rec[wave * n_rec + id0 + seg] = out;
+}
+
+// One round of the short-ORF path: the 64 segments whose descriptors the lanes hold (`dc`), walked
+// with runs of KRUN triplets.  Every wave finds its lanes' segments through 64 private words of
+// LDS (marks at the segments' first lanes, then a max-scan); tables, pass, reduction as in the
+// common path.  Ends after barrier 2 (the caller runs the record stage).
+template <int KRUN>
+__device__ __forceinline__ void short_round(seg_desc_t dc, const int *s_counts, SegInts *s_ints, RunRec *s_rec,
+                                            int *s_vlstart, int *s_tail, int *s_live, int *s_owner, int wave, int lane)
+{
+    const int ntrip_i = (int)(dc >> 26) & 0xfff;
+    const int lanes_i = (dc >> 63) ? (ntrip_i + KRUN - 1) / KRUN : 0;
+    const int incl = wave_add_scan(lanes_i);
+    const int vs_i = incl - lanes_i;
+    const int total_vl = __builtin_amdgcn_readlane(incl, kWave - 1);
+    const int vbase = wave * kWave;
+    const int vl = vbase + lane;
+    const bool pass = vbase < total_vl;  // wave-uniform
+    const bool active = vl < total_vl;
+    int q0 = 0, lim = 0, seg = 0;
+    if (pass) {
+        int *mk = s_owner + vbase;  // this wave's 64 words
+        mk[lane] = 0;
+        if (lanes_i > 0) {
+            const int tgt = vs_i - vbase;
+            if (tgt >= 0 && tgt < kWave)
+                mk[tgt] = lane + 1;
+            else if (tgt < 0 && vs_i + lanes_i > vbase)
+                mk[0] = lane + 1;  // the one segment that straddles into this pass
+        }
+        asm volatile("" ::: "memory");  // LDS operations of one wave complete in order
+        seg = wave_max_scan(mk[lane]) - 1;
+        if (seg < 0) seg = 0;  // (only on a malformed index: keep the lane fetches in range)
+        const unsigned dlo = (unsigned)__builtin_amdgcn_ds_bpermute(seg << 2, (int)(unsigned)dc);
+        const unsigned dhi = (unsigned)__builtin_amdgcn_ds_bpermute(seg << 2, (int)(unsigned)(dc >> 32));
+        const int vs_s = __builtin_amdgcn_ds_bpermute(seg << 2, vs_i);
+        const seg_desc_t ds = ((seg_desc_t)dhi << 32) | dlo;
+        const int r = vl - vs_s;
+        int n_run = ((int)(ds >> 26) & 0xfff) - r * KRUN;
+        n_run = n_run > KRUN ? KRUN : n_run;
+        q0 = active ? ((int)ds & 0x1fff) + 3 * KRUN * r : 0;
+        const int rem0 = ((int)(ds >> 13) & 0x1fff) - q0;
+        lim = rem0 - 2 < 3 * n_run ? rem0 - 2 : 3 * n_run;
+        if (!active) lim = 0;
+    }
+    if (wave == 0) {  // what the record stage needs, per slot
+        const int part = (int)(dc >> 51) & 3;
+        s_vlstart[lane] = vs_i;
+        if (lane == kWave - 1) s_vlstart[kSegChunk] = incl;
+        s_tail[lane] = part ? (((int)(dc >> 38) & 0x1fff) | (part << 16)) : -1;
+        s_live[lane] = (int)(dc >> 63);
+    }
+    __syncthreads();  // tables and cleared accumulators are in place
+    if (pass) tile_pass<KRUN>(s_counts, s_ints, s_rec, q0, lim, active, seg, vl);
+    __syncthreads();
 }
 
 // FUSED: `counts` is the dense coverage and the tile is staged through the piece plan
@@ -832,7 +890,7 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is tracked by vmcnt only
         __syncthreads();
         RP_STAMP();  // 4: tile landed (barrier 1)
-        if (pass) tile_pass(s_counts, s_ints, s_rec, q0, lim, active, seg, vl);
+        if (pass) tile_pass<kRun>(s_counts, s_ints, s_rec, q0, lim, active, seg, vl);
         RP_STAMP();  // 5: this wave's lane runs done
         __syncthreads();
         RP_STAMP();  // 6: all lane runs done (barrier 2)
@@ -866,52 +924,29 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
             const long long orf = a0 - 1 + c0 + lane;
             dc = orf < a1 ? ws.desc[orf + b] : 0;
         }
-        const int lanes_i = (int)(dc >> 53) & 0xff;
-        const int incl = wave_add_scan(lanes_i);
-        const int vs_i = incl - lanes_i;
-        const int total_vl = __builtin_amdgcn_readlane(incl, kWave - 1);
-        const int vbase = wave * kWave;
-        const int vl = vbase + lane;
-        const bool pass = vbase < total_vl;  // wave-uniform
-        const bool active = vl < total_vl;
-        int q0 = 0, lim = 0, seg = 0;
-        if (pass) {
-            int *mk = s_owner + vbase;  // this wave's 64 words
-            mk[lane] = 0;
-            if (lanes_i > 0) {
-                const int tgt = vs_i - vbase;
-                if (tgt >= 0 && tgt < kWave)
-                    mk[tgt] = lane + 1;
-                else if (tgt < 0 && vs_i + lanes_i > vbase)
-                    mk[0] = lane + 1;  // the one segment that straddles into this pass
-            }
-            asm volatile("" ::: "memory");  // LDS operations of one wave complete in order
-            seg = wave_max_scan(mk[lane]) - 1;
-            if (seg < 0) seg = 0;  // (only on a malformed index: keep the lane fetches in range)
-            const unsigned dlo = (unsigned)__builtin_amdgcn_ds_bpermute(seg << 2, (int)(unsigned)dc);
-            const unsigned dhi = (unsigned)__builtin_amdgcn_ds_bpermute(seg << 2, (int)(unsigned)(dc >> 32));
-            const int vs_s = __builtin_amdgcn_ds_bpermute(seg << 2, vs_i);
-            const seg_desc_t ds = ((seg_desc_t)dhi << 32) | dlo;
-            const int r = vl - vs_s;
-            int n_run = ((int)(ds >> 26) & 0xfff) - r * kRun;
-            n_run = n_run > kRun ? kRun : n_run;
-            q0 = active ? ((int)ds & 0x1fff) + 3 * kRun * r : 0;
-            const int rem0 = ((int)(ds >> 13) & 0x1fff) - q0;
-            lim = rem0 - 2 < 3 * n_run ? rem0 - 2 : 3 * n_run;
-            if (!active) lim = 0;
-        }
-        if (wave == 0) {  // what the record stage needs, per slot
-            const int part = (int)(dc >> 51) & 3;
-            s_vlstart[lane] = vs_i;
-            if (lane == kWave - 1) s_vlstart[kSegChunk] = incl;
-            s_tail[lane] = part ? (((int)(dc >> 38) & 0x1fff) | (part << 16)) : -1;
-            s_live[lane] = (int)(dc >> 63);
-        }
-        __syncthreads();  // tables and cleared accumulators are in place
-        if (pass) tile_pass(s_counts, s_ints, s_rec, q0, lim, active, seg, vl);
-        __syncthreads();
+        // Run length of this round: the shortest of 5 / 9 / 15 triplets per lane that still puts the
+        // 64 segments' lanes into one pass of the four waves.  Short ORFs then spread over all four
+        // waves and every lane walks 2 or 3 blocks instead of 5 (a 60-nt ORF: 4 lanes of 5 triplets
+        // instead of 15 + 5).
+        const int ntrip_i = (int)(dc >> 26) & 0xfff;
+        const int live_i = (int)(dc >> 63);
+        const int total5 = __builtin_amdgcn_readlane(wave_add_scan(live_i ? (ntrip_i + 4) / 5 : 0), kWave - 1);
+        const int total9 = __builtin_amdgcn_readlane(wave_add_scan(live_i ? (ntrip_i + 8) / 9 : 0), kWave - 1);
+        if (total5 <= kTileBlock)
+            short_round<5>(dc, s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, s_owner, wave, lane);
+        else if (total9 <= kTileBlock)
+            short_round<9>(dc, s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, s_owner, wave, lane);
+        else
+            short_round<kRun>(dc, s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, s_owner, wave, lane);
+#ifdef RP_STAMPS
+        if (n_stamp_ < 7) RP_STAMP();  // short path: 2, 4, 6 = after barrier 2 of rounds 0, 1, 2
+#endif
         record_stage(s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, ws.rec, ws.n_rec, a0 - 1 + c0 + b, wave, lane);
+#ifdef RP_STAMPS
+        if (n_stamp_ < 7) RP_STAMP();  // short path: 3, 5, 7 = records of rounds 0, 1, 2 stored
+#endif
     }
+    RP_STAMP_FLUSH();
 }
 
 // ---------------------------------------------------------------------------
