@@ -150,6 +150,14 @@ int rp_phase_score_csr_dev(int device, const int32_t *d_counts, const int64_t *d
                            size_t workspace_bytes, int algo, void *hip_stream);
 
 /*
+ * Positions per tile of the tile path for an index of n_orfs ORFs and total_nt nucleotides:
+ * 7 936, or 6 144 for indexes of short ORFs (mean length < 140 nt), where a tile then holds
+ * fewer segments.  Informational (RP_FLAG_SPLIT marks ORFs that span tiles); every sizing
+ * function and kernel derives the same value from the same two numbers.
+ */
+int rp_tile_positions(int64_t n_orfs, int64_t total_nt, int32_t *positions);
+
+/*
  * Tile plans.  export_orf_coverages scores ONE candidate-ORF index against many samples
  * (detect_orfs.py:510-520 is called once per BAM with the same ribotricer_index), and
  * everything the tile path derives from the offsets alone -- the tile index, and the check

@@ -63,6 +63,7 @@ SYMBOLS = {
     "rp_workspace_bytes": (_int, [_i64, _i64, _int, ctypes.POINTER(ctypes.c_size_t)]),
     "rp_phase_score_csr_dev": (_int, _SCORE_ARGS),
     "rp_phase_score_csr_dev_timed": (_int, _SCORE_ARGS[:-1] + [_vp, _vp, ctypes.POINTER(ctypes.c_float * 4)]),
+    "rp_tile_positions": (_int, [_i64, _i64, ctypes.POINTER(ctypes.c_int32)]),
     "rp_plan_bytes": (_int, [_i64, _i64, ctypes.POINTER(ctypes.c_size_t)]),
     "rp_plan_create_dev": (_int, [_int, _vp, _i64, _i64, _int, _vp, ctypes.c_size_t, _vp, ctypes.POINTER(_vp)]),
     "rp_plan_free": (None, [_vp]),
@@ -134,6 +135,13 @@ def filter_defaults() -> FilterParams:
     fp = FilterParams()
     check(load().rp_filter_defaults(ctypes.byref(fp)))
     return fp
+
+
+def tile_positions(n_orfs: int, total_nt: int) -> int:
+    """Positions per tile the tile path uses for such an index (7 936, or 6 144 for short ORFs)."""
+    out = ctypes.c_int32(0)
+    check(load().rp_tile_positions(n_orfs, total_nt, ctypes.byref(out)))
+    return out.value
 
 
 def plan_bytes(n_orfs: int, total_nt: int) -> int:

@@ -177,23 +177,35 @@ struct Timing {
 bool known_algo(int algo) { return algo == RP_ALGO_AUTO || algo == RP_ALGO_WAVE || algo == RP_ALGO_TILE; }
 
 // the part of a launch that depends on the offsets only: tile index + segment descriptors
-int launch_plan_kernels(const int64_t *d_offsets, int64_t n_orfs, const rp::TilePlan &plan,
+// run `call` with the tile size as a compile-time constant (the two sizes of rp_tile.hpp)
+#define RP_WITH_TILE(tile, call)                 \
+    do {                                         \
+        if ((tile) == rp::kTile) {               \
+            constexpr int TILE = rp::kTile;      \
+            call;                                \
+        } else {                                 \
+            constexpr int TILE = rp::kTileSmall; \
+            call;                                \
+        }                                        \
+    } while (0)
+
+int launch_plan_kernels(const int64_t *d_offsets, int64_t n_orfs, const rp::TilePlan &plan, int tile,
                         const rp::TileWorkspace &ws, int *d_err, hipStream_t stream)
 {
     const int block = 256;
     // head rows and descriptors are contiguous: gaps (empty ORFs, unused ids, unused slots) read as 0
-    RP_HIP(hipMemsetAsync(ws.head, 0, rp::head_bytes(plan.total_nt, rp::kTile) + (size_t)ws.n_rec * sizeof(rp::seg_desc_t), stream));
+    RP_HIP(hipMemsetAsync(ws.head, 0, rp::head_bytes(plan.total_nt, tile) + (size_t)ws.n_rec * sizeof(rp::seg_desc_t), stream));
     {
         const long long threads = n_orfs + 1;
         const int grid = (int)((threads + block - 1) / block);
-        hipLaunchKernelGGL(rp::k_tile_index<rp::kTile>, dim3(grid), dim3(block), 0, stream, d_offsets,
-                           (long long)n_orfs, plan, ws.tile_first, d_err);
+        RP_WITH_TILE(tile, hipLaunchKernelGGL(rp::k_tile_index<TILE>, dim3(grid), dim3(block), 0, stream, d_offsets,
+                                              (long long)n_orfs, plan, ws.tile_first, d_err));
         RP_HIP(hipGetLastError());
     }
     if (n_orfs > 0) {
         const int grid = (int)((n_orfs + block - 1) / block);
-        hipLaunchKernelGGL(rp::k_tile_desc<rp::kTile>, dim3(grid), dim3(block), 0, stream, d_offsets,
-                           (long long)n_orfs, plan, ws.tile_first, ws.head, ws.desc);
+        RP_WITH_TILE(tile, hipLaunchKernelGGL(rp::k_tile_desc<TILE>, dim3(grid), dim3(block), 0, stream, d_offsets,
+                                              (long long)n_orfs, plan, ws.tile_first, ws.head, ws.desc));
         RP_HIP(hipGetLastError());
     }
     {
@@ -213,6 +225,7 @@ struct rp_plan {
     int device;
     long long n_orfs, total_nt;
     int mis;         // (counts address / 4) % 4 the plan was built for
+    int tile;        // positions per tile (rp::pick_tile of the index)
     void *tables;    // device, caller-owned (inside d_plan_mem): tile index + segment descriptors
     int *err;        // device, first word of d_plan_mem
 };
@@ -222,6 +235,7 @@ struct rp_plan {
 struct rp_gather_plan {
     int device;
     long long n_orfs, n_pieces, total_nt, coverage_len, n_tiles;
+    int tile;
     rp::PiecePlanMem mem;  // device, caller-owned (inside d_plan_mem)
 };
 
@@ -281,13 +295,14 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     }
 
     // with a plan only the records live in the workspace
-    const size_t need = plan_h ? rp::record_bytes(n_orfs, total_nt, rp::kTile) : rp::workspace_bytes(n_orfs, total_nt, rp::kTile);
+    const int tile = rp::pick_tile(n_orfs, total_nt);
+    const size_t need = plan_h ? rp::record_bytes(n_orfs, total_nt, tile) : rp::workspace_bytes(n_orfs, total_nt, tile);
     if (!d_workspace || workspace_bytes < need)
         return fail(RP_ERR_WORKSPACE, "workspace of %zu bytes required, got %zu", need, workspace_bytes);
     if ((reinterpret_cast<uintptr_t>(d_workspace) & 15u) != 0)
         return fail(RP_ERR_WORKSPACE, "workspace must be 16-byte aligned");
     // RP_ALGO_TILE: plan tables (the caller's, or built here) -> scoring pass (segment records) -> per-ORF finish
-    const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt, gather ? 0 : rp::counts_phase(d_counts), rp::kTile);
+    const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt, gather ? 0 : rp::counts_phase(d_counts), tile);
     if (plan_h != nullptr) {
         if (plan_h->device != device || plan_h->n_orfs != n_orfs || plan_h->total_nt != total_nt)
             return fail(RP_ERR_ARG, "plan was built for device %d, %lld ORFs, %lld nt; called with device %d, %lld ORFs, %lld nt",
@@ -295,20 +310,20 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
         if (plan_h->mis != plan.mis)
             return fail(RP_ERR_ARG, "plan was built for counts at 16-byte phase %d, d_counts has phase %d", plan_h->mis, plan.mis);
     }
-    const rp::TileWorkspace ws = rp::carve_workspace(d_workspace, plan_h ? plan_h->tables : nullptr, n_orfs, total_nt, rp::kTile);
+    const rp::TileWorkspace ws = rp::carve_workspace(d_workspace, plan_h ? plan_h->tables : nullptr, n_orfs, total_nt, tile);
     if (plan_h == nullptr) {
         // 1. tile index (first ORF starting at or after each tile boundary) + segment descriptors
-        rc = launch_plan_kernels(d_offsets, n_orfs, plan, ws, nullptr, stream);
+        rc = launch_plan_kernels(d_offsets, n_orfs, plan, tile, ws, nullptr, stream);
         if (rc != RP_OK) return rc;
     }
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[1], stream));
     // 2. scoring pass over flat tiles: one record per (ORF, tile) segment
     if (gather != nullptr)
-        hipLaunchKernelGGL(rp::k_tile_score<true>, dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
-                           d_counts, (long long)n_orfs, plan, ws, piece_plan_of(gather));
+        RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score<true, TILE>), dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
+                                              d_counts, (long long)n_orfs, plan, ws, piece_plan_of(gather)));
     else
-        hipLaunchKernelGGL(rp::k_tile_score<false>, dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
-                           d_counts, (long long)n_orfs, plan, ws, rp::PiecePlan{});
+        RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score<false, TILE>), dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
+                                              d_counts, (long long)n_orfs, plan, ws, rp::PiecePlan{}));
     RP_HIP(hipGetLastError());
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));
     // 3. one thread per ORF: add its records, score, filter, store
@@ -316,22 +331,22 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
         const int block = rp::kFinishBlock;
         const long long grid = (n_orfs + block - 1) / block;
         if (gather != nullptr)
-            hipLaunchKernelGGL((rp::k_orf_finish<rp::kTile, rp::CoverageSource>), dim3((unsigned)grid), dim3(block), 0, stream,
-                               rp::CoverageSource{d_counts, piece_plan_of(gather)}, d_offsets, (long long)n_orfs, plan, ws, out, fp);
+            RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_orf_finish<TILE, rp::CoverageSource>), dim3((unsigned)grid), dim3(block), 0, stream,
+                                                  rp::CoverageSource{d_counts, piece_plan_of(gather)}, d_offsets, (long long)n_orfs, plan, ws, out, fp));
         else
-            hipLaunchKernelGGL((rp::k_orf_finish<rp::kTile, rp::CsrSource>), dim3((unsigned)grid), dim3(block), 0, stream,
-                               rp::CsrSource{d_counts}, d_offsets, (long long)n_orfs, plan, ws, out, fp);
+            RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_orf_finish<TILE, rp::CsrSource>), dim3((unsigned)grid), dim3(block), 0, stream,
+                                                  rp::CsrSource{d_counts}, d_offsets, (long long)n_orfs, plan, ws, out, fp));
         RP_HIP(hipGetLastError());
         // 4. the long too-close-to-call ORFs it queued (usually none): a workgroup each
         if (total_nt > rp::kLongWalk) {
             const long long cap = rp::long_capacity(total_nt);
             const dim3 lgrid((unsigned)(cap < 512 ? cap : 512));
             if (gather != nullptr)
-                hipLaunchKernelGGL((rp::k_rewalk_long<rp::kTile, rp::CoverageSource>), lgrid, dim3(rp::kLongBlock), 0, stream,
-                                   rp::CoverageSource{d_counts, piece_plan_of(gather)}, d_offsets, plan, ws, out, fp);
+                RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_rewalk_long<TILE, rp::CoverageSource>), lgrid, dim3(rp::kLongBlock), 0, stream,
+                                                      rp::CoverageSource{d_counts, piece_plan_of(gather)}, d_offsets, plan, ws, out, fp));
             else
-                hipLaunchKernelGGL((rp::k_rewalk_long<rp::kTile, rp::CsrSource>), lgrid, dim3(rp::kLongBlock), 0, stream,
-                                   rp::CsrSource{d_counts}, d_offsets, plan, ws, out, fp);
+                RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_rewalk_long<TILE, rp::CsrSource>), lgrid, dim3(rp::kLongBlock), 0, stream,
+                                                      rp::CsrSource{d_counts}, d_offsets, plan, ws, out, fp));
             RP_HIP(hipGetLastError());
         }
     }
@@ -430,7 +445,15 @@ int rp_workspace_bytes(int64_t n_orfs, int64_t total_nt, int algo, size_t *bytes
     if (!bytes) return fail(RP_ERR_NULL, "bytes is null");
     if (n_orfs < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "negative size");
     if (!known_algo(algo)) return fail(RP_ERR_ARG, "unknown algo %d", algo);
-    *bytes = algo == RP_ALGO_WAVE ? 0 : rp::workspace_bytes(n_orfs, total_nt, rp::kTile);
+    *bytes = algo == RP_ALGO_WAVE ? 0 : rp::workspace_bytes(n_orfs, total_nt, rp::pick_tile(n_orfs, total_nt));
+    return RP_OK;
+}
+
+int rp_tile_positions(int64_t n_orfs, int64_t total_nt, int32_t *positions)
+{
+    if (!positions) return fail(RP_ERR_NULL, "positions is null");
+    if (n_orfs < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "negative size");
+    *positions = rp::pick_tile(n_orfs, total_nt);
     return RP_OK;
 }
 
@@ -438,7 +461,7 @@ int rp_plan_bytes(int64_t n_orfs, int64_t total_nt, size_t *bytes)
 {
     if (!bytes) return fail(RP_ERR_NULL, "bytes is null");
     if (n_orfs < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "negative size");
-    *bytes = kPlanHeader + rp::plan_bytes(n_orfs, total_nt, rp::kTile);
+    *bytes = kPlanHeader + rp::plan_bytes(n_orfs, total_nt, rp::pick_tile(n_orfs, total_nt));
     return RP_OK;
 }
 
@@ -458,12 +481,13 @@ int rp_plan_create_dev(int device, const int64_t *d_offsets, int64_t n_orfs, int
     if ((reinterpret_cast<uintptr_t>(d_plan_mem) & 15u) != 0) return fail(RP_ERR_WORKSPACE, "plan memory must be 16-byte aligned");
     RP_ON_DEVICE(device);
     hipStream_t stream = (hipStream_t)hip_stream;
-    const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt, counts_phase, rp::kTile);
+    const int tile = rp::pick_tile(n_orfs, total_nt);
+    const rp::TilePlan plan = rp::make_tile_plan(n_orfs, total_nt, counts_phase, tile);
     int *d_err = reinterpret_cast<int *>(d_plan_mem);
     void *tables = reinterpret_cast<char *>(d_plan_mem) + kPlanHeader;
-    rp::TileWorkspace ws = rp::carve_workspace(nullptr, tables, n_orfs, total_nt, rp::kTile);
+    rp::TileWorkspace ws = rp::carve_workspace(nullptr, tables, n_orfs, total_nt, tile);
     RP_HIP(hipMemsetAsync(d_err, 0, kPlanHeader, stream));
-    rc = launch_plan_kernels(d_offsets, n_orfs, plan, ws, d_err, stream);
+    rc = launch_plan_kernels(d_offsets, n_orfs, plan, tile, ws, d_err, stream);
     if (rc != RP_OK) return rc;
     int h_err = 0;
     RP_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -475,6 +499,7 @@ int rp_plan_create_dev(int device, const int64_t *d_offsets, int64_t n_orfs, int
     h->n_orfs = n_orfs;
     h->total_nt = total_nt;
     h->mis = counts_phase;
+    h->tile = tile;
     h->tables = tables;
     h->err = d_err;
     *out = h;
@@ -579,7 +604,7 @@ int rp_gather_plan_bytes(int64_t n_orfs, int64_t n_intervals, int64_t total_nt, 
 {
     if (!bytes) return fail(RP_ERR_NULL, "bytes is null");
     if (n_orfs < 0 || n_intervals < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "negative size");
-    const rp::TilePlan tp = rp::make_tile_plan(n_orfs, total_nt, 0, rp::kTile);
+    const rp::TilePlan tp = rp::make_tile_plan(n_orfs, total_nt, 0, rp::pick_tile(n_orfs, total_nt));
     *bytes = kPlanHeader + rp::piece_plan_bytes(n_orfs, n_intervals, tp.n_tiles);
     return RP_OK;
 }
@@ -601,7 +626,8 @@ int rp_gather_plan_create_dev(int device, const int64_t *d_iv_start, const int32
     if ((reinterpret_cast<uintptr_t>(d_plan_mem) & 15u) != 0) return fail(RP_ERR_WORKSPACE, "plan memory must be 16-byte aligned");
     RP_ON_DEVICE(device);
     hipStream_t stream = (hipStream_t)hip_stream;
-    const rp::TilePlan tp = rp::make_tile_plan(n_orfs, total_nt, 0, rp::kTile);
+    const int tile = rp::pick_tile(n_orfs, total_nt);
+    const rp::TilePlan tp = rp::make_tile_plan(n_orfs, total_nt, 0, tile);
     int *d_err = reinterpret_cast<int *>(d_plan_mem);
     const rp::PiecePlanMem mem = rp::carve_piece_plan(reinterpret_cast<char *>(d_plan_mem) + kPlanHeader, n_orfs, n_intervals, tp.n_tiles);
     RP_HIP(hipMemsetAsync(d_err, 0, kPlanHeader, stream));
@@ -618,8 +644,8 @@ int rp_gather_plan_create_dev(int device, const int64_t *d_iv_start, const int32
     RP_HIP(hipStreamSynchronize(stream));
     if (h_err & 1) return fail(RP_ERR_OFFSETS, "the intervals of an ORF do not add up to its profile length (or orf_iv is not a CSR index of the intervals)");
     if (h_err & 2) return fail(RP_ERR_INTERVALS, "an interval is empty or reaches outside the coverage array: not plannable (rp_gather_profiles_dev reads such positions as 0)");
-    hipLaunchKernelGGL((rp::k_chunk_rows<rp::kTile, rp::kHalo>), dim3((unsigned)tp.n_tiles), dim3(rp::kRowBlock), 0, stream, mem,
-                       (long long)n_intervals, (long long)total_nt);
+    RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_chunk_rows<TILE, rp::kHalo>), dim3((unsigned)tp.n_tiles), dim3(rp::kRowBlock), 0, stream, mem,
+                                          (long long)n_intervals, (long long)total_nt));
     RP_HIP(hipGetLastError());
     RP_HIP(hipStreamSynchronize(stream));
     rp_gather_plan *h = new (std::nothrow) rp_gather_plan;
@@ -630,6 +656,7 @@ int rp_gather_plan_create_dev(int device, const int64_t *d_iv_start, const int32
     h->total_nt = total_nt;
     h->coverage_len = coverage_len;
     h->n_tiles = tp.n_tiles;
+    h->tile = tile;
     h->mem = mem;
     *out = h;
     return RP_OK;
@@ -646,8 +673,8 @@ int rp_gather_profiles_plan_dev(const rp_gather_plan *plan, const int32_t *d_cov
     if (!d_coverage || !d_counts) return fail(RP_ERR_NULL, "d_coverage / d_counts is null");
     if ((reinterpret_cast<uintptr_t>(d_counts) & 15u) != 0) return fail(RP_ERR_ARG, "d_counts must be 16-byte aligned");
     RP_ON_DEVICE(plan->device);
-    hipLaunchKernelGGL((rp::k_tile_gather<rp::kTile, rp::kHalo>), dim3((unsigned)plan->n_tiles), dim3(rp::kGatherTileBlock), 0,
-                       (hipStream_t)hip_stream, d_coverage, piece_plan_of(plan), plan->total_nt, d_counts);
+    RP_WITH_TILE(plan->tile, hipLaunchKernelGGL((rp::k_tile_gather<TILE, rp::kHalo>), dim3((unsigned)plan->n_tiles), dim3(rp::kGatherTileBlock), 0,
+                                                (hipStream_t)hip_stream, d_coverage, piece_plan_of(plan), plan->total_nt, d_counts));
     RP_HIP(hipGetLastError());
     return RP_OK;
 }

@@ -57,7 +57,19 @@ constexpr int kTile = RP_TILE;  // positions per tile (31 KiB of int32): 3 lane-
 constexpr int kRun = RP_KRUN;   // triplets per lane run; odd => lane stride 45 dwords, conflict free
 constexpr int kSegChunk = 64;   // segments set up per round (one per lane of wave 0)
 constexpr int kHalo = 8;        // dwords staged past the tile end (4 needed, 2 chunks loaded)
-constexpr int kLdsCounts = kTile + kHalo + 3 * kRun + 16;  // runs may read (masked) past the halo
+// Indexes of short ORFs (mean length below kSmallTileMeanNt) are cut into smaller tiles: a tile of
+// 60-nt ORFs then holds 102 segments = 2 rounds of the short-ORF path instead of 132 = 3.
+#ifndef RP_TILE_SMALL
+#define RP_TILE_SMALL 6144
+#endif
+constexpr int kTileSmall = RP_TILE_SMALL;
+constexpr long long kSmallTileMeanNt = 140;
+inline int pick_tile(long long n_orfs, long long total_nt)
+{
+    return (n_orfs > 0 && total_nt < kSmallTileMeanNt * n_orfs) ? kTileSmall : kTile;
+}
+template <int TILE>
+constexpr int lds_counts() { return TILE + kHalo + 3 * kRun + 16; }  // runs may read (masked) past the halo
 static_assert(kTile / 3 < 65536, "N_f / M_f of a segment are kept in 16-bit fields");
 constexpr int kMaxRecs = kSegChunk + (kTile / (3 * kRun) + kSegChunk + 2 * 64) / 16 + 1;  // one per (segment, 16-lane row)
 
@@ -89,6 +101,7 @@ constexpr size_t kRecordBytes = 48;
 //   bit  63     live     0 = this id is a gap (no segment: empty ORF, or an unused id)
 typedef unsigned long long seg_desc_t;
 static_assert(kTile + kHalo < 8192 && kTile / 3 < 4096 && (kTile / 3 + kRun - 1) / kRun < 256, "descriptor field widths");
+static_assert(kTileSmall <= kTile && kTileSmall % 256 == 0, "the small tile reuses the big tile's field widths and table sizes");
 
 // The first kHeadSlots segment slots of every tile are ALSO kept tile-major, behind the tile's
 // own [a0, a1) ORF range, and followed by the tile's lane map:
@@ -322,14 +335,15 @@ namespace rp {
 // Interior tiles use the LDS-DMA form of global_load (no VGPR round trip, one instruction
 // per KiB row, rows dealt round-robin to the four waves); the first / last tile take the
 // guarded path with zero fill.  The DMA is NOT waited for here.
+template <int TILE>
 __device__ __forceinline__ int load_tile_to_lds(const int32_t *__restrict__ counts, long long t0,
                                                 long long total_nt, int *s_counts, int tid)
 {
-    constexpr int n_chunks = (kTile + kHalo) / 4;  // 16-byte chunks
+    constexpr int n_chunks = (TILE + kHalo) / 4;  // 16-byte chunks
     constexpr int kRowPos = 256;                    // positions per DMA row (64 lanes x 16 B)
-    static_assert(kTile % kRowPos == 0, "tile must be a whole number of 1 KiB rows");
+    static_assert(TILE % kRowPos == 0, "tile must be a whole number of 1 KiB rows");
     static_assert(kHalo == 8, "halo is loaded as two extra chunks");
-    const bool interior = (t0 >= 0) && (t0 + kTile + kHalo <= total_nt);  // workgroup-uniform
+    const bool interior = (t0 >= 0) && (t0 + TILE + kHalo <= total_nt);  // workgroup-uniform
     if (interior) {
         typedef const __attribute__((address_space(1))) void *gptr_t;
         typedef __attribute__((address_space(3))) void *lptr_t;
@@ -342,7 +356,7 @@ __device__ __forceinline__ int load_tile_to_lds(const int32_t *__restrict__ coun
         // none and get their plan rows early.  The wave index is made scalar so that the row loop
         // is straight-line code (M0 and the global offset are SALU arithmetic).
         constexpr int kIssuers = kLoaders;
-        constexpr int kRows = kTile / kRowPos;
+        constexpr int kRows = TILE / kRowPos;
         constexpr int kEven = kRows / kIssuers;  // rows every issuing wave takes
         const int w = __builtin_amdgcn_readfirstlane(tid >> 6) - (kTileBlock / kWave - kIssuers);
         if (w >= 0) {
@@ -356,7 +370,7 @@ __device__ __forceinline__ int load_tile_to_lds(const int32_t *__restrict__ coun
                 if (w == row - kEven * kIssuers)
                     __builtin_amdgcn_global_load_lds((gptr_t)(src + row * kRowPos), (lptr_t)(s_counts + row * kRowPos), 16, 0, 0);
             if (w == kIssuers - 1 && lane < kHalo / 4)  // halo: 2 chunks past the tile
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + kTile), (lptr_t)(s_counts + kTile), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + TILE), (lptr_t)(s_counts + TILE), 16, 0, 0);
         }
         // NOTE: no wait here -- the caller waits (vmcnt only tracks the DMA) after it has
         // issued its own independent loads.  Returned: how many loads this wave put in flight.
@@ -779,12 +793,12 @@ __device__ __forceinline__ void short_round(seg_desc_t dc, const int *s_counts, 
 
 // FUSED: `counts` is the dense coverage and the tile is staged through the piece plan
 // (rp_pieces.hpp) -- the profiles never exist in HBM (plan.mis == 0 there).
-template <bool FUSED>
+template <bool FUSED, int TILE>
 __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const int32_t *__restrict__ counts,
                                                            long long n_orfs, TilePlan plan,
                                                            TileWorkspace ws, PiecePlan pp)
 {
-    __shared__ __attribute__((aligned(16))) int s_counts[kLdsCounts];
+    __shared__ __attribute__((aligned(16))) int s_counts[lds_counts<TILE>()];
     __shared__ int s_live[kSegChunk];     // the slot holds a segment of this tile
     __shared__ int s_tail[kSegChunk];     // LDS index of an owned partial last codon | its length << 16, or -1
     __shared__ int s_vlstart[kSegChunk + 1];
@@ -796,7 +810,7 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
     const long long b = blockIdx.x;
-    const long long t0 = b * (long long)kTile - plan.mis;  // position of LDS index 0 (may be < 0 for b == 0)
+    const long long t0 = b * (long long)TILE - plan.mis;  // position of LDS index 0 (may be < 0 for b == 0)
 
     if (blockIdx.x == 0 && tid == 0) *ws.long_count = 0;  // (k_orf_finish, next in the stream, appends)
     RP_STAMP_DECL
@@ -829,10 +843,10 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
         if (tile_lo != kTileSlow)
             stage_tile_chunks(counts, pp, b, tile_lo, n_chunks, mine, s_counts, lane, wave);
         else
-            stage_tile_slow<kTile, kHalo>(counts, pp, b, plan.total_nt, s_counts, lane, wave);
+            stage_tile_slow<TILE, kHalo>(counts, pp, b, plan.total_nt, s_counts, lane, wave);
         __builtin_amdgcn_s_setprio(0);
     } else {
-        load_tile_to_lds(counts, t0, plan.total_nt, s_counts, tid);
+        load_tile_to_lds<TILE>(counts, t0, plan.total_nt, s_counts, tid);
     }
     if (wave == 0) {  // the integer accumulators of the 64 slots (before anyone's atomics: barrier 1)
         s_ints[lane].nn = 0;

@@ -62,7 +62,48 @@ def test_fuzz_against_oracle(eng, algo, seed):
     res = r.cpu_numpy()
     assert_matches_oracle(res, counts, offsets)
     split = (res["flags"] & 4) != 0
-    tile = TILES[algo]
+    from ribotricer_amd import _lib
+
+    tile = _lib.tile_positions(lens.size, total)  # 7 936, or 6 144 for an index of short ORFs
     starts, ends = offsets[:-1] + mis, offsets[1:] + mis
     expect_split = (lens > 0) & ((ends - 1) // tile > starts // tile)
     assert np.array_equal(split, expect_split)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_small_tile_boundaries(eng, seed):
+    """Indexes of short ORFs run on 6 144-position tiles: ORF ends hugging those boundaries, empty
+    ORFs on them, a few multi-tile ORFs among thousands of short ones, every 16-byte phase."""
+    from ribotricer_amd import _lib
+
+    rng = np.random.default_rng(500 + seed)
+    small = 6144
+    lens = []
+    total = 0
+    for k in range(1, 9):  # short ORFs up to each boundary, the last one ending at boundary + d
+        d = int(rng.integers(-2, 3))
+        target = small * k + d - (seed % 4)  # (the device array starts `mis` ints off the 16-byte grid)
+        while target - total > 130:
+            n = int(rng.integers(1, 100))
+            lens.append(n)
+            total += n
+        lens.append(target - total)
+        total = target
+        if k % 3 == 0:
+            lens += [0, 0]  # empty ORFs sitting on a boundary
+    lens += [int(x) for x in rng.integers(1, 60, 3000)]
+    lens[len(lens) // 2] = 3 * small + 7          # a multi-tile ORF among the short ones
+    lens.append(2 * small)
+    lens = np.asarray(lens, np.int64)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    total = int(offsets[-1])
+    assert _lib.tile_positions(lens.size, total) == small
+    counts = rng.poisson(np.repeat(rng.choice([0.02, 0.4, 3.0], size=lens.size), lens)).astype(np.int32)
+    mis = seed % 4
+    dev = torch.zeros(total + 8, dtype=torch.int32, device="cuda:0")
+    view = dev[mis : mis + total]
+    view.copy_(torch.from_numpy(counts))
+    res = eng.score(view, torch.from_numpy(offsets).cuda(), algo="tile").cpu_numpy()
+    assert_matches_oracle(res, counts, offsets)
+    starts, ends = offsets[:-1] + mis, offsets[1:] + mis
+    assert np.array_equal((res["flags"] & 4) != 0, (lens > 0) & ((ends - 1) // small > starts // small))
