@@ -151,7 +151,7 @@ int rp_phase_score_csr_dev(int device, const int32_t *d_counts, const int64_t *d
 
 /*
  * Positions per tile of the tile path for an index of n_orfs ORFs and total_nt nucleotides:
- * 7 936, or 6 144 for indexes of short ORFs (mean length < 140 nt), where a tile then holds
+ * 7 936, or 6 144 for indexes of short ORFs (mean length < 180 nt), where a tile then holds
  * fewer segments.  Informational (RP_FLAG_SPLIT marks ORFs that span tiles); every sizing
  * function and kernel derives the same value from the same two numbers.
  */

@@ -63,7 +63,10 @@ constexpr int kHalo = 8;        // dwords staged past the tile end (4 needed, 2 
 #define RP_TILE_SMALL 6144
 #endif
 constexpr int kTileSmall = RP_TILE_SMALL;
-constexpr long long kSmallTileMeanNt = 140;
+#ifndef RP_SMALL_MEAN
+#define RP_SMALL_MEAN 180
+#endif
+constexpr long long kSmallTileMeanNt = RP_SMALL_MEAN;
 inline int pick_tile(long long n_orfs, long long total_nt)
 {
     return (n_orfs > 0 && total_nt < kSmallTileMeanNt * n_orfs) ? kTileSmall : kTile;
