@@ -368,15 +368,23 @@ __device__ __forceinline__ void replay_codon_terms(int a, int b, int c, double &
 }
 
 // One wave, one ORF.  Lane t takes triplets t, t + 64, ...: five counts give it one codon of
-// each reading frame (one pass over the profile for all three frames); the per-frame sums are
-// then folded in codon order, wave-uniform, exactly as numpy folds them.
+// each reading frame (one pass over the profile for all three frames).  The per-frame sums are
+// plain left folds in codon order, exactly as numpy performs them -- inherently sequential, so
+// they run in ONE lane per frame (lanes 0, 1, 2, side by side): every chunk's non-zero codons
+// are compacted into LDS in codon order and the three lanes add theirs up, then score their
+// frame.  (The fold used to be wave-uniform, 15 instructions and six lane reads per codon and
+// frame after frame; it was most of the ~18 us a replay took.)
+struct ReplayLds {
+    double t[3][65][3];  // [frame][slot][pxx, pxr, pxi]; 65: the frames' rows on different banks
+};
+
 template <typename Counts>
 __device__ __forceinline__ void replay_tie_wave(Counts v, long long len, int lane,
-                                             double &phase, int &valid)
+                                             double &phase, int &valid, ReplayLds *lds)
 {
     constexpr double kPyySeg = 0x1.5555555555555p-1;
-    double sxx[3] = {0.0, 0.0, 0.0}, sxr[3] = {0.0, 0.0, 0.0}, sxi[3] = {0.0, 0.0, 0.0};  // wave-uniform folds
-    int n[3] = {0, 0, 0};
+    double sxx = 0.0, sxr = 0.0, sxi = 0.0;  // lane f < 3: the running sums of frame f
+    int n = 0;
     const long long n_trip = len / 3;  // frame f has a codon at triplet j iff 3j + f + 2 < len
     const long long last = len > 0 ? len - 1 : 0;
     auto load5 = [&](long long j, int (&w)[5]) {  // the five counts of triplet j (clamped reads, masked)
@@ -390,54 +398,62 @@ __device__ __forceinline__ void replay_tie_wave(Counts v, long long len, int lan
     };
     int w[5], wn[5];
     load5(lane, w);
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     for (long long j0 = 0; j0 < n_trip; j0 += kWave) {
         const long long j = j0 + lane;
         const long long p = 3 * j;
         load5(j + kWave, wn);  // the next chunk is in flight while this one is folded
+        int mine = 0;  // lane f < 3: how many codons of frame f this chunk holds
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
             const bool nz = j < n_trip && p + f + 2 < len && (w[f] | w[f + 1] | w[f + 2]) != 0;
-            double pxx = 0.0, pxr = 0.0, pxi = 0.0;
-            if (nz) replay_codon_terms(w[f], w[f + 1], w[f + 2], pxx, pxr, pxi);
-            unsigned long long mask = __ballot(nz);
-            while (mask != 0) {  // numpy's reductions here are plain left folds in segment order
-                const int l = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const double t0 = readlane_f64(pxx, l), t1 = readlane_f64(pxr, l), t2 = readlane_f64(pxi, l);
-                if (n[f] == 0) {
-                    sxx[f] = t0;
-                    sxr[f] = t1;
-                    sxi[f] = t2;
+            const unsigned long long mask = __ballot(nz);
+            if (nz) {
+                double pxx, pxr, pxi;
+                replay_codon_terms(w[f], w[f + 1], w[f + 2], pxx, pxr, pxi);
+                double *slot = lds->t[f][__builtin_popcountll(mask & below)];
+                slot[0] = pxx;
+                slot[1] = pxr;
+                slot[2] = pxi;
+            }
+            if (lane == f) mine = __builtin_popcountll(mask);
+        }
+        __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations complete in order)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < 3) {
+            const double(*row)[3] = lds->t[lane];
+            for (int i = 0; i < mine; ++i) {  // numpy's reductions here are plain left folds in segment order
+                const double t0 = row[i][0], t1 = row[i][1], t2 = row[i][2];
+                if (n == 0) {
+                    sxx = t0;
+                    sxr = t1;
+                    sxi = t2;
                 } else {
-                    sxx[f] = sxx[f] + t0;
-                    sxr[f] = sxr[f] + t1;
-                    sxi[f] = sxi[f] + t2;
+                    sxx = sxx + t0;
+                    sxr = sxr + t1;
+                    sxi = sxi + t2;
                 }
-                ++n[f];
+                ++n;
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows are rewritten by the next chunk
 #pragma unroll
         for (int k = 0; k < 5; ++k) w[k] = wn[k];
     }
-    double coh = 0.0;
-    int val = -1;
-#pragma unroll
-    for (int f = 0; f < 3; ++f) {
-        if (n[f] == 0) {  // empty frame: reset (statistics.py:94-95)
-            coh = 0.0;
-            val = 0;
-            continue;
-        }
-        double pxx_m = sxx[f], pyy_m = kPyySeg, re = sxr[f], im = sxi[f];
-        if (n[f] > 1) {
-            const double dn = (double)n[f];
-            pxx_m = sxx[f] / dn;
+    // lanes 0..2: the frame's coherence at f = 1/3
+    double score = 0.0;
+    if (lane < 3 && n > 0) {
+        double pxx_m = sxx, pyy_m = kPyySeg, re = sxr, im = sxi;
+        if (n > 1) {
+            const double dn = (double)n;
+            pxx_m = sxx / dn;
             double syy = kPyySeg;
-            for (int k = 1; k < n[f]; ++k) syy = syy + kPyySeg;
+            for (int k = 1; k < n; ++k) syy = syy + kPyySeg;
             pyy_m = syy / dn;
             const double scl = 1.0 / dn;
-            re = sxr[f] * scl;
-            im = sxi[f] * scl;
+            re = sxr * scl;
+            im = sxi * scl;
         }
         const double ar = __builtin_fabs(re), ai = __builtin_fabs(im);
         const double mx = ar > ai ? ar : ai, mn = ar > ai ? ai : ar;
@@ -446,12 +462,25 @@ __device__ __forceinline__ void replay_tie_wave(Counts v, long long len, int lan
             const double q = mn / mx;
             ab = mx * __builtin_sqrt(__builtin_fma(q, q, 1.0));
         }
-        const double score = ((ab * ab) / pxx_m) / pyy_m;
-        if (score > coh) {  // the reference's own strict '>' (statistics.py:109); NaN never wins
-            coh = score;
-            val = n[f];
+        score = ((ab * ab) / pxx_m) / pyy_m;
+    }
+    // the frame state machine, wave-uniform, on the three lanes' results
+    double coh = 0.0;
+    int val = -1;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        const int nf = __builtin_amdgcn_readlane(n, f);
+        const double sf = readlane_f64(score, f);
+        if (nf == 0) {  // empty frame: reset (statistics.py:94-95)
+            coh = 0.0;
+            val = 0;
+            continue;
         }
-        if (val == -1) val = n[f];
+        if (sf > coh) {  // the reference's own strict '>' (statistics.py:109); NaN never wins
+            coh = sf;
+            val = nf;
+        }
+        if (val == -1) val = nf;
     }
     phase = __builtin_sqrt(coh);
     valid = val;

@@ -982,6 +982,7 @@ __global__ __launch_bounds__(kFinishBlock) void k_orf_finish(Source source,
                                                              TileWorkspace ws, OrfOutputs out,
                                                              FilterParams fp)
 {
+    __shared__ ReplayLds s_replay;  // (one wave per workgroup)
     const int lane = threadIdx.x;
     const long long orf = (long long)blockIdx.x * kFinishBlock + lane;
     long long beg = 0, len = 0, count = 0;
@@ -1055,7 +1056,7 @@ __global__ __launch_bounds__(kFinishBlock) void k_orf_finish(Source source,
         unsigned flags;
         combine_frames(fr2, phase, valid, flags);
         if (flags & RP_FLAG_TIE) {
-            replay_tie_wave(source.orf(orf_s, beg_s), len_s, lane, phase, valid);
+            replay_tie_wave(source.orf(orf_s, beg_s), len_s, lane, phase, valid, &s_replay);
             flags |= RP_FLAG_REPLAY;
         }
         if (lane == 0)
@@ -1077,6 +1078,7 @@ __global__ __launch_bounds__(kLongBlock) void k_rewalk_long(Source source,
     __shared__ double s_part[kWaves][6];
     __shared__ int s_parti[kWaves][7];
     __shared__ long long s_partc[kWaves];
+    __shared__ ReplayLds s_replay;  // (wave 0 replays)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int n_long = *ws.long_count;
@@ -1131,7 +1133,7 @@ __global__ __launch_bounds__(kLongBlock) void k_rewalk_long(Source source,
         unsigned flags;
         combine_frames(fr, phase, valid, flags);
         if (flags & RP_FLAG_TIE) {
-            replay_tie_wave(source.orf(orf, beg), len, lane, phase, valid);
+            replay_tie_wave(source.orf(orf, beg), len, lane, phase, valid, &s_replay);
             flags |= RP_FLAG_REPLAY;
         }
         const unsigned split = (beg + plan.mis) / TILE != (beg + len - 1 + plan.mis) / TILE ? RP_FLAG_SPLIT : 0u;

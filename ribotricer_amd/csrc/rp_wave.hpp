@@ -81,7 +81,7 @@ constexpr long long kWaveFp32MaxLen = 16384;
 
 __device__ __forceinline__ void wave_score_orf(const int32_t *__restrict__ v, long long len, int lane,
                                                const FilterParams &fp, double &phase, int &valid,
-                                               long long &count, int &min_codon, unsigned &flags)
+                                               long long &count, int &min_codon, unsigned &flags, ReplayLds *replay_lds)
 {
     FrameScore fr[3];
     unsigned extra = 0;
@@ -105,7 +105,7 @@ __device__ __forceinline__ void wave_score_orf(const int32_t *__restrict__ v, lo
     combine_frames(fr, phase, valid, flags);
     flags |= extra;
     if (flags & RP_FLAG_TIE) {  // an exact frame tie: the reference's own bits decide (wave-uniform)
-        replay_tie_wave(v, len, lane, phase, valid);
+        replay_tie_wave(v, len, lane, phase, valid, replay_lds);
         flags |= RP_FLAG_REPLAY;
     }
 }
@@ -120,6 +120,7 @@ __global__ __launch_bounds__(kWaveBlock) void k_wave_score(const int32_t *__rest
                                                            long long n_orfs, OrfOutputs out,
                                                            FilterParams fp)
 {
+    __shared__ ReplayLds s_replay[kWaveBlock / kWave];  // one per wave
     const int lane = threadIdx.x & (kWave - 1);
     const long long waves_total = (long long)gridDim.x * (kWaveBlock / kWave);
     long long orf = (long long)blockIdx.x * (kWaveBlock / kWave) + (threadIdx.x >> 6);
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(kWaveBlock) void k_wave_score(const int32_t *__rest
         int valid, min_codon;
         long long count;
         unsigned flags;
-        wave_score_orf(counts + beg, len, lane, fp, phase, valid, count, min_codon, flags);
+        wave_score_orf(counts + beg, len, lane, fp, phase, valid, count, min_codon, flags, &s_replay[threadIdx.x >> 6]);
         if (lane == 0) store_orf(out, fp, orf, phase, valid, count, min_codon, flags, len);
     }
 }
