@@ -340,31 +340,24 @@ __device__ __forceinline__ double readlane_f64(double x, int l)
 }
 
 #pragma clang fp contract(off)
-// (pxx, pxr, pxi) of one non-zero codon
-__device__ __forceinline__ void replay_codon_terms(int a, int b, int c, double &pxx, double &pxr, double &pxi)
+// (pxx, pxr, pxi) of one non-zero codon whose counts are past the host-filled table (pow as x*x)
+__device__ __forceinline__ void replay_codon_compute(int a, int b, int c, double &pxx, double &pxr, double &pxi)
 {
     constexpr double kC23 = -0x1.ffffffffffffcp-2, kC43 = -0x1.0000000000004p-1;
     constexpr double kS23 = 0x1.bb67ae8584cabp-1, kS43 = -0x1.bb67ae8584ca8p-1;
     constexpr double kTwI = 0x1.bb67ae8584caap-1, kScale = 0x1.5555555555555p-2;
-    if ((unsigned)(a | b | c) < (1u << kCodonTabBits)) {
-        const CodonTerms t = rp_codon_tab[(a << (2 * kCodonTabBits)) | (b << kCodonTabBits) | c];
-        pxx = t.pxx;
-        pxr = t.pxr;
-        pxi = t.pxi;
-    } else {
-        const double real = ((double)a + (double)b * kC23) + (double)c * kC43;
-        const double image = (double)b * kS23 + (double)c * kS43;
-        double norm = __builtin_sqrt(real * real + image * image);
-        if (norm == 0.0) norm = 1.0;
-        const double v0 = (double)a / norm, v1 = (double)b / norm, v2 = (double)c / norm;
-        const double m = ((v0 + v1) + v2) / 3.0;
-        const double d0 = v0 - m, d1 = v1 - m, d2 = v2 - m;
-        const double xr = d0 + (-0.5) * (d1 + d2);
-        const double xi = kTwI * (d2 - d1);
-        pxx = (__builtin_fma(xr, xr, xi * xi) * kScale) * 2.0;
-        pxr = (xr * kScale) * 2.0;
-        pxi = (-xi * kScale) * 2.0;
-    }
+    const double real = ((double)a + (double)b * kC23) + (double)c * kC43;
+    const double image = (double)b * kS23 + (double)c * kS43;
+    double norm = __builtin_sqrt(real * real + image * image);
+    if (norm == 0.0) norm = 1.0;
+    const double v0 = (double)a / norm, v1 = (double)b / norm, v2 = (double)c / norm;
+    const double m = ((v0 + v1) + v2) / 3.0;
+    const double d0 = v0 - m, d1 = v1 - m, d2 = v2 - m;
+    const double xr = d0 + (-0.5) * (d1 + d2);
+    const double xi = kTwI * (d2 - d1);
+    pxx = (__builtin_fma(xr, xr, xi * xi) * kScale) * 2.0;
+    pxr = (xr * kScale) * 2.0;
+    pxi = (-xi * kScale) * 2.0;
 }
 
 // One wave, one ORF.  Lane t takes triplets t, t + 64, ...: five counts give it one codon of
@@ -404,13 +397,21 @@ __device__ __forceinline__ void replay_tie_wave(Counts v, long long len, int lan
         const long long p = 3 * j;
         load5(j + kWave, wn);  // the next chunk is in flight while this one is folded
         int mine = 0;  // lane f < 3: how many codons of frame f this chunk holds
+        bool nz[3], big[3];
+        CodonTerms t[3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {  // the three frames' table rows travel together: one memory latency, not three
+            const int a = w[f], b = w[f + 1], c = w[f + 2];
+            nz[f] = j < n_trip && p + f + 2 < len && (a | b | c) != 0;
+            big[f] = (unsigned)(a | b | c) >= (1u << kCodonTabBits);
+            t[f] = rp_codon_tab[(nz[f] && !big[f]) ? ((a << (2 * kCodonTabBits)) | (b << kCodonTabBits) | c) : 0];
+        }
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
-            const bool nz = j < n_trip && p + f + 2 < len && (w[f] | w[f + 1] | w[f + 2]) != 0;
-            const unsigned long long mask = __ballot(nz);
-            if (nz) {
-                double pxx, pxr, pxi;
-                replay_codon_terms(w[f], w[f + 1], w[f + 2], pxx, pxr, pxi);
+            const unsigned long long mask = __ballot(nz[f]);
+            if (nz[f]) {
+                double pxx = t[f].pxx, pxr = t[f].pxr, pxi = t[f].pxi;
+                if (big[f]) replay_codon_compute(w[f], w[f + 1], w[f + 2], pxx, pxr, pxi);
                 double *slot = lds->t[f][__builtin_popcountll(mask & below)];
                 slot[0] = pxx;
                 slot[1] = pxr;
