@@ -10,7 +10,7 @@
 // stages its tile of counts straight from the coverage arrays with LDS-DMA, one chunk per
 // instruction, issued from straight-line code:
 //   * k_tile_gather writes the staged tile out: the CSR `counts` array (report_all mode);
-//   * k_tile_score<true> scores it in place: the profiles are never written to HBM.
+//   * k_tile_score<true, TILE> scores it in place: the profiles are never written to HBM.
 // The plan depends on the index (and the coverage layout derived from it) only, so it is
 // built once per index and reused for every sample.
 #pragma once
