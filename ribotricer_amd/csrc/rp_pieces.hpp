@@ -257,6 +257,9 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
 // next to three other workgroups' lane runs: one instruction per ~10 cycles.)
 // Nothing is waited for here.
 // ---------------------------------------------------------------------------------------
+#ifndef RP_CHUNK_POLICY
+#define RP_CHUNK_POLICY " nt"  // the coverage is read once per launch: tile gather -5 % on gapped / 60-nt layouts, else unchanged
+#endif
 #define RP_DMA_STEP(I)                                          \
     "v_readlane_b32 %[so], %[w0], " #I "\n\t"                   \
     "v_readlane_b32 %[s1], %[w1], " #I "\n\t"                   \
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
     "s_lshr_b32 %[sd], %[st], 8\n\t"                            \
     "v_mad_i32_i24 %[vt], %[sd], %[vdelta], %[vup]\n\t"         \
     "v_add_u32 %[vt], %[so], %[vt]\n\t"                         \
-    "global_load_lds_dword %[vt], %[base]\n\t"
+    "global_load_lds_dword %[vt], %[base]" RP_CHUNK_POLICY "\n\t"
 #define RP_DMA_STEP8(A, B, C, D, E, F, G, H, LIM)               \
     RP_DMA_STEP(A) RP_DMA_STEP(B) RP_DMA_STEP(C) RP_DMA_STEP(D) \
     RP_DMA_STEP(E) RP_DMA_STEP(F) RP_DMA_STEP(G) RP_DMA_STEP(H) \
