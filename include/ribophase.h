@@ -386,6 +386,17 @@ int rp_index_view_host(const rp_index *index, rp_index_view *view);
 void rp_index_free(rp_index *index);
 
 /*
+ * The interval table of rp_gather_profiles_dev / rp_gather_plan_create_dev from a parsed index and
+ * a coverage layout (host, one pass): interval k of an ORF of group g starts at coverage index
+ * group_start[g] + (iv_start[k] - group_lo[g]) and is iv_end[k] - iv_start[k] + 1 long
+ * (interval.py:60-62); out_offsets = prefix sum of the ORF lengths.  Arrays as in rp_index_view.
+ */
+int rp_interval_table_host(const int64_t *iv_start, const int64_t *iv_end, const int64_t *orf_iv, const int32_t *group,
+                           const int64_t *length, int64_t n_orfs, int64_t n_intervals, const int64_t *group_start,
+                           const int64_t *group_lo, int64_t n_groups, int64_t *out_iv_start, int32_t *out_iv_len,
+                           int64_t *out_offsets);
+
+/*
  * ---- host side: BAM front end ----------------------------------
  *
  * rp_bam_split_host replaces split_bam (bam.py:33-153) without pysam: the BGZF file is read

@@ -891,6 +891,33 @@ int rp_index_view_host(const rp_index *index, rp_index_view *view)
 
 void rp_index_free(rp_index *index) { delete index; }
 
+int rp_interval_table_host(const int64_t *iv_start, const int64_t *iv_end, const int64_t *orf_iv, const int32_t *group,
+                           const int64_t *length, int64_t n_orfs, int64_t n_intervals, const int64_t *group_start,
+                           const int64_t *group_lo, int64_t n_groups, int64_t *out_iv_start, int32_t *out_iv_len,
+                           int64_t *out_offsets)
+{
+    if (n_orfs < 0 || n_intervals < 0 || n_groups < 0) return fail(RP_ERR_SIZE, "negative size");
+    if (!out_offsets || !orf_iv || (n_orfs > 0 && (!group || !length || !group_start || !group_lo)) ||
+        (n_intervals > 0 && (!iv_start || !iv_end || !out_iv_start || !out_iv_len)))
+        return fail(RP_ERR_NULL, "index arrays and outputs must be non-null");
+    int64_t total = 0;
+    out_offsets[0] = 0;
+    for (int64_t i = 0; i < n_orfs; ++i) {
+        const int32_t g = group[i];
+        const int64_t k0 = orf_iv[i], k1 = orf_iv[i + 1];
+        if (g < 0 || g >= n_groups || k0 < 0 || k1 < k0 || k1 > n_intervals)
+            return fail(RP_ERR_ARG, "ORF %lld: group %d / interval range [%lld, %lld) out of range", (long long)i, (int)g, (long long)k0, (long long)k1);
+        const int64_t shift = group_start[g] - group_lo[g];
+        for (int64_t k = k0; k < k1; ++k) {
+            out_iv_start[k] = iv_start[k] + shift;
+            out_iv_len[k] = (int32_t)(iv_end[k] - iv_start[k] + 1);
+        }
+        total += length[i];
+        out_offsets[i + 1] = total;
+    }
+    return RP_OK;
+}
+
 int rp_format_double_repr(double value, char *buf) { return buf ? rpfmt::double_repr(value, buf) : 0; }
 
 size_t rp_format_int_list(const int32_t *values, int64_t n, char *out)

@@ -159,17 +159,24 @@ def build_interval_table(records, base) -> IntervalTable:
 
 
 def interval_table_from_index(index, base) -> IntervalTable:
-    """IntervalTable of a natively parsed index (``ribotricer_amd.index.NativeIndex``),
-    vectorised: no per-ORF Python."""
+    """IntervalTable of a natively parsed index (``ribotricer_amd.index.NativeIndex``): one native
+    pass (``rp_interval_table_host``), no per-ORF Python."""
     keys = index.group_keys
     g_start = np.array([base[k][0] for k in keys], np.int64)
     g_lo = np.array([base[k][1] for k in keys], np.int64)
-    per_iv_group = np.repeat(index.group, np.diff(index.orf_iv))
-    iv_start = g_start[per_iv_group] + (index.iv_start - g_lo[per_iv_group])
-    iv_len = (index.iv_end - index.iv_start + 1).astype(np.int32)
-    offsets = np.zeros(index.n_orfs + 1, np.int64)
-    np.cumsum(index.length, out=offsets[1:])
-    return IntervalTable(iv_start, iv_len, index.orf_iv.copy(), index.reverse.copy(), offsets)
+    n, m = int(index.n_orfs), int(index.iv_start.size)
+    iv_start = np.empty(m, np.int64)
+    iv_len = np.empty(m, np.int32)
+    offsets = np.empty(n + 1, np.int64)
+    arrays = [np.ascontiguousarray(a, dtype=t) for a, t in (
+        (index.iv_start, np.int64), (index.iv_end, np.int64), (index.orf_iv, np.int64), (index.group, np.int32), (index.length, np.int64))]
+
+    def ptr(a):
+        return ctypes.c_void_p(a.ctypes.data if a.size else 0)
+
+    _lib.check(_lib.load().rp_interval_table_host(
+        *[ptr(a) for a in arrays], n, m, ptr(g_start), ptr(g_lo), len(keys), ptr(iv_start), ptr(iv_len), ptr(offsets)))
+    return IntervalTable(iv_start, iv_len, arrays[2].copy(), np.ascontiguousarray(index.reverse, dtype=np.uint8).copy(), offsets)
 
 
 class GatherPlan:

@@ -66,7 +66,7 @@ t = time.perf_counter()
 coverage2, _ = build_coverage_device(cols, index); T_cols = time.perf_counter() - t; torch.cuda.synchronize()
 assert torch.equal(coverage, coverage2)
 t = time.perf_counter()
-table = interval_table_from_index(index, base); t = lap("interval_table_numpy", t)
+table = interval_table_from_index(index, base); t = lap("interval_table_native", t)
 d_counts, d_offsets = gather_profiles_device(coverage, table); t = lap("table_h2d_plus_gather_f1", t)
 res = d.score_profiles(d_counts, d_offsets, 0.428571428571, 5, 0, 0, 0.0); t = lap("score_plus_d2h_outputs", t)
 counts, offsets = d_counts.cpu().numpy(), d_offsets.cpu().numpy(); t = lap("d2h_profiles", t)
