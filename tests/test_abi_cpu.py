@@ -100,3 +100,16 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "ribophase.h"\nint main(void){ rp_filter_params p; (void)p; return RP_OK; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(REPO, "include"),
                            "-c", str(src), "-o", str(tmp_path / "t.o")])
+
+
+def test_tile_positions_rule():
+    """rp_tile_positions (no device needed): short-ORF indexes get the smaller tile."""
+    from ribotricer_amd import _lib
+
+    assert _lib.tile_positions(1000, 100_000) == 6144      # mean 100 nt
+    assert _lib.tile_positions(1000, 179_999) == 6144
+    assert _lib.tile_positions(1000, 180_000) == 7936      # mean 180 nt and up
+    assert _lib.tile_positions(11_000_000, 3_966_674_436) == 7936
+    assert _lib.tile_positions(0, 0) == 7936
+    # the sizing functions follow the same rule: a short-ORF index needs the bigger plan per nucleotide
+    assert _lib.plan_bytes(1000, 100_000) > 0 and _lib.workspace_bytes(1000, 100_000, _lib.RP_ALGO_TILE) > 0
