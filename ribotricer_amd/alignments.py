@@ -13,6 +13,7 @@ are accepted everywhere through one conversion pass (the compatibility shim).
 from __future__ import annotations
 
 import ctypes
+import os
 from collections import Counter, defaultdict
 from operator import itemgetter
 from typing import NamedTuple
@@ -37,6 +38,25 @@ def _factorize(values):
         return list(seen), code
 
 
+_PYDICT = [False, None]
+
+
+def _pydict_reader():
+    """``rp_counter_columns`` of csrc/libribopy.so (built where Python.h is installed), or None."""
+    if not _PYDICT[0]:
+        _PYDICT[0] = True
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libribopy.so")
+        if os.path.exists(path):
+            try:
+                fn = ctypes.PyDLL(path).rp_counter_columns
+                fn.restype = ctypes.c_longlong
+                fn.argtypes = [ctypes.py_object, ctypes.py_object, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong]
+                _PYDICT[1] = fn
+            except (OSError, AttributeError):  # pragma: no cover
+                _PYDICT[1] = None
+    return _PYDICT[1]
+
+
 class MergedColumns(NamedTuple):
     """What ``merge_read_lengths`` returns, as columns: one row per (read length, strand, chrom,
     shifted pos) key -- rows of different read lengths may name the same position; they add up."""
@@ -50,24 +70,36 @@ class MergedColumns(NamedTuple):
     @classmethod
     def from_counters(cls, merged_alignments) -> "MergedColumns":
         """The reference's ``strand -> Counter{(chrom, pos): count}`` in one pass per strand."""
+        fast = _pydict_reader()
         strands, chrom_codes, poss, counts = [], [], [], []
         names: dict = {}
+        name_list: list = []
         for strand, table in merged_alignments.items():
             if not table or strand not in STRANDS:
                 continue
-            keys = list(table.keys())
-            n = len(keys)
-            pos = np.fromiter(map(itemgetter(1), keys), np.int64, n)
-            cnt = np.fromiter(table.values(), np.int64, n)
-            local, code = _factorize(list(map(itemgetter(0), keys)))
-            remap = np.array([names.setdefault(c, len(names)) for c in local], np.int32)
+            n = len(table)
+            if fast is not None:  # one PyDict_Next loop in C (csrc/rp_pydict.cpp)
+                code = np.empty(n, np.int32)
+                pos = np.empty(n, np.int64)
+                cnt = np.empty(n, np.int64)
+                got = fast(table, name_list, code.ctypes.data, pos.ctypes.data, cnt.ctypes.data, n)
+                if got != n:  # pragma: no cover - (a Python error is raised by ctypes before we get here)
+                    raise ValueError("merged_alignments: malformed Counter")
+                chrom_codes.append(code)
+            else:
+                keys = list(table.keys())
+                pos = np.fromiter(map(itemgetter(1), keys), np.int64, n)
+                cnt = np.fromiter(table.values(), np.int64, n)
+                local, code = _factorize(list(map(itemgetter(0), keys)))
+                remap = np.array([names.setdefault(c, len(names)) for c in local], np.int32)
+                chrom_codes.append(remap[code])
             strands.append(np.full(n, STRANDS.index(strand), np.uint8))
-            chrom_codes.append(remap[code])
             poss.append(pos)
             counts.append(cnt)
         if not poss:
             return cls(np.zeros(0, np.uint8), np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros(0, np.int64), [])
-        return cls(np.concatenate(strands), np.concatenate(chrom_codes), np.concatenate(poss), np.concatenate(counts), list(names))
+        return cls(np.concatenate(strands), np.concatenate(chrom_codes), np.concatenate(poss), np.concatenate(counts),
+                   name_list if fast is not None else list(names))
 
     def as_counters(self):
         """Back to ``strand -> Counter`` (for ``export_wig`` and other consumers of the reference's format)."""
