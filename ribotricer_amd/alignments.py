@@ -78,28 +78,36 @@ class MergedColumns(NamedTuple):
             if not table or strand not in STRANDS:
                 continue
             n = len(table)
+            done = False
             if fast is not None:  # one PyDict_Next loop in C (csrc/rp_pydict.cpp)
                 code = np.empty(n, np.int32)
                 pos = np.empty(n, np.int64)
                 cnt = np.empty(n, np.int64)
-                got = fast(table, name_list, code.ctypes.data, pos.ctypes.data, cnt.ctypes.data, n)
-                if got != n:  # pragma: no cover - (a Python error is raised by ctypes before we get here)
-                    raise ValueError("merged_alignments: malformed Counter")
-                chrom_codes.append(code)
-            else:
+                known = len(name_list)
+                try:
+                    done = fast(table, name_list, code.ctypes.data, pos.ctypes.data, cnt.ctypes.data, n) == n
+                except (TypeError, ValueError, OverflowError):
+                    del name_list[known:]  # e.g. float counts: let the Python loop below decide
+                if done:
+                    chrom_codes.append(code)
+            if not done:
+                fast = None  # (one numbering of the chromosomes per call: stay on this path)
+                if name_list and not names:
+                    names = {c: k for k, c in enumerate(name_list)}
                 keys = list(table.keys())
                 pos = np.fromiter(map(itemgetter(1), keys), np.int64, n)
                 cnt = np.fromiter(table.values(), np.int64, n)
                 local, code = _factorize(list(map(itemgetter(0), keys)))
                 remap = np.array([names.setdefault(c, len(names)) for c in local], np.int32)
                 chrom_codes.append(remap[code])
+                name_list = list(names)
             strands.append(np.full(n, STRANDS.index(strand), np.uint8))
             poss.append(pos)
             counts.append(cnt)
         if not poss:
             return cls(np.zeros(0, np.uint8), np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros(0, np.int64), [])
         return cls(np.concatenate(strands), np.concatenate(chrom_codes), np.concatenate(poss), np.concatenate(counts),
-                   name_list if fast is not None else list(names))
+                   name_list)
 
     def as_counters(self):
         """Back to ``strand -> Counter`` (for ``export_wig`` and other consumers of the reference's format)."""
