@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define RP_VERSION_STRING "0.2.0"
+#define RP_VERSION_STRING "0.3.0"
 
 /* largest admissible P-site count per nucleotide (exact in fp32; codon sums stay inside
  * int32 and a lane's 45-position partial read count inside uint32) */
@@ -70,6 +70,11 @@ typedef enum rp_status {
 #define RP_FLAG_SPLIT 0x04u    /* profile spanned more than one tile (several segment records) */
 #define RP_FLAG_REPLAY 0x08u   /* phase / valid_codons of this tie-flagged ORF come from the on-device
                                   replay of the reference's own float64 (numpy / scipy) arithmetic */
+#define RP_FLAG_BIGTIE 0x10u   /* the replay met a codon with a count >= 16: the reference squares through
+                                  the host C library's pow() (statistics.py:83), which the device cannot
+                                  restate past its host-filled table; phase / valid_codons stand on x*x
+                                  there.  rp_tie_replay_host on the profile gives the reference's bits
+                                  (the Python layer does that for every such ORF: engine.resolve_ties) */
 
 /* two frame scores count as tied when they differ by no more than RP_TIE_RTOL * (the larger
  * one) + RP_TIE_ATOL: relative, because the reference's own rounding noise is relative (~1e-15);
@@ -204,6 +209,21 @@ int rp_phase_score_frames_dev(int device, const int32_t *d_counts, const int64_t
 int rp_phase_score_f64_csr_dev(int device, const double *d_values, const int64_t *d_offsets,
                                int64_t n_profiles, double *d_phase, int32_t *d_valid,
                                uint8_t *d_flags, void *hip_stream);
+
+/*
+ * Exact frame ties the device cannot finish with the reference's bits (HOST functions, no GPU
+ * involved): statistics.py:83 squares through the C library's pow(), which is not x*x and
+ * belongs to the machine the reference runs on -- so this step is taken with this host's own
+ * libm.  For every profile of the CSR batch: phase[i], valid[i] = what statistics.py:48-115
+ * returns, float64 operation for float64 operation (csrc/rp_replay.hpp).  Meant for the few
+ * profiles per sample flagged RP_FLAG_BIGTIE (integer profiles, a tie involving a count >= 16)
+ * and for tie-flagged float profiles (metagene.py:243-244); it is NOT a scoring path -- a
+ * single thread, ~1 microsecond per codon.
+ */
+int rp_tie_replay_host(const int32_t *counts, const int64_t *offsets, int64_t n_profiles,
+                       double *phase, int32_t *valid);
+int rp_tie_replay_f64_host(const double *values, const int64_t *offsets, int64_t n_profiles,
+                           double *phase, int32_t *valid);
 
 /*
  * Profile gather: builds the CSR counts array on the device from

@@ -23,6 +23,7 @@ FLAG_TIE = 0x01
 FLAG_RECHECK64 = 0x02
 FLAG_SPLIT = 0x04
 FLAG_REPLAY = 0x08
+FLAG_BIGTIE = 0x10
 MIN_CODON_COV_EMPTY = 2147483647
 MAX_COUNT = 16777215
 ERR_INTERVALS = -12
@@ -70,6 +71,9 @@ SYMBOLS = {
     "rp_phase_score_csr_plan_dev": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(FilterParams), _vp, ctypes.c_size_t, _vp]),
     "rp_phase_score_frames_dev": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "rp_phase_score_f64_csr_dev": (_int, [_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    # host side (no GPU): exact-tie replay with this host's libm
+    "rp_tie_replay_host": (_int, [_vp, _vp, _i64, _vp, _vp]),
+    "rp_tie_replay_f64_host": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "rp_gather_profiles_dev": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "rp_gather_plan_bytes": (_int, [_i64, _i64, _i64, ctypes.POINTER(ctypes.c_size_t)]),
     "rp_gather_plan_create_dev": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp, ctypes.POINTER(_vp)]),
@@ -161,3 +165,22 @@ def workspace_bytes(n_orfs: int, total_nt: int, algo: int) -> int:
     out = ctypes.c_size_t(0)
     check(load().rp_workspace_bytes(n_orfs, total_nt, algo, ctypes.byref(out)))
     return out.value
+
+
+def tie_replay_host(values, offsets):
+    """``(phase float64[n], valid int32[n])`` of every profile of a host CSR batch, with the
+    reference's own float64 operations and this host's libm ``pow`` (``rp_tie_replay_host`` for
+    integer profiles, ``rp_tie_replay_f64_host`` for float64 ones).  For the handful of exact
+    frame ties the device cannot finish with the reference's bits; not a scoring path."""
+    import numpy as np
+
+    values = np.ascontiguousarray(values)
+    is_float = values.dtype.kind == "f"
+    values = np.ascontiguousarray(values, dtype=np.float64 if is_float else np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = offsets.size - 1
+    phase = np.empty(n, np.float64)
+    valid = np.empty(n, np.int32)
+    fn = load().rp_tie_replay_f64_host if is_float else load().rp_tie_replay_host
+    check(fn(values.ctypes.data if values.size else None, offsets.ctypes.data, n, phase.ctypes.data, valid.ctypes.data))
+    return phase, valid

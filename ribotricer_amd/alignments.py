@@ -215,13 +215,21 @@ def build_coverage_device(merged, index, device=None):
     if cols.pos.size == 0 or total == 0:
         return coverage, base
     group = cols.group_codes(keys)
-    live = group >= 0
-    if cols.count.size and (int(cols.count.min()) < 0 or int(cols.count.max()) > _lib.MAX_COUNT):
-        bad = int(cols.count.min()) if int(cols.count.min()) < 0 else int(cols.count.max())
-        raise _lib.RibophaseError(-7, f"P-site count {bad} outside [0, {_lib.MAX_COUNT}]")
     g_start = np.array([base[k][0] for k in keys], np.int64)
     g_lo = np.array([extent[k][0] for k in keys], np.int64)
     g_hi = np.array([extent[k][1] for k in keys], np.int64)
+    # Only rows the reference would ever look up take part: a position on a contig without
+    # candidate ORFs (rRNA, chrM) or outside every ORF's extent is never a key of a lookup
+    # (detect_orfs.py:176-187), whatever its count -- k_coverage_build drops those rows as well.
+    live = group >= 0
+    if live.any():
+        gl = np.where(live, group, 0)
+        live &= (cols.pos >= g_lo[gl]) & (cols.pos <= g_hi[gl])
+    if live.any():
+        c_live = cols.count[live]
+        if int(c_live.min()) < 0 or int(c_live.max()) > _lib.MAX_COUNT:
+            bad = int(c_live.min()) if int(c_live.min()) < 0 else int(c_live.max())
+            raise _lib.RibophaseError(-7, f"P-site count {bad} outside [0, {_lib.MAX_COUNT}]")
     to_dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev, non_blocking=True)  # noqa: E731
     d_group, d_pos, d_count = to_dev(group[live], np.int32), to_dev(cols.pos[live], np.int64), to_dev(cols.count[live], np.int32)
     d_start, d_lo, d_hi = to_dev(g_start, np.int64), to_dev(g_lo, np.int64), to_dev(g_hi, np.int64)

@@ -10,4 +10,4 @@ MINIMUM_READS_PER_CODON = 0  # const.py:32
 MINIMUM_VALID_CODONS_RATIO = 0  # const.py:35
 MINIMUM_DENSITY_OVER_ORF = 0.0  # const.py:39
 TYPICAL_OFFSET = 12  # const.py:23
-META_MIN_READS = 100000  # const.py:44
+META_MIN_READS = 100000  # const.py:42

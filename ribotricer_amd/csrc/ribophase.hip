@@ -21,6 +21,7 @@
 #include "rp_bam.hpp"
 #include "rp_wave.hpp"
 #include "rp_coverage.hpp"
+#include "rp_replay.hpp"
 
 namespace {
 
@@ -99,38 +100,25 @@ struct DeviceGuard {
 // scipy.signal.coherence): norm = sqrt(pow(real,2) + pow(image,2)) with glibc's pow(), which
 // is not x*x, then the three values of the segment's spectra.  They depend on the codon alone,
 // so all codons with counts < 16 are tabulated HERE, once per device, with this host's libm --
-// the libm the reference itself would run on.  Same operation order as oracle/scipy_replay.c.
+// the libm the reference itself would run on (rp_replay.hpp: codon_terms).
 constexpr int kMaxDevices = 64;
 std::mutex g_tab_mutex;
 bool g_tab_ready[kMaxDevices] = {};
 
-#pragma clang fp contract(off)
 void fill_codon_table(rp::CodonTerms *tab)
 {
     constexpr int B = rp::kCodonTabBits, N = 1 << B;
-    double (*volatile libm_pow)(double, double) = pow;  // not foldable into x*x
-    const double c23 = cos(2 * M_PI / 3), c43 = cos(4 * M_PI / 3), s23 = sin(2 * M_PI / 3), s43 = sin(4 * M_PI / 3);
-    const double tw = 0x1.bb67ae8584caap-1, scale = 0x1.5555555555555p-2;
     for (int a = 0; a < N; ++a)
         for (int b = 0; b < N; ++b)
             for (int c = 0; c < N; ++c) {
-                const double real = ((double)a + (double)b * c23) + (double)c * c43;
-                const double image = (double)b * s23 + (double)c * s43;
-                double norm = sqrt(libm_pow(real, 2.0) + libm_pow(image, 2.0));
-                if (norm == 0.0) norm = 1.0;
-                const double v0 = (double)a / norm, v1 = (double)b / norm, v2 = (double)c / norm;
-                const double m = ((v0 + v1) + v2) / 3.0;
-                const double d0 = v0 - m, d1 = v1 - m, d2 = v2 - m;
-                const double xr = d0 + (-0.5) * (d1 + d2);
-                const double xi = tw * (d2 - d1);
-                rp::CodonTerms &t = tab[(a << (2 * B)) | (b << B) | c];
-                t.pxx = (fma(xr, xr, xi * xi) * scale) * 2.0;
-                t.pxr = (xr * scale) * 2.0;
-                t.pxi = (-xi * scale) * 2.0;
-                t.pad = 0.0;
+                const rpreplay::Terms t = rpreplay::codon_terms((double)a, (double)b, (double)c);
+                rp::CodonTerms &e = tab[(a << (2 * B)) | (b << B) | c];
+                e.pxx = t.pxx;
+                e.pxr = t.pxr;
+                e.pxi = t.pxi;
+                e.pad = 0.0;
             }
 }
-#pragma clang fp contract(on)
 
 int ensure_norm_table(int device)  // call with `device` current
 {
@@ -577,6 +565,30 @@ int rp_phase_score_f64_csr_dev(int device, const double *d_values, const int64_t
                        (hipStream_t)hip_stream, d_values, d_offsets, (long long)n_profiles, d_phase,
                        d_valid, d_flags);
     RP_HIP(hipGetLastError());
+    return RP_OK;
+}
+
+int rp_tie_replay_host(const int32_t *counts, const int64_t *offsets, int64_t n_profiles, double *phase, int32_t *valid)
+{
+    if (n_profiles < 0) return fail(RP_ERR_SIZE, "n_profiles must be >= 0");
+    if (n_profiles > 0 && (!offsets || !phase || !valid)) return fail(RP_ERR_NULL, "offsets / phase / valid is null");
+    for (int64_t i = 0; i < n_profiles; ++i) {
+        const int64_t beg = offsets[i], len = offsets[i + 1] - beg;
+        if (len < 0 || (len > 0 && !counts)) return fail(RP_ERR_OFFSETS, "profile %lld: bad offsets or null counts", (long long)i);
+        rpreplay::replay_profile(counts + beg, len, &phase[i], &valid[i]);
+    }
+    return RP_OK;
+}
+
+int rp_tie_replay_f64_host(const double *values, const int64_t *offsets, int64_t n_profiles, double *phase, int32_t *valid)
+{
+    if (n_profiles < 0) return fail(RP_ERR_SIZE, "n_profiles must be >= 0");
+    if (n_profiles > 0 && (!offsets || !phase || !valid)) return fail(RP_ERR_NULL, "offsets / phase / valid is null");
+    for (int64_t i = 0; i < n_profiles; ++i) {
+        const int64_t beg = offsets[i], len = offsets[i + 1] - beg;
+        if (len < 0 || (len > 0 && !values)) return fail(RP_ERR_OFFSETS, "profile %lld: bad offsets or null values", (long long)i);
+        rpreplay::replay_profile(values + beg, len, &phase[i], &valid[i]);
+    }
     return RP_OK;
 }
 

@@ -128,11 +128,14 @@ private:
         }
         if (bsize < 0) return kFormat;
         const long payload = (long)bsize + 1 - 12 - (long)xlen - 8;  // compressed bytes of this block
-        if (payload < 0) return kFormat;
+        if (payload < 0 || payload > 65536) return kFormat;  // (BSIZE is 16 bits: a block is <= 64 KiB)
         blk.comp.resize((size_t)payload + 8);
         if (fread(blk.comp.data(), 1, blk.comp.size(), fh_) != blk.comp.size()) return kFormat;
         const unsigned char *t = blk.comp.data() + payload;
         blk.isize = t[4] | (t[5] << 8) | (t[6] << 16) | ((unsigned)t[7] << 24);
+        // ISIZE comes from the file: the BGZF format caps the uncompressed size of a block at 64 KiB,
+        // anything larger is a damaged trailer (and would otherwise size the inflate buffer)
+        if (blk.isize > 65536) return kFormat;
         return kOk;
     }
 
@@ -218,43 +221,81 @@ private:
 inline uint32_t le32(const unsigned char *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline uint16_t le16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
-// NH tag of a record's aux block: found -> *nh (as a signed 64-bit value)
-inline bool find_nh(const unsigned char *aux, const unsigned char *end, int64_t *nh)
+// The aux block of a record, as far as the decision list needs it.  The reference asks
+// `dict(read.get_tags())["NH"] == 1` (common.py:54-58): the LAST NH tag of the record decides, and a
+// tag of any type takes part in the comparison -- an integer or a float equal to 1 is unique, a
+// character or string value never is.  Also found here: the real CIGAR of a record with more than
+// 65 535 operations, which the BAM format moves into a CG:B,I tag (SAM spec 4.2.2; htslib swaps
+// it back in before pysam sees the read).
+struct AuxScan {
+    bool has_nh = false;
+    bool nh_is_one = false;
+    const unsigned char *cg = nullptr;  // CG:B,I payload (little-endian uint32 operations)
+    uint32_t cg_ops = 0;
+};
+
+inline void scan_aux(const unsigned char *aux, const unsigned char *end, AuxScan *out)
 {
     while (aux + 3 <= end) {
         const unsigned char t0 = aux[0], t1 = aux[1], ty = aux[2];
         aux += 3;
-        auto scalar = [&](size_t n, int64_t v) {
-            if (t0 == 'N' && t1 == 'H') *nh = v;
+        const bool is_nh = t0 == 'N' && t1 == 'H';
+        auto integer = [&](size_t n, int64_t v) {
+            if (is_nh) {
+                out->has_nh = true;
+                out->nh_is_one = v == 1;
+            }
             aux += n;
-            return t0 == 'N' && t1 == 'H';
+        };
+        auto other = [&]() {  // a value Python would not find equal to 1
+            if (is_nh) {
+                out->has_nh = true;
+                out->nh_is_one = false;
+            }
         };
         switch (ty) {
-            case 'A': aux += 1; break;
-            case 'c': if (aux + 1 > end) return false; if (scalar(1, (int8_t)aux[0])) return true; break;
-            case 'C': if (aux + 1 > end) return false; if (scalar(1, aux[0])) return true; break;
-            case 's': if (aux + 2 > end) return false; if (scalar(2, (int16_t)le16(aux))) return true; break;
-            case 'S': if (aux + 2 > end) return false; if (scalar(2, le16(aux))) return true; break;
-            case 'i': if (aux + 4 > end) return false; if (scalar(4, (int32_t)le32(aux))) return true; break;
-            case 'I': if (aux + 4 > end) return false; if (scalar(4, le32(aux))) return true; break;
-            case 'f': aux += 4; break;
+            case 'A': if (aux + 1 > end) return; other(); aux += 1; break;
+            case 'c': if (aux + 1 > end) return; integer(1, (int8_t)aux[0]); break;
+            case 'C': if (aux + 1 > end) return; integer(1, aux[0]); break;
+            case 's': if (aux + 2 > end) return; integer(2, (int16_t)le16(aux)); break;
+            case 'S': if (aux + 2 > end) return; integer(2, le16(aux)); break;
+            case 'i': if (aux + 4 > end) return; integer(4, (int32_t)le32(aux)); break;
+            case 'I': if (aux + 4 > end) return; integer(4, le32(aux)); break;
+            case 'f': {
+                if (aux + 4 > end) return;
+                float f;
+                const uint32_t bits = le32(aux);
+                memcpy(&f, &bits, 4);
+                if (is_nh) {
+                    out->has_nh = true;
+                    out->nh_is_one = f == 1.0f;
+                }
+                aux += 4;
+                break;
+            }
             case 'Z':
             case 'H':
+                other();
                 while (aux < end && *aux) ++aux;
                 ++aux;
                 break;
             case 'B': {
-                if (aux + 5 > end) return false;
+                if (aux + 5 > end) return;
                 const unsigned char sub = aux[0];
                 const uint32_t cnt = le32(aux + 1);
                 const size_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                if ((size_t)(end - (aux + 5)) < (size_t)cnt * w) return;
+                other();
+                if (t0 == 'C' && t1 == 'G' && sub == 'I') {
+                    out->cg = aux + 5;
+                    out->cg_ops = cnt;
+                }
                 aux += 5 + (size_t)cnt * w;
                 break;
             }
-            default: return false;  // unknown type: stop scanning
+            default: return;  // unknown type: stop scanning
         }
     }
-    return false;
 }
 
 // protocol: 0 = forward, 1 = reverse (bam.py:108-128).  read_lengths == nullptr: every length.
@@ -355,14 +396,22 @@ inline int split_bam(const char *path, int protocol, const int32_t *read_lengths
         const size_t cigar_at = 32 + (size_t)l_name;
         const size_t aux_at = cigar_at + 4 * (size_t)n_cigar + ((size_t)l_seq + 1) / 2 + l_seq;
         if (aux_at > block) return fail(kFormat, "alignment record fields overrun the record");
-        int64_t nh = 0;
-        const bool has_nh = find_nh(r + aux_at, r + block, &nh);
-        const bool uniq = has_nh ? nh == 1 : mapq == 255;
+        AuxScan aux;
+        scan_aux(r + aux_at, r + block, &aux);
+        const bool uniq = aux.has_nh ? aux.nh_is_one : mapq == 255;
         if (!uniq) { out.multi += 1; continue; }
+        // the CIGAR: in place, or -- behind the <l_seq>S<n>N placeholder of a record with more than
+        // 65 535 operations -- in the CG tag
+        const unsigned char *cigar = r + cigar_at;
+        uint32_t n_ops = n_cigar;
+        if (n_cigar == 2 && aux.cg != nullptr && le32(cigar) == ((l_seq << 4) | 4u) && (le32(cigar + 4) & 15u) == 3u) {
+            cigar = aux.cg;
+            n_ops = aux.cg_ops;
+        }
         // reference positions under M / = / X
         int64_t refpos = pos0, first = -1, last = -1, aligned = 0;
-        for (unsigned k = 0; k < n_cigar; ++k) {
-            const uint32_t c = le32(r + cigar_at + 4 * k);
+        for (uint32_t k = 0; k < n_ops; ++k) {
+            const uint32_t c = le32(cigar + 4 * (size_t)k);
             const uint32_t op = c & 15, len = c >> 4;
             if (op == 0 || op == 7 || op == 8) {  // M = X
                 if (len > 0) {
@@ -375,7 +424,9 @@ inline int split_bam(const char *path, int protocol, const int32_t *read_lengths
                 refpos += len;
             }
         }
-        if (aligned == 0 || ref_id < 0) continue;  // (no aligned base / no reference name: nothing to key)
+        // no aligned base, or no reference name (pysam's reference_name is None for an id outside the
+        // header's list, and bam.py:130 then skips the read), or a negative position: nothing to key
+        if (aligned == 0 || ref_id < 0 || (uint32_t)ref_id >= n_ref || pos0 < 0) continue;
         if (read_lengths) {
             bool wanted = false;
             for (int k = 0; k < n_lengths; ++k) wanted = wanted || read_lengths[k] == aligned;
@@ -393,7 +444,7 @@ inline int split_bam(const char *path, int protocol, const int32_t *read_lengths
             minus = !reverse_map;
             five = reverse_map ? first : last;
         }
-        if (aligned >= 1024 || five + 1 >= (1LL << 32)) continue;  // outside the key's fields (not a Ribo-seq read)
+        if (aligned >= 1024 || five < 0 || five + 1 >= (1LL << 32)) continue;  // outside the key's fields (not a Ribo-seq read)
         if (!length_seen[aligned]) {
             length_seen[aligned] = 1;
             out.length_order.push_back((int32_t)aligned);

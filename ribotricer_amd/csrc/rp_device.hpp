@@ -371,10 +371,13 @@ struct ReplayLds {
     double t[3][65][3];  // [frame][slot][pxx, pxr, pxi]; 65: the frames' rows on different banks
 };
 
+// Returns true (wave-uniform) when a codon past the table took part: the result then stands on
+// x*x where the reference has the host libm's pow() -- RP_FLAG_BIGTIE, resolved on the host.
 template <typename Counts>
-__device__ __forceinline__ void replay_tie_wave(Counts v, long long len, int lane,
+__device__ __forceinline__ bool replay_tie_wave(Counts v, long long len, int lane,
                                              double &phase, int &valid, ReplayLds *lds)
 {
+    bool any_big = false;
     constexpr double kPyySeg = 0x1.5555555555555p-1;
     double sxx = 0.0, sxr = 0.0, sxi = 0.0;  // lane f < 3: the running sums of frame f
     int n = 0;
@@ -411,7 +414,10 @@ __device__ __forceinline__ void replay_tie_wave(Counts v, long long len, int lan
             const unsigned long long mask = __ballot(nz[f]);
             if (nz[f]) {
                 double pxx = t[f].pxx, pxr = t[f].pxr, pxi = t[f].pxi;
-                if (big[f]) replay_codon_compute(w[f], w[f + 1], w[f + 2], pxx, pxr, pxi);
+                if (big[f]) {
+                    replay_codon_compute(w[f], w[f + 1], w[f + 2], pxx, pxr, pxi);
+                    any_big = true;
+                }
                 double *slot = lds->t[f][__builtin_popcountll(mask & below)];
                 slot[0] = pxx;
                 slot[1] = pxr;
@@ -485,6 +491,7 @@ __device__ __forceinline__ void replay_tie_wave(Counts v, long long len, int lan
     }
     phase = __builtin_sqrt(coh);
     valid = val;
+    return __ballot(any_big) != 0;
 }
 #pragma clang fp contract(fast)
 

@@ -276,6 +276,13 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
     "s_cmp_le_u32 %[steps], " #LIM "\n\t"                       \
     "s_cbranch_scc1 1f\n\t"
 
+// Call sites must be wave-uniform with all 64 lanes active: the block overwrites EXEC and leaves
+// it all-ones (stage_tile_chunks is reached through workgroup-uniform branches only).  M0 and EXEC
+// are on the clobber list so that no M0 value (the compiler's own LDS-DMA set-up, merged M0
+// initialisations) and no EXEC-dependent state is carried across the block; clang notes that both
+// are reserved registers, which is the point.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void issue_chunks(const int32_t *base, unsigned w0, unsigned w1, int steps, int lane)
 {
     const int vup = lane * 4, vdelta = (63 - 2 * lane) * 4;  // vup + vdelta = (63 - lane) * 4
@@ -294,8 +301,9 @@ __device__ __forceinline__ void issue_chunks(const int32_t *base, unsigned w0, u
         "s_mov_b64 exec, -1"
         : [so] "=&s"(so), [s1] "=&s"(s1), [st] "=&s"(st), [sd] "=&s"(sd), [vt] "=&v"(vt)
         : [w0] "v"(w0), [w1] "v"(w1), [vdelta] "v"(vdelta), [vup] "v"(vup), [base] "s"(base), [steps] "s"(steps)
-        : "memory", "scc");
+        : "memory", "scc", "m0", "exec");  // every step rewrites M0 and EXEC (EXEC is left all-ones, as it came in)
 }
+#pragma clang diagnostic pop
 #undef RP_DMA_STEP8
 #undef RP_DMA_STEP
 

@@ -1059,8 +1059,8 @@ __global__ __launch_bounds__(kFinishBlock) void k_orf_finish(Source source,
         unsigned flags;
         combine_frames(fr2, phase, valid, flags);
         if (flags & RP_FLAG_TIE) {
-            replay_tie_wave(source.orf(orf_s, beg_s), len_s, lane, phase, valid, &s_replay);
-            flags |= RP_FLAG_REPLAY;
+            const bool big = replay_tie_wave(source.orf(orf_s, beg_s), len_s, lane, phase, valid, &s_replay);
+            flags |= RP_FLAG_REPLAY | (big ? RP_FLAG_BIGTIE : 0u);
         }
         if (lane == 0)
             store_orf(out, fp, orf_s, phase, valid, count_s, min_s, flags | split_s | RP_FLAG_RECHECK64, len_s);
@@ -1136,8 +1136,8 @@ __global__ __launch_bounds__(kLongBlock) void k_rewalk_long(Source source,
         unsigned flags;
         combine_frames(fr, phase, valid, flags);
         if (flags & RP_FLAG_TIE) {
-            replay_tie_wave(source.orf(orf, beg), len, lane, phase, valid, &s_replay);
-            flags |= RP_FLAG_REPLAY;
+            const bool big = replay_tie_wave(source.orf(orf, beg), len, lane, phase, valid, &s_replay);
+            flags |= RP_FLAG_REPLAY | (big ? RP_FLAG_BIGTIE : 0u);
         }
         const unsigned split = (beg + plan.mis) / TILE != (beg + len - 1 + plan.mis) / TILE ? RP_FLAG_SPLIT : 0u;
         if (lane == 0) store_orf(out, fp, orf, phase, valid, count, min_codon, flags | split | RP_FLAG_RECHECK64, len);

@@ -105,8 +105,8 @@ __device__ __forceinline__ void wave_score_orf(const int32_t *__restrict__ v, lo
     combine_frames(fr, phase, valid, flags);
     flags |= extra;
     if (flags & RP_FLAG_TIE) {  // an exact frame tie: the reference's own bits decide (wave-uniform)
-        replay_tie_wave(v, len, lane, phase, valid, replay_lds);
-        flags |= RP_FLAG_REPLAY;
+        const bool big = replay_tie_wave(v, len, lane, phase, valid, replay_lds);
+        flags |= RP_FLAG_REPLAY | (big ? RP_FLAG_BIGTIE : 0u);
     }
 }
 

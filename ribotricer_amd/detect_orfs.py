@@ -177,9 +177,8 @@ def score_profiles(counts, offsets, phase_score_cutoff, min_valid_codons, min_re
                    min_valid_codons_ratio, min_density_over_orf, device=None, devices=None) -> dict:
     """One launch for the whole batch; host numpy arrays back (24 B + 2 B per ORF).  With
     ``devices`` (several GPUs of this node): nt-balanced ORF-index slices, one per GPU, host
-    concat (``engine.score_sharded``)."""
-    import torch
-
+    concat (``engine.score_sharded``).  Exact frame ties carry the reference's bits throughout
+    (``engine.resolve_big_ties`` finishes the few the device cannot)."""
     thresholds = make_filter(
         phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio, min_density_over_orf
     )
@@ -188,9 +187,7 @@ def score_profiles(counts, offsets, phase_score_cutoff, min_valid_codons, min_re
 
         return score_sharded(counts, offsets, devices, thresholds=thresholds)
     eng = get_engine(device if devices is None or not len(devices) else devices[0])
-    res = eng.score(counts, offsets, thresholds=thresholds)
-    torch.cuda.synchronize(eng.device)
-    return res.cpu_numpy()
+    return eng.score_host(counts, offsets, thresholds=thresholds)
 
 
 def format_rows(records, counts, offsets, res, report_all: bool):
@@ -300,7 +297,8 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     import torch
 
     from .alignments import build_coverage_device
-    from .gather import gather_profiles_device, interval_table_from_index, make_gather_plan, select_orfs
+    from .engine import resolve_big_ties
+    from .gather import coverage_profiles_of, gather_profiles_device, interval_table_from_index, make_gather_plan, select_orfs
 
     device = None if not devices else f"cuda:{int(devices[0])}"
     coverage, base = build_coverage_device(merged_alignments, index, device)
@@ -327,6 +325,7 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
         res = eng.score_coverage(coverage, plan, thresholds=thresholds)
         torch.cuda.synchronize(eng.device)
         res = res.cpu_numpy()
+        resolve_big_ties(res, coverage_profiles_of(coverage, table, device), thresholds)
     keep = res["status"] != 0
     chosen = np.flatnonzero(keep)
     d_counts, _ = gather_profiles_device(coverage, select_orfs(table, chosen), device)
@@ -376,22 +375,35 @@ def detect_orfs(bam, ribotricer_index, prefix, protocol, read_lengths, psite_off
     ``export_orf_coverages``.  Same argument order, same output files -- except the two PDF plots
     (plotting is out of scope) and protocol inference: ``protocol`` ('forward' / 'reverse') must be
     given, as ``--stranded`` does on the reference's CLI."""
+    import datetime
     import os
 
     from . import alignments as al
     from . import metagene as mg
 
+    def banner(text: str, dots: str = "...") -> None:  # the stage lines of detect_orfs.py:401-525
+        print("{} {} {}".format(datetime.datetime.now().strftime("%b %d %H:%M:%S"), dots, text))
+
     if protocol not in ("forward", "reverse"):
         sys.exit("Error: ribotricer_amd.detect_orfs needs protocol 'forward' or 'reverse' (protocol inference is not part of this engine)")
+    banner("started ribotricer detect-orfs", ".....")
+    banner("started parsing ribotricer index file")
+    annotated = mg.annotated_records(ribotricer_index)
     parent = os.path.dirname(prefix)
     if parent:
         os.makedirs(parent, exist_ok=True)
-    annotated = mg.annotated_records(ribotricer_index)
+    banner("started reading bam file")
     cols, read_length_counts = al.split_bam(bam, protocol, prefix, read_lengths)
+    banner("started calculating metagene profiles. This may take a long time...")
     metagenes = mg.metagene_coverage(annotated, cols, read_length_counts, prefix, meta_min_reads=meta_min_reads)
     if psite_offsets is None:
+        banner("started inferring P-site offsets")
         psite_offsets = mg.align_metagenes(metagenes, read_length_counts, prefix, phase_score_cutoff, read_lengths is None)
+    banner("started shifting according to P-site offsets")
     merged = al.merge_read_lengths(cols, psite_offsets)
+    banner("started exporting wig file of alignments after shifting")
     export_wig(merged, prefix)
+    banner("started calculating phase scores for each ORF")
     export_orf_coverages(ribotricer_index, merged, prefix, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
                          min_valid_codons_ratio, min_density_over_orf, report_all)
+    banner("finished ribotricer detect-orfs")

@@ -367,6 +367,87 @@ class PhaseScoreEngine:
         return phase, valid, flags
 
 
+    def score_host(self, counts, offsets, thresholds: Optional[FilterParams] = None, algo: str = "auto", plan="auto") -> dict:
+        """:meth:`score`, waited for and brought to the host as a dict of numpy arrays, with the
+        exact frame ties the device could not finish resolved (:func:`resolve_big_ties`): every
+        ``phase`` / ``valid`` then carries the reference's bits wherever a tie is flagged."""
+        res = self.score(counts, offsets, thresholds=thresholds, algo=algo, plan=plan)
+        torch.cuda.synchronize(self.device)
+        host = res.cpu_numpy()
+        resolve_big_ties(host, csr_profiles_of(counts, offsets), thresholds)
+        return host
+
+    def release_stream(self, stream) -> None:
+        """Drop the workspace / reusable outputs kept for ``stream`` (a torch stream that is about to
+        go away: the sharded helpers create one per slice)."""
+        key = int(stream.cuda_stream)
+        self._workspace.pop(key, None)
+        self._out.pop(key, None)
+
+
+def status_host(thresholds: FilterParams, phase, valid, read_count, min_codon_cov, lengths) -> np.ndarray:
+    """The status predicate of detect_orfs.py:281,285-299 on host arrays (the same IEEE divisions
+    and comparisons the device makes) -- for the few ORFs whose phase / valid_codons are patched on
+    the host (:func:`resolve_big_ties`)."""
+    n_codons = np.maximum(1, np.asarray(lengths, np.int64) // 3)
+    ok = (
+        (np.asarray(phase) >= thresholds.phase_score_cutoff)
+        & (np.asarray(valid) >= thresholds.min_valid_codons)
+        & (np.asarray(min_codon_cov).astype(np.float64) >= thresholds.min_reads_per_codon)
+        & (np.asarray(valid) / n_codons >= thresholds.min_valid_codons_ratio)
+        & (np.asarray(read_count) / n_codons >= thresholds.min_density_over_orf)
+    )
+    return ok.astype(np.uint8)
+
+
+def resolve_big_ties(res: dict, profiles_of, thresholds: Optional[FilterParams] = None) -> int:
+    """Finish the exact frame ties the device could not (``RP_FLAG_BIGTIE``: the tie involves a
+    count >= 16, where the reference's ``real**2 + image**2`` -- statistics.py:83 -- goes through
+    the host C library's ``pow``): their profiles are fetched with ``profiles_of(orf_ids) ->
+    (counts, offsets)`` (host CSR), replayed by ``rp_tie_replay_host`` with this host's libm, and
+    ``phase`` / ``valid`` (and ``status``, given ``thresholds``) of ``res`` -- host arrays -- are
+    patched in place.  Returns how many ORFs that was (none on typical data: such an ORF is
+    sparse AND piles >= 16 reads on one codon)."""
+    idx = np.flatnonzero(res["flags"] & _lib.FLAG_BIGTIE)
+    if idx.size == 0:
+        return 0
+    counts, offsets = profiles_of(idx)
+    phase, valid = _lib.tie_replay_host(counts, offsets)
+    res["phase"][idx] = phase
+    res["valid"][idx] = valid
+    if thresholds is not None and res.get("status") is not None:
+        res["status"][idx] = status_host(thresholds, phase, valid, res["read_count"][idx], res["min_codon_cov"][idx], np.diff(offsets))
+    return int(idx.size)
+
+
+def csr_profiles_of(counts, offsets):
+    """``profiles_of`` for :func:`resolve_big_ties` over a CSR batch (host arrays or device tensors)."""
+
+    def fetch(idx):
+        off = offsets.cpu().numpy() if isinstance(offsets, torch.Tensor) else np.asarray(offsets)
+        lens = off[idx + 1] - off[idx]
+        out = np.zeros(idx.size + 1, np.int64)
+        np.cumsum(lens, out=out[1:])
+        parts = [counts[int(off[i]) : int(off[i + 1])] for i in idx]
+        parts = [p.cpu().numpy() if isinstance(p, torch.Tensor) else np.asarray(p) for p in parts]
+        return (np.concatenate(parts).astype(np.int32) if parts and out[-1] else np.zeros(0, np.int32)), out
+
+    return fetch
+
+
+def _wait_for_producers(stream, *inputs) -> None:
+    """Make ``stream`` wait for the work already queued on the current stream of every device that
+    holds one of ``inputs`` (device tensors produced by the caller moments ago): a fresh stream has
+    no ordering with them otherwise."""
+    import torch as _t
+
+    seen = set()
+    for x in inputs:
+        if isinstance(x, _t.Tensor) and x.is_cuda and x.device not in seen:
+            seen.add(x.device)
+            stream.wait_stream(_t.cuda.current_stream(x.device))
+
+
 _engines: dict = {}
 _engines_lock = threading.Lock()
 
@@ -413,6 +494,7 @@ def score_sharded(counts, offsets, devices: Sequence, thresholds: Optional[Filte
         eng = get_engine(dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.Stream(device=dev)
+            _wait_for_producers(stream, counts, offsets)
             with torch.cuda.stream(stream):
                 c = counts[a:b]
                 c = torch.from_numpy(np.ascontiguousarray(c, dtype=np.int32)) if not isinstance(c, torch.Tensor) else c
@@ -421,7 +503,10 @@ def score_sharded(counts, offsets, devices: Sequence, thresholds: Optional[Filte
                 res = eng.score(c, o, thresholds=thresholds, algo=algo, plan=None)
                 host = {k_: (None if v is None else v.cpu()) for k_, v in res._asdict().items()}
             stream.synchronize()
-        return {k_: (None if v is None else v.numpy()) for k_, v in host.items()}
+            eng.release_stream(stream)
+        out = {k_: (None if v is None else v.numpy()) for k_, v in host.items()}
+        resolve_big_ties(out, csr_profiles_of(c, o), thresholds)
+        return out
 
     if len(devs) == 1:
         parts = [work(0)]
@@ -437,7 +522,7 @@ def score_coverage_sharded(coverage, table, devices: Sequence, thresholds: Optio
     every device gets a copy of the dense coverage and the gather plan of ITS slice, results are
     concatenated on the host.  No collective; the profiles exist on no device.  Raises
     ``RibophaseError`` (status ``ERR_INTERVALS``) for a table that cannot be planned."""
-    from .gather import GatherPlan, select_orfs
+    from .gather import GatherPlan, coverage_profiles_of, select_orfs
     from .sharding import concat_results, slice_bounds
 
     devs = [torch.device(d) if not isinstance(d, int) else torch.device("cuda", d) for d in devices]
@@ -453,11 +538,15 @@ def score_coverage_sharded(coverage, table, devices: Sequence, thresholds: Optio
             stream = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(stream):
                 cov = _as_device(coverage, torch.int32, dev)
-                plan = GatherPlan(select_orfs(table, np.arange(lo, hi, dtype=np.int64)), cov.numel(), dev)
+                sub = select_orfs(table, np.arange(lo, hi, dtype=np.int64))
+                plan = GatherPlan(sub, cov.numel(), dev)
                 res = eng.score_coverage(cov, plan, thresholds=thresholds)
                 host = {k_: (None if v is None else v.cpu()) for k_, v in res._asdict().items()}
             stream.synchronize()
-        return {k_: (None if v is None else v.numpy()) for k_, v in host.items()}
+            out = {k_: (None if v is None else v.numpy()) for k_, v in host.items()}
+            resolve_big_ties(out, coverage_profiles_of(cov, sub, dev), thresholds)
+            eng.release_stream(stream)
+        return out
 
     if len(devs) == 1:
         parts = [work(0)]

@@ -276,3 +276,14 @@ def gather_profiles_device(coverage, table: IntervalTable, device=None, plan=Non
         )
     )
     return counts, offsets
+
+
+def coverage_profiles_of(coverage, table: IntervalTable, device=None):
+    """``profiles_of`` for ``engine.resolve_big_ties`` over an interval table: the chosen ORFs'
+    profiles gathered on the device (per-ORF kernel) and copied to the host."""
+
+    def fetch(idx):
+        counts, offsets = gather_profiles_device(coverage, select_orfs(table, idx), device)
+        return counts.cpu().numpy(), offsets.cpu().numpy()
+
+    return fetch

@@ -41,13 +41,23 @@ def phasescore_batch(profiles: Sequence[Sequence[float]], device=None):
         if flat.size and (flat.min() < 0 or flat.max() > _lib.MAX_COUNT):
             integral = False
     if integral:
-        res = eng.score(flat.astype(np.int32), offsets)
-        torch.cuda.synchronize(eng.device)
-        return res.phase.cpu().numpy(), res.valid.cpu().numpy(), res.flags.cpu().numpy()
+        res = eng.score_host(flat.astype(np.int32), offsets)
+        return res["phase"], res["valid"], res["flags"]
     flat = np.concatenate([a.astype(np.float64) for a in arrays]) if offsets[-1] else np.zeros(0)
     phase, valid, flags = eng.score_float_profiles(flat, offsets)
     torch.cuda.synchronize(eng.device)
-    return phase.cpu().numpy(), valid.cpu().numpy(), flags.cpu().numpy()
+    phase, valid, flags = phase.cpu().numpy(), valid.cpu().numpy(), flags.cpu().numpy()
+    # Exact frame ties of float profiles (a few metagene profiles per sample, metagene.py:243-244):
+    # the reference's strict `>` is decided by the last bits of its own float64 arithmetic, libm
+    # pow() included -- replayed on the host for the flagged profiles (rp_tie_replay_f64_host).
+    tied = np.flatnonzero(flags & _lib.FLAG_TIE)
+    if tied.size:
+        sub_off = np.zeros(tied.size + 1, np.int64)
+        np.cumsum(lengths[tied], out=sub_off[1:])
+        sub = np.concatenate([flat[offsets[i] : offsets[i + 1]] for i in tied]) if sub_off[-1] else np.zeros(0)
+        phase[tied], valid[tied] = _lib.tie_replay_host(sub.astype(np.float64), sub_off)
+        flags[tied] |= _lib.FLAG_REPLAY
+    return phase, valid, flags
 
 
 def phasescore(original_values: Sequence[float]) -> tuple[np.float64, int]:

@@ -128,3 +128,90 @@ def synth_csr_device(n_orfs: int, seed: int = 20260213, cfg: str = "cfg2", devic
         del ln, off, lam, framed, orf_id, pos, w, rate, chunk
     offsets = torch.from_numpy(offsets_np[lo_all : hi_all + 1] - base).to(dev)
     return counts, offsets
+
+
+# ------------------------------------------------------------------------------------------------
+# A synthetic candidate-ORF INDEX over a dense coverage array (what detect_orfs.py:134-203 walks:
+# exon intervals per ORF, '-' strand ORFs read backwards), for the fused gather + score path at
+# BASELINE sizes.  Profiles are windows onto ONE coverage array -- the expected profile of an ORF is
+# a host-side gather of its intervals (``profiles_from_coverage``), independent of every kernel.
+# ------------------------------------------------------------------------------------------------
+EXON_P = np.array([0.35, 0.30, 0.20, 0.15])  # 1..4 exons per ORF
+COVERAGE_BLOCK = 2048  # positions that share one Poisson rate / frame weighting
+COVERAGE_CHUNK = 1 << 26  # positions drawn per device generator (part of the data definition)
+
+
+def synth_exon_layout(lengths: np.ndarray, seed: int, max_intron: int = 300, max_spacer: int = 64, reverse_frac: float = 0.5):
+    """ORFs laid one after the other along a coverage array: every ORF is cut into 1-4 exons at
+    random positions, ``[0, max_intron)`` unused positions between its exons, ``[0, max_spacer)``
+    between ORFs, ``reverse_frac`` of them on the '-' strand.  Returns ``(iv_start int64[], iv_len
+    int32[], orf_iv int64[n+1], reverse uint8[n], offsets int64[n+1], coverage_len)`` -- the fields
+    of ``gather.IntervalTable`` plus the coverage length.  Vectorised numpy: ~1 s per million ORFs."""
+    lengths = np.asarray(lengths, np.int64)
+    n = lengths.size
+    rng = np.random.default_rng(seed + 11)
+    k = rng.choice(np.arange(1, 5), size=n, p=EXON_P)
+    # cut points in [1, L-1]: unused columns (and ORFs too short to cut) get the sentinel L
+    cuts = 1 + np.floor(rng.random((n, 3)) * np.maximum(lengths - 1, 1)[:, None]).astype(np.int64)
+    cuts[np.arange(3)[None, :] >= (k - 1)[:, None]] = -1
+    cuts = np.where((cuts < 0) | (lengths[:, None] < 2), lengths[:, None], cuts)
+    cuts.sort(axis=1)
+    edges = np.concatenate([np.zeros((n, 1), np.int64), cuts, lengths[:, None]], axis=1)
+    exon = np.diff(edges, axis=1)  # (n, 4), zeros where cut points coincide / are unused
+    live = exon > 0
+    n_ex = live.sum(axis=1)
+    orf_iv = np.zeros(n + 1, np.int64)
+    np.cumsum(n_ex, out=orf_iv[1:])
+    iv_len = exon[live]  # row-major: exons of ORF 0, then ORF 1, ... in ascending coverage order
+    n_iv = iv_len.size
+    gap = rng.integers(0, max(1, max_intron), size=n_iv)
+    first = np.zeros(n_iv, bool)
+    first[orf_iv[:-1][n_ex > 0]] = True
+    gap[first] = rng.integers(0, max(1, max_spacer), size=int(first.sum()))
+    iv_start = np.cumsum(gap + iv_len) - iv_len  # every interval starts `gap` after the previous one's end
+    reverse = (rng.random(n) < reverse_frac).astype(np.uint8)
+    offsets = offsets_from_lengths(lengths)
+    coverage_len = int(iv_start[-1] + iv_len[-1]) + 16 if n_iv else 16
+    return iv_start.astype(np.int64), iv_len.astype(np.int32), orf_iv, reverse, offsets, coverage_len
+
+
+def synth_coverage_device(coverage_len: int, seed: int, device="cuda"):
+    """Dense int32 coverage drawn on the device: blocks of ``COVERAGE_BLOCK`` positions share a rate
+    from ``LAMBDAS`` (so sparse and dense stretches -- exact frame ties and clear winners -- both
+    occur), half of the blocks carry the (2, .5, .5) position-mod-3 weighting."""
+    import torch
+
+    dev = torch.device(device)
+    n_blocks = (coverage_len + COVERAGE_BLOCK - 1) // COVERAGE_BLOCK
+    rng = np.random.default_rng(seed + 21)
+    lam = torch.from_numpy(rng.choice(LAMBDAS, size=n_blocks, p=LAMBDA_P).astype(np.float32)).to(dev)
+    framed = torch.from_numpy(rng.random(n_blocks) < 0.5).to(dev)
+    cov = torch.empty(coverage_len, dtype=torch.int32, device=dev)
+    for c, lo in enumerate(range(0, coverage_len, COVERAGE_CHUNK)):
+        hi = min(coverage_len, lo + COVERAGE_CHUNK)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed + 23 + 7919 * c)
+        pos = torch.arange(lo, hi, device=dev)
+        blk = pos // COVERAGE_BLOCK
+        w = torch.where(framed[blk], torch.where(pos % 3 == 0, 2.0, 0.5), 1.0)
+        cov[lo:hi] = torch.poisson(lam[blk] * w, generator=gen).to(torch.int32)
+        del pos, blk, w
+    return cov
+
+
+def profiles_from_coverage(cov_window: np.ndarray, window_lo: int, iv_start, iv_len, orf_iv, reverse, lo: int, hi: int):
+    """Host-side gather of ORFs ``lo..hi`` (detect_orfs.py:176-202 on a dense array): the exon
+    intervals in ascending order, the whole profile reversed for a '-' strand ORF.  ``cov_window``
+    holds coverage positions ``window_lo ..``.  Returns CSR ``(counts int32, offsets int64)``."""
+    parts, lens = [], []
+    for i in range(lo, hi):
+        k0, k1 = int(orf_iv[i]), int(orf_iv[i + 1])
+        p = [cov_window[int(iv_start[k]) - window_lo : int(iv_start[k]) - window_lo + int(iv_len[k])] for k in range(k0, k1)]
+        prof = np.concatenate(p) if p else np.zeros(0, np.int32)
+        if reverse[i]:
+            prof = prof[::-1]
+        parts.append(prof)
+        lens.append(prof.size)
+    off = np.zeros(len(lens) + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    return (np.concatenate(parts).astype(np.int32) if parts else np.zeros(0, np.int32)), off

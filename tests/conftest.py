@@ -65,5 +65,15 @@ def g5():
     return load_json("g5_float.json")["vectors"]
 
 
+@pytest.fixture(scope="session")
+def g8():
+    return load_npz("g8_bigties.npz")
+
+
+@pytest.fixture(scope="session")
+def g8f():
+    return load_json("g8_float_ties.json")["vectors"]
+
+
 def split_csr(counts, offsets):
     return [counts[offsets[i] : offsets[i + 1]] for i in range(len(offsets) - 1)]

@@ -21,6 +21,8 @@ Fixture sets:
   g6_*                   end-to-end: index + alignments + the reference's TSVs
   g7_*                   the front end in miniature: per-read-length alignments ->
                          metagene profiles, P-site offsets, merged alignments, WIG, TSV
+  g8_bigties.npz         3200 sparse profiles with counts 16..1000 (some to 3e6) built to tie
+  g8_float_ties.json     400 float-valued profiles built to tie
 """
 
 from __future__ import annotations
@@ -396,7 +398,85 @@ def g7():
     print("g7: reads per length", dict(sorted(read_length_counts.items())), "offsets", dict(psite_offsets))
 
 
+# --------------------------------------------------------------------------- G8
+def g8():
+    """Exact frame ties that involve counts >= 16 (where the reference's `real**2 + image**2`,
+    statistics.py:83, is libm pow() and not x*x), and float-valued profiles with exact ties
+    (metagene.py:243-244): what rp_tie_replay_host / rp_tie_replay_f64_host must reproduce."""
+    rng = np.random.default_rng(808)
+    vecs = []
+    for k in range(3200):
+        length = int(rng.integers(6, 601)) if k % 5 == 0 else 3 * int(rng.integers(20, 201))
+        v = np.zeros(length, np.int64)
+        kind = k % 8
+        big = lambda size=None: rng.integers(16, 1001, size=size)  # noqa: E731
+        if kind == 0:  # a few piles, all on one residue class: score == 1 in two or three frames
+            r = int(rng.integers(0, 3))
+            at = r + 3 * rng.integers(0, max(1, (length - r + 2) // 3), size=int(rng.integers(1, 7)))
+            at = at[at < length]
+            v[at] = big(at.size)
+        elif kind == 1:  # perfectly periodic, one or two residues occupied
+            c = big(3)
+            c[int(rng.integers(0, 3))] = 0
+            if k % 16 == 1:
+                c[int(rng.integers(0, 3))] = 0
+            v[:] = np.tile(c, length // 3 + 1)[:length]
+        elif kind == 2:  # the unit vectors cancel: equal piles on residues 0, 1, 2
+            c = int(big())
+            trip = rng.choice(max(1, length // 3), size=3, replace=length // 3 < 3)
+            for r, j in enumerate(trip):
+                if 3 * int(j) + r < length:
+                    v[3 * int(j) + r] = c
+        elif kind == 3:  # sparse Poisson scaled up: few non-zero codons, large values
+            v[:] = rng.poisson(0.01, size=length) * big(length)
+        elif kind == 4:  # sparse with one residue favoured
+            w = np.array([1.0, 0.05, 0.05])[(np.arange(length) + int(rng.integers(0, 3))) % 3]
+            v[:] = rng.poisson(0.03 * w) * big(length)
+        elif kind == 5:  # two piles (the SURVEY A.4 example shape) with big counts
+            at = rng.integers(0, length, size=2)
+            v[at] = big(2)
+        elif kind == 6:  # very large counts on one residue
+            r = int(rng.integers(0, 3))
+            at = r + 3 * rng.integers(0, max(1, (length - r + 2) // 3), size=int(rng.integers(1, 5)))
+            at = at[at < length]
+            v[at] = rng.integers(1000, 3_000_000, size=at.size)
+        else:  # mixture of small and big piles
+            at = rng.integers(0, length, size=int(rng.integers(1, 6)))
+            v[at] = np.where(rng.random(at.size) < 0.5, big(at.size), rng.integers(1, 4, size=at.size))
+        vecs.append(v.tolist())
+    save_csr_set("g8_bigties.npz", vecs)
+    # float profiles
+    rows, fvecs = [], []
+    for k in range(400):
+        length = 3 * int(rng.integers(4, 80)) + int(rng.integers(0, 3)) * (k % 4 == 0)
+        v = np.zeros(length)
+        kind = k % 4
+        if kind == 0:
+            r = int(rng.integers(0, 3))
+            at = r + 3 * rng.integers(0, max(1, (length - r + 2) // 3), size=int(rng.integers(1, 7)))
+            at = at[at < length]
+            v[at] = np.round(rng.gamma(2.0, 3.0, size=at.size), 3)
+        elif kind == 1:
+            c = np.round(rng.gamma(2.0, 3.0, size=3), 3)
+            c[int(rng.integers(0, 3))] = 0.0
+            v[:] = np.tile(c, length // 3 + 1)[:length]
+        elif kind == 2:
+            v[:] = (rng.random(length) < 0.03) * np.round(rng.gamma(2.0, 0.7, size=length), 4)
+        else:
+            c = float(np.round(rng.gamma(2.0, 3.0), 3))
+            for r, j in enumerate(rng.choice(max(1, length // 3), size=3, replace=length // 3 < 3)):
+                if 3 * int(j) + r < length:
+                    v[3 * int(j) + r] = c
+        fvecs.append(v.tolist())
+    for v in fvecs:
+        p, va = phasescore(v)
+        rows.append({"input": v, "phase": float(p), "valid": int(va)})
+    with open(os.path.join(HERE, "g8_float_ties.json"), "w") as fh:
+        json.dump({"meta": META, "vectors": rows}, fh)
+    print(f"g8_float_ties.json: {len(rows)} vectors")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for name in which:
         globals()[name]()

@@ -51,3 +51,4 @@ def test_bam_reader_is_clean_under_asan_ubsan(tmp_path):
     run = subprocess.run([exe, bam, str(tmp_path / "mut.bam")], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "split rc=0" in run.stdout and "ok mutated:" in run.stdout
+    assert "huge isize rc=2" in run.stdout  # a damaged ISIZE trailer is a format error, not a 3.9 GB allocation

@@ -31,5 +31,20 @@ int main(int argc, char **argv)
         (r2 == 0 ? ok : bad) += 1;
     }
     printf("ok mutated: %d readable, %d rejected\n", ok, bad);
+    // a damaged ISIZE trailer (0xF0000000 claimed for the first block) must be rejected as a format
+    // error, not used to size a 3.9 GB inflate buffer (BGZF blocks hold <= 64 KiB)
+    {
+        std::string t = data;
+        const size_t bsize = (size_t)(unsigned char)t[16] | ((size_t)(unsigned char)t[17] << 8);  // BC subfield of block 0
+        const size_t isize_at = bsize + 1 - 4;
+        t[isize_at] = 0; t[isize_at + 1] = 0; t[isize_at + 2] = 0; t[isize_at + 3] = (char)0xF0;
+        FILE *o = fopen(tmp.c_str(), "wb");
+        fwrite(t.data(), 1, t.size(), o);
+        fclose(o);
+        rpbam::Split s3;
+        const int r3 = rpbam::split_bam(tmp.c_str(), 0, nullptr, 0, s3);
+        printf("huge isize rc=%d\n", r3);
+        if (r3 != rpbam::kFormat) return 2;
+    }
     return 0;
 }
