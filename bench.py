@@ -38,8 +38,11 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-CFG_NAMES = {"cfg2": "BASELINE configs[1]", "cfg3": "BASELINE configs[2]", "cfg5": "BASELINE configs[4]"}
-DEFAULT_ORFS = {"cfg2": 1_000_000, "cfg3": 11_000_000, "cfg5": 20_000_000}
+CFG_NAMES = {"cfg2": "BASELINE configs[1]", "cfg3": "BASELINE configs[2]", "cfg5": "BASELINE configs[4]",
+             "gencode": "GENCODE-like candidate set (67 % of the ORFs 60-150 nt)",
+             "gencode_short": "uORF/dORF-dominated candidate set (77 % of the ORFs 60-150 nt)"}
+DEFAULT_ORFS = {"cfg2": 1_000_000, "cfg3": 11_000_000, "cfg5": 20_000_000, "gencode": 11_000_000, "gencode_short": 11_000_000}
+VERIFY_SLICE = 20_000  # ORFs per slice of the after-the-fact oracle check
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -48,7 +51,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--cfg", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--cfg", default="cfg3", choices=list(CFG_NAMES))
     ap.add_argument("--orfs", type=int, default=0, help="ORFs of the whole set (default: the config's size)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: one set sharded over the GPUs (configs[3]); weak: --orfs ORFs on every GPU")
@@ -56,7 +59,9 @@ def parse_args():
     ap.add_argument("--no-plan", action="store_true", help="rebuild the tile index inside every step")
     ap.add_argument("--cpu-sample", type=int, default=12000, help="ORFs per process for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-cores", type=int, default=0, help="processes for the CPU baseline (default: the usable cores, at most 64)")
-    ap.add_argument("--no-verify", action="store_true", help="skip the concat == whole check at N > 1")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of head / middle / tail slices (N = 1) and the concat == whole check (N > 1)")
+    ap.add_argument("--no-fused", action="store_true", help="skip the fused gather + score section (N = 1)")
+    ap.add_argument("--fused-steps", type=int, default=10)
     ap.add_argument("--seed", type=int, default=20260213)
     return ap.parse_args()
 
@@ -132,6 +137,104 @@ def measured_traffic(cfg, n_orfs, algo, seed):
             if rec["cfg"] == cfg and rec["orfs_per_gpu"] == n_orfs and rec["algo"] == algo and rec["seed"] == seed:
                 return int((2 * rec["fetch_size_kib"] + rec["write_size_kib"]) * 1024), rec.get("source", "profiles/traffic.json")
     return None, None
+
+
+def verify_slices(out, counts, offsets, n_orfs, profiles_of=None):
+    """AFTER the timed region: head / middle / tail slices (and the ORFs around 2^31 / 2^32 nt) of
+    what the steps computed, against the C oracle on the same bytes (oracle/verify.py: integers
+    bit-exact, phase <= 1e-6, exact frame ties bit for bit).  The oracle is the checker here, never
+    the thing measured.  ``profiles_of(lo, hi)``: host CSR of ORFs lo..hi when ``counts`` is not a
+    CSR array (the fused section)."""
+    import numpy as np
+
+    from oracle import verify
+    from ribotricer_amd.engine import csr_profiles_of, resolve_big_ties
+
+    off = offsets.cpu().numpy()
+    n = n_orfs
+    k = min(VERIFY_SLICE, n)
+    ranges = {"head": (0, k), "middle": (max(0, n // 2 - k // 2), min(n, n // 2 - k // 2 + k)), "tail": (n - k, n)}
+    for label, b in (("at_2^31_nt", 1 << 31), ("at_2^32_nt", 1 << 32)):
+        if int(off[-1]) > b:
+            i = int(np.searchsorted(off, b))
+            ranges[label] = (max(0, i - k // 4), min(n, i + k // 4))
+    rep = {"ok": True, "orfs_checked": 0, "max_abs_dphase": 0.0, "ties_bit_exact": 0, "slices": {}}
+    keys = ("phase", "valid", "read_count", "min_codon_cov", "flags", "status")
+    for label, (lo, hi) in ranges.items():
+        part = {kk: getattr(out, kk)[lo:hi].cpu().numpy() for kk in keys}
+        if profiles_of is None:
+            a, b = int(off[lo]), int(off[hi])
+            c_host, o_host = counts[a:b].cpu().numpy(), off[lo : hi + 1] - off[lo]
+        else:
+            c_host, o_host = profiles_of(lo, hi)
+        resolve_big_ties(part, csr_profiles_of(c_host, o_host))
+        try:
+            st = verify.check_slice(part, c_host, o_host)
+        except AssertionError as e:
+            rep["ok"] = False
+            rep["slices"][label] = {"orfs": [lo, hi], "error": str(e)}
+            continue
+        rep["orfs_checked"] += hi - lo
+        rep["max_abs_dphase"] = max(rep["max_abs_dphase"], st["max_abs_dphase"])
+        rep["ties_bit_exact"] += st["ties"]
+        rep["slices"][label] = {"orfs": [lo, hi], "first_nt": int(off[lo]), "max_abs_dphase": st["max_abs_dphase"], "ties": st["ties"]}
+    return rep
+
+
+def fused_section(args, eng, dev, thresholds, n_set, csr_out):
+    """What `export_orf_coverages` runs by default: gather + score FUSED (rp_phase_score_coverage_dev,
+    k_tile_score<true>) over a candidate index of the same length law laid out as exons over a dense
+    coverage array (synth_exon_layout: 1-4 exons per ORF, introns, half of the ORFs on '-')."""
+    import time
+
+    import numpy as np
+    import torch
+
+    from ribotricer_amd.gather import GatherPlan, IntervalTable
+    from ribotricer_amd.synth import orf_lengths, profiles_from_coverage, synth_coverage_device, synth_exon_layout
+
+    lengths = orf_lengths(n_set, args.seed, args.cfg)
+    iv_start, iv_len, orf_iv, reverse, offsets, coverage_len = synth_exon_layout(lengths, args.seed)
+    table = IntervalTable(iv_start, iv_len, orf_iv, reverse, offsets)
+    cov = synth_coverage_device(coverage_len, args.seed, device=dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    gplan = GatherPlan(table, coverage_len, dev)
+    torch.cuda.synchronize(dev)
+    gplan_ms = 1e3 * (time.perf_counter() - t0)
+    for _ in range(3):
+        out = eng.score_coverage(cov, gplan, thresholds=thresholds, reuse_outputs=True)
+    tm: list = []
+    for _ in range(max(3, args.fused_steps)):
+        out = eng.score_coverage(cov, gplan, thresholds=thresholds, reuse_outputs=True, timings=tm)
+    k_main = sum(t[1] for t in tm) / len(tm)
+    k_fin = sum(t[2] for t in tm) / len(tm)
+    k_all = sum(t[3] for t in tm) / len(tm)
+    n = offsets.size - 1
+    total_nt = int(offsets[-1])
+    algo_bytes = 4 * total_nt + 8 * (n + 1) + 24 * n
+    rep = {
+        "workload": f"{n} ORFs / {iv_len.size} exons of the {args.cfg} length law over a dense coverage of {coverage_len} positions "
+                    f"({total_nt} nt of profiles; introns < 300 nt, half of the ORFs on the '-' strand)",
+        "kernel": "rp::k_tile_score<true> (tile staged from the coverage through the gather plan)",
+        "kernel_ms": k_main, "finish_ms": k_fin, "step_device_ms": k_all,
+        "achieved": algo_bytes / (k_main * 1e-3) / 1e9, "frac": algo_bytes / (k_main * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "step_frac": algo_bytes / (k_all * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "value": n / (k_all * 1e-3), "unit": "ORFs/s",
+        "gather_plan_build_ms": gplan_ms,
+        "algorithmic_bytes_per_launch": algo_bytes,
+        "translating": int(out.status.sum()),
+    }
+    if not args.no_verify:
+        def profiles_of(lo, hi):
+            k0, k1 = int(orf_iv[lo]), int(orf_iv[hi])
+            w_lo = int(iv_start[k0:k1].min())
+            w_hi = int((iv_start[k0:k1] + iv_len[k0:k1]).max())
+            return profiles_from_coverage(cov[w_lo:w_hi].cpu().numpy(), w_lo, iv_start, iv_len, orf_iv, reverse, lo, hi)
+
+        rep["verify"] = verify_slices(out, None, gplan.offsets, n, profiles_of)
+    del cov, gplan
+    return rep
 
 
 def main():
@@ -241,6 +344,24 @@ def main():
     k_index = sum(t[0] for t in timings) / len(timings)
     k_main = sum(t[1] for t in timings) / len(timings)
     k_fin = sum(t[2] for t in timings) / len(timings)
+    # A single-sample `detect-orfs` run uses its index ONCE: the plan is then part of the job.
+    # Timed separately (same K-step protocol, fewer steps): the tile index, descriptors and head
+    # rows rebuilt inside every step (rp_phase_score_csr_dev without a plan).
+    single_ms = None
+    if plan is not None:
+        n_single = max(3, min(args.steps, 10))
+        for _ in range(2):
+            eng.score(counts, offsets, thresholds=thresholds, algo="tile", reuse_outputs=True, plan=None)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n_single):
+            eng.score(counts, offsets, thresholds=thresholds, algo="tile", reuse_outputs=True, plan=None)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        single_ms = e0.elapsed_time(e1) / n_single
+        out = step()  # (the outputs checked below come from the planned path the headline times)
+        torch.cuda.synchronize(dev)
     per_rank = {"rank": rank, "orfs": n_orfs, "nt": total_nt, "kernel_ms": k_main, "finish_ms": k_fin,
                 "step_device_ms": dev_ms_per_step}
     ranks = [per_rank]
@@ -286,6 +407,19 @@ def main():
         barrier()
         if rank == 0 and not verify["ok"]:
             print(json.dumps({"error": "sharded results differ from the one-GPU result", "verify": verify}), flush=True)
+            sys.exit(2)
+
+    fused = None
+    if rank == 0 and world == 1:
+        if not args.no_verify and n_orfs > 0:
+            verify = verify_slices(out, counts, offsets, n_orfs)
+            verify["read_count_checksum_ok"] = bool(int(out.read_count.sum()) == int(counts.sum(dtype=torch.int64)))
+            verify["ok"] = verify["ok"] and verify["read_count_checksum_ok"]
+        if not args.no_fused and resolved == "tile" and n_orfs > 0:
+            fused = fused_section(args, eng, dev, thresholds, n_set, out)
+        bad = (verify is not None and not verify["ok"]) or (fused is not None and "verify" in fused and not fused["verify"]["ok"])
+        if bad:
+            print(json.dumps({"error": "results differ from the oracle", "verify": verify, "fused": fused}), flush=True)
             sys.exit(2)
 
     if rank == 0:
@@ -346,8 +480,14 @@ def main():
                 "translating": int(out.status.sum()),
             },
         }
+        if single_ms is not None:
+            result["value_single_sample"] = n_job / (single_ms * 1e-3) if world == 1 else None
+            result["single_sample"] = {"ms_per_step": single_ms, "what": "tile index + segment descriptors + head rows rebuilt inside every step "
+                                       "(an index used for ONE sample); rank 0's slice", "steps": max(3, min(args.steps, 10))}
         if verify is not None:
             result["verify"] = verify
+        if fused is not None:
+            result["fused"] = fused
         if pool is not None:
             per_core = args.cpu_sample
             n_s = min(max(per_core * pool.n, 200_000), n_orfs)

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_version_and_status_strings():
-    assert _lib.version() == "0.2.0"
+    assert _lib.version() == "0.3.0"
     lib = _lib.load()
     assert lib.rp_status_string(0) == b"ok"
     assert lib.rp_status_string(-3) == b"bad CSR offsets"

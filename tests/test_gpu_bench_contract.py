@@ -40,6 +40,12 @@ def test_bench_line_has_the_contract_fields():
     assert d["value"] > 0 and d["ms_per_step"] > 0
     assert "configs[2]" in d["config"]["workload"] and d["config"]["orfs_total"] == 60000
     assert d["roofline"]["kernel"] == "rp::k_tile_score"
+    # after the timed region: head / middle / tail slices against the oracle, the fused section, the single-sample rate
+    v = d["verify"]
+    assert v["ok"] is True and v["orfs_checked"] >= 60000 and v["max_abs_dphase"] <= 1e-6 and v["read_count_checksum_ok"] is True
+    f = d["fused"]
+    assert f["kernel_ms"] > 0 and 0 < f["frac"] < 1 and f["verify"]["ok"] is True and f["verify"]["orfs_checked"] >= 60000
+    assert 0 < d["value_single_sample"] < d["value"] * 1.05
 
 
 def test_two_ranks_shard_one_set_and_concat_equals_whole():

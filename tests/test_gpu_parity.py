@@ -30,11 +30,8 @@ def eng():
 
 
 def run(eng, counts, offsets, algo, thresholds=None):
-    import torch
-
-    res = eng.score(np.asarray(counts, np.int32), np.asarray(offsets, np.int64), thresholds=thresholds, algo=algo)
-    torch.cuda.synchronize()
-    return res.cpu_numpy()
+    """What a caller of the package gets: device scoring + the host step for RP_FLAG_BIGTIE ORFs."""
+    return eng.score_host(np.asarray(counts, np.int32), np.asarray(offsets, np.int64), thresholds=thresholds, algo=algo)
 
 
 def csr_of(vectors):
@@ -71,19 +68,61 @@ def test_reference_fixtures(eng, request, name, algo):
     assert (int(tie.sum()), disagree) == TIE_CENSUS[name], (name, int(tie.sum()), disagree)
 
 
-def test_float_profiles(eng, g5):
+@pytest.mark.parametrize("algo", ALGOS)
+def test_big_count_ties(eng, g8, algo):
+    """G8: exact frame ties whose codons hold counts 16 .. 3e6.  The device replays them with x*x
+    past its host-filled table and says so (RP_FLAG_BIGTIE); the package's host step
+    (engine.resolve_big_ties -> rp_tie_replay_host, this host's libm pow) then gives the reference's
+    bits: EVERY ORF of the set equals the reference's own output, phase bitwise on the ties."""
     import torch
 
-    vecs = [np.asarray(r["input"], np.float64) for r in g5]
-    lens = np.array([len(v) for v in vecs])
-    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    phase, valid, flags = eng.score_float_profiles(np.concatenate(vecs), offsets)
+    raw = eng.score(g8["counts"], g8["offsets"], algo=algo)
     torch.cuda.synchronize()
-    phase, valid, flags = phase.cpu().numpy(), valid.cpu().numpy(), flags.cpu().numpy()
-    for i, r in enumerate(g5):
-        assert abs(phase[i] - r["phase"]) <= 1e-9
-        if not flags[i] & 1:
-            assert valid[i] == r["valid"]
+    raw = raw.cpu_numpy()
+    tie = (raw["flags"] & 1) != 0
+    bigtie = (raw["flags"] & 0x10) != 0
+    assert tie.sum() > 400 and bigtie.sum() > 300 and not (bigtie & ~tie).any()
+    # an ORF without the flag already carries the reference's bits on the device
+    plain = tie & ~bigtie
+    assert np.array_equal(raw["valid"][plain], g8["valid"][plain]) and np.array_equal(raw["phase"][plain], g8["phase"][plain])
+    res = eng.score_host(g8["counts"], g8["offsets"], algo=algo)
+    assert np.array_equal(res["flags"], raw["flags"])
+    assert_matches_fixture(res, g8, PHASE_TOL)
+    assert_matches_oracle(res, g8["counts"], g8["offsets"])
+
+
+def test_big_count_ties_status_follows_the_resolved_values(eng, g8):
+    """The status of a host-resolved ORF is recomputed from the resolved phase / valid_codons."""
+    from ribotricer_amd.engine import make_filter
+
+    th = make_filter(phase_score_cutoff=0.999999, min_valid_codons=1)
+    res = eng.score_host(g8["counts"], g8["offsets"], thresholds=th, algo="tile")
+    lengths = np.diff(g8["offsets"])
+    expect = reference_status(res["phase"], res["valid"], res["read_count"], res["min_codon_cov"], lengths, cutoff=0.999999, min_valid=1)
+    assert np.array_equal(res["status"], expect)
+    expect_ref = reference_status(g8["phase"], g8["valid"], res["read_count"], res["min_codon_cov"], lengths, cutoff=0.999999, min_valid=1)
+    tie = (res["flags"] & 1) != 0
+    assert np.array_equal(res["status"][tie], expect_ref[tie])  # replayed ORFs: the reference's own bits decide
+
+
+@pytest.mark.parametrize("name", ["g5", "g8f"])
+def test_float_profiles(eng, request, name):
+    """Float-valued profiles (metagene.py:243-244 -> statistics.py:48) through the package's
+    phasescore_batch: closed form on the device, exact frame ties replayed on the host with the
+    reference's own float64 operations -- valid_codons equal on EVERY profile, phase bitwise on ties."""
+    from ribotricer_amd.statistics import phasescore_batch
+
+    rows = request.getfixturevalue(name)
+    phase, valid, flags = phasescore_batch([np.asarray(r["input"], np.float64) for r in rows])
+    n_tie = 0
+    for i, r in enumerate(rows):
+        assert abs(phase[i] - r["phase"]) <= 1e-9, i
+        assert valid[i] == r["valid"], i
+        if flags[i] & 1:
+            assert phase[i] == r["phase"], i
+            n_tie += 1
+    if name == "g8f":
+        assert n_tie > 100
 
 
 def test_frame_diagnostics(eng, g2):
