@@ -15,6 +15,7 @@
 #include "../../include/ribophase.h"
 #include "rp_device.hpp"
 #include "rp_tile.hpp"
+#include "rp_ring.hpp"
 #include <new>
 #include "rp_format.hpp"
 #include "rp_index.hpp"
@@ -26,6 +27,9 @@
 namespace {
 
 thread_local char g_err[512] = "";
+#ifndef RP_RING
+#define RP_RING 0  // 1: persistent ring kernel (rp_ring.hpp, measured 30 % slower); 0: one workgroup per tile (k_tile_score) for the CSR scorer, as in rounds 1-2 (A/B)
+#endif
 constexpr long long kAutoWaveNt = 2LL << 20;  // RP_ALGO_AUTO switches to the wave kernel below this
 
 int fail(int code, const char *fmt, ...)
@@ -308,10 +312,18 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     // 2. scoring pass over flat tiles: one record per (ORF, tile) segment
     if (gather != nullptr)
         RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score<true, TILE>), dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
-                                              d_counts, (long long)n_orfs, plan, ws, piece_plan_of(gather)));
-    else
+                                              d_counts, (long long)n_orfs, plan, ws, piece_plan_of(gather), out, fp));
+    else if (RP_RING) {
+        // persistent workgroups with a two-slot LDS ring (rp_ring.hpp): kRingWgsPerCu per CU
+        int cus = 0;
+        RP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        long long grid = (long long)(cus > 0 ? cus : 256) * rp::kRingWgsPerCu;
+        if (grid > plan.n_tiles) grid = plan.n_tiles;
+        RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score_ring<TILE>), dim3((unsigned)grid), dim3(rp::kTileBlock), 0, stream,
+                                              d_counts, (long long)n_orfs, plan, ws, out, fp));
+    } else
         RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score<false, TILE>), dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
-                                              d_counts, (long long)n_orfs, plan, ws, rp::PiecePlan{}));
+                                              d_counts, (long long)n_orfs, plan, ws, rp::PiecePlan{}, out, fp));
     RP_HIP(hipGetLastError());
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));
     // 3. one thread per ORF: add its records, score, filter, store

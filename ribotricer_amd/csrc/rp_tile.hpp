@@ -83,15 +83,24 @@ struct TilePlan {
     int mis;  // (counts address / 4) % 4: tiles live on the 16-byte aligned grid
 };
 
-// One record per (ORF, tile) segment: the sums over the triplets of the ORF that the tile
-// owns.  Indexed by  orf + tile : an ORF spanning tiles s..e owns the ids orf+s .. orf+e, and
-// the next ORF starts in a tile >= e, so ids never collide.  48 bytes as three 16-byte words
-// in three planes (rec[k * n_rec + id]): writers (a wave per plane, a thread per segment) and
-// readers (a thread per ORF) then touch consecutive words with consecutive threads.
-//   plane 0  p[0] p[1] p[2] q[0]          fp32: the float64 sum of <= 11 fp32 row records, rounded once
-//   plane 1  q[1] q[2] count.lo count.hi
-//   plane 2  n0|n1<<16  n2|m0<<16  m1|m2<<16  min_codon     (a tile owns < 2^16 triplets)
+// One record per (ORF, tile) segment OF AN ORF THAT SPANS TILES: the sums over the triplets of
+// the ORF that the tile owns.  (An ORF that lies inside one tile -- nearly all of them -- is
+// finished by the scoring kernel itself and leaves no record, see record_stage.)  Indexed by
+// orf + tile : an ORF spanning tiles s..e owns the ids orf+s .. orf+e, and the next ORF starts
+// in a tile >= e, so ids never collide.  48 bytes as three 16-byte words in three planes
+// (rec[f * n_rec + id]), one per reading frame -- wave f of the scoring kernel sums, scores and
+// writes frame f:
+//   plane f  p[f]  q[f]  n_f | m_f << 16  extra_f     p, q fp32: the float64 sum of <= 11 fp32 row
+//            records, rounded once; extra_0 = count.lo, extra_1 = count.hi, extra_2 = min_codon
+//            (a tile owns < 2^16 triplets)
 constexpr size_t kRecordBytes = 48;
+// flags[i] of an ORF the scoring kernel has seen whole but could not settle (fp32 frame decision
+// or cutoff comparison too close to call): k_orf_finish re-walks it in float64 and overwrites the
+// flag.  Never visible to the caller.
+constexpr unsigned kFlagPending = 0x80u;
+#ifndef RP_INKERNEL_FINISH
+#define RP_INKERNEL_FINISH 0  // 1: whole ORFs finished by the scoring kernel (measured slower); 0: every segment leaves a record and k_orf_finish finishes every ORF (round 2's flow; A/B)
+#endif
 
 // One descriptor per segment id, derived from the offsets alone (k_tile_desc): where the
 // segment's triplets lie inside its tile's LDS image and how many lanes walk them.
@@ -101,6 +110,7 @@ constexpr size_t kRecordBytes = 48;
 //   bits 38-50  tail     LDS index of an owned partial last codon (L % 3 != 0) ...
 //   bits 51-52  part     ... and its length (0 = none)
 //   bits 53-60  lanes    ceil(ntrip / kRun)
+//   bit  62     whole    the segment is the whole ORF (it starts and ends inside this tile)
 //   bit  63     live     0 = this id is a gap (no segment: empty ORF, or an unused id)
 typedef unsigned long long seg_desc_t;
 static_assert(kTile + kHalo < 8192 && kTile / 3 < 4096 && (kTile / 3 + kRun - 1) / kRun < 256, "descriptor field widths");
@@ -277,8 +287,9 @@ __global__ void k_tile_desc(const int64_t *__restrict__ offsets, long long n_orf
             }
         }
         const int lanes = (ntrip + kRun - 1) / kRun;
+        const seg_desc_t whole = (RP_INKERNEL_FINISH && b_first == b_last) ? 1ull : 0ull;
         const seg_desc_t d = (seg_desc_t)qfirst | ((seg_desc_t)endq << 13) | ((seg_desc_t)ntrip << 26) |
-                             ((seg_desc_t)tail << 38) | ((seg_desc_t)part << 51) | ((seg_desc_t)lanes << 53) | (1ull << 63);
+                             ((seg_desc_t)tail << 38) | ((seg_desc_t)part << 51) | ((seg_desc_t)lanes << 53) | (whole << 62) | (1ull << 63);
         desc[orf + b] = d;
         const long long slot = orf - (tile_first[b] - 1);  // slot 0 = the ORF straddling in from the left
         if (slot >= 0 && slot < kHeadSlots) head[b * kHeadRow + 2 + slot] = d;
@@ -687,59 +698,100 @@ __device__ __forceinline__ void tile_pass(const int *__restrict__ s_counts, SegI
     }
 }
 
-// Record stage: row records + integer sums -> ONE record per live segment.  The three words
-// of a record live in three planes (rec[k * n_rec + id]); wave k < 3 writes plane k for all
-// 64 slots (thread = slot), so the three short dependency chains run side by side on three
-// SIMDs and every store instruction covers consecutive 16-byte words.
+// what the record stage keeps per slot: bit 0 live, bit 1 whole ORF, bits 2.. its length (endq - qfirst, unclamped then)
+__device__ __forceinline__ int live_word(seg_desc_t d)
+{
+    const int live = (int)(d >> 63), whole = (int)(d >> 62) & 1;
+    const int len = (((int)(d >> 13)) & 0x1fff) - ((int)d & 0x1fff);
+    return live | (whole << 1) | (whole ? len << 2 : 0);
+}
+
+// Record stage, after the lane runs of a round: row records + integer sums -> per segment, either
+//   * the finished ORF, when the segment IS the whole ORF (it starts and ends in this tile): frame
+//     scores -> state machine -> filters -> the six outputs, straight from here -- no record, no
+//     round trip through k_orf_finish (which, at 11 M ORFs, spent 0.16 ms reading 48-byte records
+//     back and the scoring kernel 0.1 ms writing them); an ORF whose fp32 frame decision or cutoff
+//     comparison is too close to call only gets flags = kFlagPending and is re-walked in float64
+//     by k_orf_finish, as before;
+//   * or ONE 48-byte record (an ORF that spans tiles), summed up by k_orf_finish.
+// Wave f < 3 takes reading frame f for all 64 slots (thread = slot): sums the row records of
+// (P_f, Q_f) in float64, and either writes plane f of the record or scores the frame
+// (frame_score, the float64 chain of the stage) -- three short chains side by side on three SIMDs;
+// after one more barrier wave 0 combines the three scores of every whole ORF.  The arithmetic is
+// operation for operation what k_orf_finish does with a single record (P, Q rounded to fp32 once,
+// then float64), so both routes give the same bits.
 __device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, const SegInts *__restrict__ s_ints,
                                              const RunRec *__restrict__ s_rec, const int *__restrict__ s_vlstart,
                                              const int *__restrict__ s_tail, const int *__restrict__ s_live,
-                                             uint4 *__restrict__ rec, long long n_rec, long long id0, int wave, int seg)
+                                             double (*__restrict__ s_score)[kSegChunk], uint4 *__restrict__ rec, long long n_rec,
+                                             long long id0, long long orf0, int wave, int seg, const OrfOutputs &out,
+                                             const FilterParams &fp)
 {
-    if (wave >= 3 || !s_live[seg]) return;
+    const int live = s_live[seg];  // bit 0: the slot holds a segment; bit 1: it is a whole ORF, whose length sits in bits 2..
+    const bool whole = (live & 2) != 0;
     const int vs = s_vlstart[seg];
     const int ve = s_vlstart[seg + 1];
-    const int w_first = vs >> 4;
-    const int w_last = ve > vs ? (ve - 1) >> 4 : w_first - 1;
     const int tail = s_tail[seg];
-    unsigned codon = 0;
-    if (tail >= 0 && wave > 0) {
-        codon = (unsigned)s_counts[tail & 0xffff];
-        if ((tail >> 16) == 2) codon += (unsigned)s_counts[(tail & 0xffff) + 1];
-    }
-    uint4 out;
-    if (wave == 0) {  // p[0] p[1] p[2] q[0]
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        for (int w = w_first; w <= w_last; ++w) {
-            const RunRec &r = s_rec[seg + w];
-            a0 += (double)r.p[0];
-            a1 += (double)r.p[1];
-            a2 += (double)r.p[2];
-            a3 += (double)r.q[0];
+    unsigned long long count = 0;
+    unsigned min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
+    if (live != 0 && (wave < 3)) {
+        unsigned codon = 0;
+        if (tail >= 0) {
+            codon = (unsigned)s_counts[tail & 0xffff];
+            if ((tail >> 16) == 2) codon += (unsigned)s_counts[(tail & 0xffff) + 1];
         }
-        out = make_uint4(__float_as_uint((float)a0), __float_as_uint((float)a1), __float_as_uint((float)a2), __float_as_uint((float)a3));
-    } else if (wave == 1) {  // q[1] q[2] count
+        if (ve > vs) {
+            count = s_ints[seg].count;
+            min_codon = s_ints[seg].min_codon;
+        }
+        if (tail >= 0) {
+            count += codon;
+            min_codon = min(min_codon, codon);
+        }
+        const int w_first = vs >> 4;
+        const int w_last = ve > vs ? (ve - 1) >> 4 : w_first - 1;
         double a0 = 0.0, a1 = 0.0;
         for (int w = w_first; w <= w_last; ++w) {
             const RunRec &r = s_rec[seg + w];
-            a0 += (double)r.q[1];
-            a1 += (double)r.q[2];
+            a0 += (double)(wave == 0 ? r.p[0] : wave == 1 ? r.p[1] : r.p[2]);
+            a1 += (double)(wave == 0 ? r.q[0] : wave == 1 ? r.q[1] : r.q[2]);
         }
-        unsigned long long count = ve > vs ? s_ints[seg].count : 0ull;
-        if (tail >= 0) count += codon;
-        out = make_uint4(__float_as_uint((float)a0), __float_as_uint((float)a1), (unsigned)count, (unsigned)(count >> 32));
-    } else {  // n0 n1 n2 m0 m1 m2 (16-bit fields: nn = n0 | n1 << 16 | n2 << 32, mm likewise), min
-        unsigned long long nn = 0, mm = 0;
-        unsigned min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
+        const float pf = (float)a0, qf = (float)a1;
+        unsigned n = 0, m = 0;
         if (ve > vs) {
-            nn = s_ints[seg].nn;
-            mm = s_ints[seg].mm;
-            min_codon = s_ints[seg].min_codon;
+            n = (unsigned)(s_ints[seg].nn >> (16 * wave)) & 0xffffu;
+            m = (unsigned)(s_ints[seg].mm >> (16 * wave)) & 0xffffu;
         }
-        if (tail >= 0) min_codon = min(min_codon, codon);
-        out = make_uint4((unsigned)nn, (unsigned)(nn >> 32) | ((unsigned)mm << 16), (unsigned)(mm >> 16), min_codon);
+        if (!whole) {
+            const unsigned extra = wave == 0 ? (unsigned)count : wave == 1 ? (unsigned)(count >> 32) : min_codon;
+            rec[wave * n_rec + id0 + seg] = make_uint4(__float_as_uint(pf), __float_as_uint(qf), n | (m << 16), extra);
+        } else {
+            s_score[wave][seg] = frame_score((double)pf, (double)qf, (int)n, (int)m).score;
+        }
     }
-    rec[wave * n_rec + id0 + seg] = out;
+#if RP_INKERNEL_FINISH
+    __syncthreads();  // barrier 3: the three frames' scores are in LDS
+    if (wave == 0 && whole) {
+        FrameScore fr[3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            fr[f].score = s_score[f][seg];
+            fr[f].n = ve > vs ? (int)((s_ints[seg].nn >> (16 * f)) & 0xffffu) : 0;
+            fr[f].m = ve > vs ? (int)((s_ints[seg].mm >> (16 * f)) & 0xffffu) : 0;
+        }
+        double phase;
+        int valid;
+        unsigned flags;
+        combine_frames(fr, phase, valid, flags);
+        const long long orf = orf0 + seg;
+        if (fp32_decision_unsafe(fr, /*tile_sums=*/true) || near_cutoff(fp, phase)) {
+            out.flags[orf] = (uint8_t)kFlagPending;
+        } else {
+            const long long length = live >> 2;
+            store_orf(out, fp, orf, phase, valid, (long long)count, (int)min_codon, flags, length);
+        }
+    }
+#endif
 }
 
 // One round of the short-ORF path: the 64 segments whose descriptors the lanes hold (`dc`), walked
@@ -790,7 +842,7 @@ __device__ __forceinline__ void short_round(seg_desc_t dc, const int *s_counts, 
         s_vlstart[lane] = vs_i;
         if (lane == kWave - 1) s_vlstart[kSegChunk] = incl;
         s_tail[lane] = part ? (((int)(dc >> 38) & 0x1fff) | (part << 16)) : -1;
-        s_live[lane] = (int)(dc >> 63);
+        s_live[lane] = live_word(dc);
     }
     __syncthreads();  // tables and cleared accumulators are in place
     if (pass) tile_pass<KRUN>(s_counts, s_ints, s_rec, q0, lim, active, seg, vl);
@@ -802,7 +854,8 @@ __device__ __forceinline__ void short_round(seg_desc_t dc, const int *s_counts, 
 template <bool FUSED, int TILE>
 __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const int32_t *__restrict__ counts,
                                                            long long n_orfs, TilePlan plan,
-                                                           TileWorkspace ws, PiecePlan pp)
+                                                           TileWorkspace ws, PiecePlan pp, OrfOutputs out,
+                                                           FilterParams fp)
 {
     __shared__ __attribute__((aligned(16))) int s_counts[lds_counts<TILE>()];
     __shared__ int s_live[kSegChunk];     // the slot holds a segment of this tile
@@ -811,6 +864,7 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
     __shared__ int s_owner[kTileBlock];   // short-ORF path: 64 private words per wave for the segment marks
     __shared__ RunRec s_rec[kMaxRecs];
     __shared__ SegInts s_ints[kSegChunk];
+    __shared__ double s_score[3][kSegChunk];  // the frame scores of the round's whole ORFs (record_stage)
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -904,7 +958,7 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
             s_vlstart[lane] = vs_i;
             if (lane == kWave - 1) s_vlstart[kSegChunk] = incl;
             s_tail[lane] = part ? (((int)(d >> 38) & 0x1fff) | (part << 16)) : -1;
-            s_live[lane] = (int)(d >> 63);
+            s_live[lane] = live_word(d);
         }
         RP_STAMP();  // 3: mapped, arrived at barrier 1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is tracked by vmcnt only
@@ -914,7 +968,7 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
         RP_STAMP();  // 5: this wave's lane runs done
         __syncthreads();
         RP_STAMP();  // 6: all lane runs done (barrier 2)
-        record_stage(s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, ws.rec, ws.n_rec, a0 - 1 + b, wave, lane);
+        record_stage(s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, s_score, ws.rec, ws.n_rec, a0 - 1 + b, a0 - 1, wave, lane, out, fp);
         RP_STAMP();  // 7: records stored
         RP_STAMP_FLUSH();
         return;
@@ -961,7 +1015,7 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
 #ifdef RP_STAMPS
         if (n_stamp_ < 7) RP_STAMP();  // short path: 2, 4, 6 = after barrier 2 of rounds 0, 1, 2
 #endif
-        record_stage(s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, ws.rec, ws.n_rec, a0 - 1 + c0 + b, wave, lane);
+        record_stage(s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, s_score, ws.rec, ws.n_rec, a0 - 1 + c0 + b, a0 - 1 + c0, wave, lane, out, fp);
 #ifdef RP_STAMPS
         if (n_stamp_ < 7) RP_STAMP();  // short path: 3, 5, 7 = records of rounds 0, 1, 2 stored
 #endif
@@ -992,43 +1046,57 @@ __global__ __launch_bounds__(kFinishBlock) void k_orf_finish(Source source,
     int min_codon = RP_MIN_CODON_COV_EMPTY;
     unsigned split = 0;
     bool unsafe = false;
+    bool walked = false;  // no record was read: read count and minimum codon come from the re-walk
     if (orf < n_orfs) {
         beg = offsets[orf];
         len = (long long)offsets[orf + 1] - beg;
         double p[3] = {0, 0, 0}, q[3] = {0, 0, 0};
         int n[3] = {0, 0, 0}, m[3] = {0, 0, 0};
+        bool settled = false;  // the scoring kernel has stored this ORF's outputs already
         if (len > 0) {
             const long long b_first = (beg + plan.mis) / TILE;
             const long long b_last = (beg + len - 1 + plan.mis) / TILE;
-            for (long long b = b_first; b <= b_last; ++b) {  // tile order: deterministic sums
-                const uint4 w0 = ws.rec[orf + b], w1 = ws.rec[ws.n_rec + orf + b], w2 = ws.rec[2 * ws.n_rec + orf + b];
-                p[0] += (double)__uint_as_float(w0.x);
-                p[1] += (double)__uint_as_float(w0.y);
-                p[2] += (double)__uint_as_float(w0.z);
-                q[0] += (double)__uint_as_float(w0.w);
-                q[1] += (double)__uint_as_float(w1.x);
-                q[2] += (double)__uint_as_float(w1.y);
-                count += (long long)(((unsigned long long)w1.w << 32) | w1.z);
-                n[0] += (int)(w2.x & 0xffffu);
-                n[1] += (int)(w2.x >> 16);
-                n[2] += (int)(w2.y & 0xffffu);
-                m[0] += (int)(w2.y >> 16);
-                m[1] += (int)(w2.z & 0xffffu);
-                m[2] += (int)(w2.z >> 16);
-                min_codon = min(min_codon, (int)w2.w);
+            if (RP_INKERNEL_FINISH && b_first == b_last) {
+                // an ORF inside one tile: finished by k_tile_score, unless too close to call there
+                // (then nothing but the pending mark exists: the re-walk below supplies everything)
+                walked = true;
+                if (out.flags[orf] == (uint8_t)kFlagPending)
+                    unsafe = true;
+                else
+                    settled = true;
+            } else {
+                for (long long b = b_first; b <= b_last; ++b) {  // tile order: deterministic sums
+                    const uint4 w0 = ws.rec[orf + b], w1 = ws.rec[ws.n_rec + orf + b], w2 = ws.rec[2 * ws.n_rec + orf + b];
+                    p[0] += (double)__uint_as_float(w0.x);
+                    q[0] += (double)__uint_as_float(w0.y);
+                    p[1] += (double)__uint_as_float(w1.x);
+                    q[1] += (double)__uint_as_float(w1.y);
+                    p[2] += (double)__uint_as_float(w2.x);
+                    q[2] += (double)__uint_as_float(w2.y);
+                    n[0] += (int)(w0.z & 0xffffu);
+                    m[0] += (int)(w0.z >> 16);
+                    n[1] += (int)(w1.z & 0xffffu);
+                    m[1] += (int)(w1.z >> 16);
+                    n[2] += (int)(w2.z & 0xffffu);
+                    m[2] += (int)(w2.z >> 16);
+                    count += (long long)(((unsigned long long)w1.w << 32) | w0.w);
+                    min_codon = min(min_codon, (int)w2.w);
+                }
+                if (b_last > b_first) split = RP_FLAG_SPLIT;
             }
-            if (b_last > b_first) split = RP_FLAG_SPLIT;
         }
-        FrameScore fr[3];
+        if (!settled && !unsafe) {
+            FrameScore fr[3];
 #pragma unroll
-        for (int f = 0; f < 3; ++f) fr[f] = frame_score(p[f], q[f], n[f], m[f]);
-        double phase;
-        int valid;
-        unsigned flags;
-        combine_frames(fr, phase, valid, flags);
-        // re-walk in float64 when the frame decision OR the cutoff comparison is too close to call
-        unsafe = fp32_decision_unsafe(fr, /*tile_sums=*/true) || near_cutoff(fp, phase);
-        if (!unsafe) store_orf(out, fp, orf, phase, valid, count, min_codon, flags | split, len);
+            for (int f = 0; f < 3; ++f) fr[f] = frame_score(p[f], q[f], n[f], m[f]);
+            double phase;
+            int valid;
+            unsigned flags;
+            combine_frames(fr, phase, valid, flags);
+            // re-walk in float64 when the frame decision OR the cutoff comparison is too close to call
+            unsafe = fp32_decision_unsafe(fr, /*tile_sums=*/true) || near_cutoff(fp, phase);
+            if (!unsafe) store_orf(out, fp, orf, phase, valid, count, min_codon, flags | split, len);
+        }
     }
 
     // The too-close-to-call ORFs of this wave (~0.4 %), one after the other, by the whole wave:
@@ -1041,15 +1109,20 @@ __global__ __launch_bounds__(kFinishBlock) void k_orf_finish(Source source,
         const long long orf_s = readlane64(orf, l);
         const long long beg_s = readlane64(beg, l);
         const long long len_s = readlane64(len, l);
-        const long long count_s = readlane64(count, l);
-        const int min_s = __builtin_amdgcn_readlane(min_codon, l);
+        long long count_s = readlane64(count, l);
+        int min_s = __builtin_amdgcn_readlane(min_codon, l);
         const unsigned split_s = (unsigned)__builtin_amdgcn_readlane((int)split, l);
+        const bool walked_s = __builtin_amdgcn_readlane((int)walked, l) != 0;
         if (len_s > kLongWalk) {  // a whole workgroup takes it (k_rewalk_long)
             if (lane == 0) ws.long_list[atomicAdd(ws.long_count, 1)] = orf_s;
             continue;
         }
         WalkResult<double> w;
         wave_walk<double>(source.orf(orf_s, beg_s), len_s, lane, w);
+        if (walked_s) {  // (wave-uniform) an ORF the scoring kernel left pending: the walk's own integer sums
+            count_s = wave_sum(w.count);
+            min_s = wave_min(w.min_codon);
+        }
         FrameScore fr2[3];
 #pragma unroll
         for (int f = 0; f < 3; ++f)

@@ -519,11 +519,14 @@ def score_sharded(counts, offsets, devices: Sequence, thresholds: Optional[Filte
 def score_coverage_sharded(coverage, table, devices: Sequence, thresholds: Optional[FilterParams] = None) -> dict:
     """The fused gather + score (:meth:`PhaseScoreEngine.score_coverage`) on several GPUs of this
     node: ``table`` (``gather.IntervalTable``) is cut into nt-balanced contiguous ORF-index slices,
-    every device gets a copy of the dense coverage and the gather plan of ITS slice, results are
-    concatenated on the host.  No collective; the profiles exist on no device.  Raises
-    ``RibophaseError`` (status ``ERR_INTERVALS``) for a table that cannot be planned."""
-    from .gather import GatherPlan, coverage_profiles_of, select_orfs
-    from .sharding import concat_results, slice_bounds
+    every device gets the WINDOWS of the dense coverage that its slice's exons touch
+    (``sharding.coverage_windows``: on a human-sized index an eighth of the 25 GB array per GPU of
+    eight, not a full copy each) and the gather plan of its slice re-based onto them; the uploads of
+    the devices run side by side (one thread and one stream per device), results are concatenated on
+    the host.  No collective; the profiles exist on no device.  Raises ``RibophaseError`` (status
+    ``ERR_INTERVALS``) for a table that cannot be planned."""
+    from .gather import GatherPlan, IntervalTable, coverage_profiles_of, select_orfs
+    from .sharding import compact_coverage, concat_results, coverage_windows, remap_to_windows, slice_bounds
 
     devs = [torch.device(d) if not isinstance(d, int) else torch.device("cuda", d) for d in devices]
     if not devs:
@@ -536,9 +539,15 @@ def score_coverage_sharded(coverage, table, devices: Sequence, thresholds: Optio
         eng = get_engine(dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.Stream(device=dev)
+            _wait_for_producers(stream, coverage)
             with torch.cuda.stream(stream):
-                cov = _as_device(coverage, torch.int32, dev)
                 sub = select_orfs(table, np.arange(lo, hi, dtype=np.int64))
+                if len(devs) > 1:  # only what this slice reads crosses to the device
+                    w_start, w_len, w_base, w_total = coverage_windows(sub.iv_start, sub.iv_len)
+                    cov = compact_coverage(coverage, w_start, w_len, w_base, max(w_total, 16), dev)
+                    sub = IntervalTable(remap_to_windows(sub.iv_start, w_start, w_base), sub.iv_len, sub.orf_iv, sub.reverse, sub.offsets)
+                else:
+                    cov = _as_device(coverage, torch.int32, dev)
                 plan = GatherPlan(sub, cov.numel(), dev)
                 res = eng.score_coverage(cov, plan, thresholds=thresholds)
                 host = {k_: (None if v is None else v.cpu()) for k_, v in res._asdict().items()}

@@ -58,3 +58,66 @@ def gather_results(local: dict, group=None) -> dict:
     parts = [None] * world
     dist.all_gather_object(parts, {k: v for k, v in local.items() if v is not None}, group=group)
     return concat_results(parts)
+
+
+def coverage_windows(iv_start: np.ndarray, iv_len: np.ndarray, gap: int = 1 << 20):
+    """The part of the dense coverage a set of exon intervals touches, as a few WINDOWS.
+
+    A slice of the candidate-ORF index reads only the coverage under its own intervals -- on a
+    human-sized index one eighth of 25 GB, in two stretches (the slice's transcripts on the '+'
+    and on the '-' arrays) -- so a device that scores the slice needs those windows, not the whole
+    array.  Intervals are merged into windows wherever they lie closer than ``gap`` positions.
+
+    Returns ``(win_start int64[w], win_len int64[w], win_base int64[w], total)``: window k covers
+    coverage ``[win_start[k], win_start[k] + win_len[k])`` and sits at ``win_base[k]`` of the
+    compacted array of ``total`` positions (windows in ascending order, 16-position aligned so
+    that 16-byte aligned staging stays aligned).
+    """
+    iv_start = np.asarray(iv_start, np.int64)
+    iv_len = np.asarray(iv_len, np.int64)
+    if iv_start.size == 0:
+        z = np.zeros(0, np.int64)
+        return z, z, z, 0
+    order = np.argsort(iv_start, kind="stable")
+    s = iv_start[order]
+    e = s + iv_len[order]
+    reach = np.maximum.accumulate(e)
+    new = np.ones(s.size, bool)
+    new[1:] = s[1:] > reach[:-1] + gap
+    first = np.flatnonzero(new)
+    win_start = (s[first] // 16) * 16
+    last_reach = np.concatenate([reach[first[1:] - 1], reach[-1:]])
+    win_len = ((last_reach - win_start + 15) // 16) * 16
+    win_base = np.zeros(first.size, np.int64)
+    np.cumsum(win_len[:-1], out=win_base[1:])
+    return win_start, win_len, win_base, int(win_len.sum())
+
+
+def remap_to_windows(iv_start: np.ndarray, win_start: np.ndarray, win_base: np.ndarray) -> np.ndarray:
+    """Interval starts in the compacted coverage of :func:`coverage_windows`."""
+    iv_start = np.asarray(iv_start, np.int64)
+    if iv_start.size == 0:
+        return iv_start.copy()
+    k = np.searchsorted(win_start, iv_start, side="right") - 1
+    return iv_start - win_start[k] + win_base[k]
+
+
+def compact_coverage(coverage, win_start, win_len, win_base, total: int, device=None):
+    """The compacted coverage of a slice on ``device``: window k of ``coverage`` (a host array or a
+    tensor on any device) copied to ``[win_base[k], win_base[k] + win_len[k])``; reads past the end
+    of ``coverage`` (the 16-position rounding of the last window) stay 0."""
+    import torch
+
+    is_tensor = isinstance(coverage, torch.Tensor)
+    n = coverage.numel() if is_tensor else int(np.asarray(coverage).size)
+    dev = torch.device(device) if device is not None else (coverage.device if is_tensor else torch.device("cpu"))
+    out = torch.zeros(total, dtype=torch.int32, device=dev)
+    for a, ln, at in zip(win_start.tolist(), win_len.tolist(), win_base.tolist()):
+        b = min(a + ln, n)
+        if b <= a:
+            continue
+        part = coverage[a:b]
+        if not is_tensor:
+            part = torch.from_numpy(np.ascontiguousarray(part, dtype=np.int32))
+        out[at : at + (b - a)].copy_(part, non_blocking=True)
+    return out

@@ -74,3 +74,47 @@ def test_two_rank_gloo_gather():
     ok = mp.get_context("spawn").Value("i", 0)
     mp.spawn(_worker, args=(world, 29531 + os.getpid() % 200, ok), nprocs=world, join=True)
     assert ok.value == 1
+
+
+def test_coverage_windows_carry_exactly_what_a_slice_reads():
+    """score_coverage_sharded uploads, per device, only the coverage under ITS slice's exons
+    (sharding.coverage_windows); the re-based interval table must read the same counts out of the
+    compacted array as the original table reads out of the whole one -- for every slice of a
+    two-strand, gapped layout, including '-' strand ORFs (read backwards) and windows clipped at the
+    end of the array."""
+    from ribotricer_amd.sharding import compact_coverage, coverage_windows, remap_to_windows
+    from ribotricer_amd.synth import orf_lengths, profiles_from_coverage, synth_exon_layout
+
+    lengths = orf_lengths(6000, 5, "cfg3")
+    iv_start, iv_len, orf_iv, reverse, offsets, cov_len = synth_exon_layout(lengths, 5, max_intron=5000, max_spacer=3000)
+    # a second "strand": the '-' ORFs live in a copy of the layout far away (as (strand, chrom) groups do)
+    far = cov_len + (7 << 20)
+    minus_iv = np.repeat(reverse.astype(bool), np.diff(orf_iv))
+    iv_start = np.where(minus_iv, iv_start + far, iv_start)
+    total_cov = int((iv_start + iv_len).max())  # the array ends right behind the last interval: last window is clipped
+    rng = np.random.default_rng(1)
+    cov = rng.integers(0, 50, total_cov).astype(np.int32)
+    for world in (1, 2, 8):
+        b = slice_bounds(offsets, world)
+        uploaded = 0
+        for r in range(world):
+            lo, hi = int(b[r]), int(b[r + 1])
+            k0, k1 = int(orf_iv[lo]), int(orf_iv[hi])
+            s, ln = iv_start[k0:k1], iv_len[k0:k1]
+            w_start, w_len, w_base, w_total = coverage_windows(s, ln, gap=1 << 20)
+            assert np.all(w_start % 16 == 0) and np.all(w_len % 16 == 0) and np.all(np.diff(w_start) > 0)
+            assert np.all(w_start[1:] >= w_start[:-1] + w_len[:-1])  # windows do not overlap
+            compact = compact_coverage(cov, w_start, w_len, w_base, w_total).numpy()
+            s2 = remap_to_windows(s, w_start, w_base)
+            assert s2.min() >= 0 and int((s2 + ln).max()) <= w_total
+            want = profiles_from_coverage(cov, 0, iv_start, iv_len, orf_iv, reverse, lo, hi)
+            got = profiles_from_coverage(compact, 0, s2, ln, orf_iv[lo : hi + 1] - k0, reverse[lo:hi], 0, hi - lo)
+            assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1])
+            uploaded += w_total
+            if world == 8:
+                assert len(w_start) <= 4  # a slice = a stretch on each strand array, not thousands of pieces
+        if world == 8:
+            assert uploaded < 1.3 * total_cov / 1  # together about one copy of what is touched ...
+            assert uploaded / world < 0.2 * total_cov  # ... an eighth each, not a full copy per device
+    z = coverage_windows(np.zeros(0, np.int64), np.zeros(0, np.int32))
+    assert z[3] == 0 and z[0].size == 0
