@@ -311,6 +311,19 @@ int rp_coverage_build_dev(int device, const int32_t *d_group, const int64_t *d_p
                           int64_t coverage_len, void *hip_stream);
 
 /*
+ * The same from the columns merge_read_lengths hands over (detect_orfs.py:54-83 as columns: strand
+ * uint8 0 '+' / 1 '-', chromosome code int32, shifted position int64, count int64), with the
+ * (strand, chromosome) -> group lookup on the device: d_lut[strand * n_chroms + chrom] = group of the
+ * candidate-ORF index, or -1 where no ORF lives.  Rows outside every group's extent are dropped
+ * whatever their count (the reference never looks them up); RP_ERR_COUNTS if a row that does land,
+ * or an accumulated sum, leaves [0, RP_MAX_COUNT].  Synchronous.
+ */
+int rp_coverage_build_rows_dev(int device, const uint8_t *d_strand, const int32_t *d_chrom, const int64_t *d_pos,
+                               const int64_t *d_count, int64_t n_rows, const int32_t *d_lut, int32_t n_chroms,
+                               const int64_t *d_group_start, const int64_t *d_group_lo, const int64_t *d_group_hi,
+                               int32_t n_groups, int32_t *d_coverage, int64_t coverage_len, void *hip_stream);
+
+/*
  * Metagene profiles of one read length: replaces the per-ORF pandas
  * loop of metagene_coverage (metagene.py:203-228).  d_counts / d_offsets: the profiles
  * "leader + ORF + trailer, first max_positions nucleotides, transcript orientation" of the

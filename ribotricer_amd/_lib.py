@@ -84,6 +84,7 @@ SYMBOLS = {
     "rp_validate_csr_dev": (_int, [_int, _vp, _vp, _i64, _i64, _vp]),
     "rp_metagene_dev": (_int, [_int, _vp, _vp, _i64, ctypes.c_int32, _vp, _vp, _vp, _vp]),
     "rp_coverage_build_dev": (_int, [_int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp]),
+    "rp_coverage_build_rows_dev": (_int, [_int, _vp, _vp, _vp, _vp, _i64, _vp, ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp]),
     # host side (no GPU): TSV row rendering
     "rp_format_rows_host": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp,
                                    ctypes.c_size_t, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_size_t)]),

@@ -214,30 +214,32 @@ def build_coverage_device(merged, index, device=None):
     coverage = torch.zeros(total, dtype=torch.int32, device=dev)
     if cols.pos.size == 0 or total == 0:
         return coverage, base
-    group = cols.group_codes(keys)
     g_start = np.array([base[k][0] for k in keys], np.int64)
     g_lo = np.array([extent[k][0] for k in keys], np.int64)
     g_hi = np.array([extent[k][1] for k in keys], np.int64)
-    # Only rows the reference would ever look up take part: a position on a contig without
-    # candidate ORFs (rRNA, chrM) or outside every ORF's extent is never a key of a lookup
-    # (detect_orfs.py:176-187), whatever its count -- k_coverage_build drops those rows as well.
-    live = group >= 0
-    if live.any():
-        gl = np.where(live, group, 0)
-        live &= (cols.pos >= g_lo[gl]) & (cols.pos <= g_hi[gl])
-    if live.any():
-        c_live = cols.count[live]
-        if int(c_live.min()) < 0 or int(c_live.max()) > _lib.MAX_COUNT:
-            bad = int(c_live.min()) if int(c_live.min()) < 0 else int(c_live.max())
-            raise _lib.RibophaseError(-7, f"P-site count {bad} outside [0, {_lib.MAX_COUNT}]")
-    to_dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev, non_blocking=True)  # noqa: E731
-    d_group, d_pos, d_count = to_dev(group[live], np.int32), to_dev(cols.pos[live], np.int64), to_dev(cols.count[live], np.int32)
-    d_start, d_lo, d_hi = to_dev(g_start, np.int64), to_dev(g_lo, np.int64), to_dev(g_hi, np.int64)
+    # (strand, chromosome) -> group of the index; -1 where no ORF lives.  Everything per row -- the
+    # lookup, the extent test, the range check of the counts that DO land (a position on a contig
+    # without candidate ORFs is never a key of a lookup in the reference, whatever its count:
+    # detect_orfs.py:176-187) and the adding-up -- happens on the device: the columns go up as they are.
+    n_chroms = max(1, len(cols.chroms))
+    lut = np.full((2, n_chroms), -1, np.int32)
+    where = {name: k for k, name in enumerate(cols.chroms)}
+    for g, (strand, chrom) in enumerate(keys):
+        if strand in STRANDS and chrom in where:
+            lut[STRANDS.index(strand), where[chrom]] = g
+
+    def to_dev(a, dt):
+        a = np.ascontiguousarray(a, dtype=dt)
+        return torch.from_numpy(a).to(dev, non_blocking=True)
+
+    d_strand, d_chrom = to_dev(cols.strand, np.uint8), to_dev(cols.chrom, np.int32)
+    d_pos, d_count = to_dev(cols.pos, np.int64), to_dev(cols.count, np.int64)
+    d_lut, d_start, d_lo, d_hi = to_dev(lut.ravel(), np.int32), to_dev(g_start, np.int64), to_dev(g_lo, np.int64), to_dev(g_hi, np.int64)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     _lib.check(
-        _lib.load().rp_coverage_build_dev(
-            dev.index, _ptr(d_group), _ptr(d_pos), _ptr(d_count), d_pos.numel(), _ptr(d_start), _ptr(d_lo), _ptr(d_hi),
-            len(keys), _ptr(coverage), coverage.numel(), stream,
+        _lib.load().rp_coverage_build_rows_dev(
+            dev.index, _ptr(d_strand), _ptr(d_chrom), _ptr(d_pos), _ptr(d_count), d_pos.numel(), _ptr(d_lut), n_chroms,
+            _ptr(d_start), _ptr(d_lo), _ptr(d_hi), len(keys), _ptr(coverage), coverage.numel(), stream,
         )
     )
     return coverage, base

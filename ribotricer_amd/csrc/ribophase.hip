@@ -15,7 +15,6 @@
 #include "../../include/ribophase.h"
 #include "rp_device.hpp"
 #include "rp_tile.hpp"
-#include "rp_ring.hpp"
 #include <new>
 #include "rp_format.hpp"
 #include "rp_index.hpp"
@@ -27,9 +26,6 @@
 namespace {
 
 thread_local char g_err[512] = "";
-#ifndef RP_RING
-#define RP_RING 0  // 1: persistent ring kernel (rp_ring.hpp, measured 30 % slower); 0: one workgroup per tile (k_tile_score) for the CSR scorer, as in rounds 1-2 (A/B)
-#endif
 constexpr long long kAutoWaveNt = 2LL << 20;  // RP_ALGO_AUTO switches to the wave kernel below this
 
 int fail(int code, const char *fmt, ...)
@@ -201,8 +197,9 @@ int launch_plan_kernels(const int64_t *d_offsets, int64_t n_orfs, const rp::Tile
         RP_HIP(hipGetLastError());
     }
     {
-        const int grid = (int)((plan.n_tiles * 64 + block - 1) / block);
-        hipLaunchKernelGGL(rp::k_tile_head, dim3(grid), dim3(block), 0, stream, plan.n_tiles, ws.tile_first, ws.head);
+        const int per_block = rp::kHeadBlock / 64;  // a wave per tile
+        const int grid = (int)((plan.n_tiles + per_block - 1) / per_block);
+        hipLaunchKernelGGL(rp::k_tile_head, dim3(grid), dim3(rp::kHeadBlock), 0, stream, plan.n_tiles, ws.tile_first, ws.head);
         RP_HIP(hipGetLastError());
     }
     return RP_OK;
@@ -312,18 +309,10 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     // 2. scoring pass over flat tiles: one record per (ORF, tile) segment
     if (gather != nullptr)
         RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score<true, TILE>), dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
-                                              d_counts, (long long)n_orfs, plan, ws, piece_plan_of(gather), out, fp));
-    else if (RP_RING) {
-        // persistent workgroups with a two-slot LDS ring (rp_ring.hpp): kRingWgsPerCu per CU
-        int cus = 0;
-        RP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-        long long grid = (long long)(cus > 0 ? cus : 256) * rp::kRingWgsPerCu;
-        if (grid > plan.n_tiles) grid = plan.n_tiles;
-        RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score_ring<TILE>), dim3((unsigned)grid), dim3(rp::kTileBlock), 0, stream,
-                                              d_counts, (long long)n_orfs, plan, ws, out, fp));
-    } else
+                                              d_counts, (long long)n_orfs, plan, ws, piece_plan_of(gather)));
+    else
         RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score<false, TILE>), dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
-                                              d_counts, (long long)n_orfs, plan, ws, rp::PiecePlan{}, out, fp));
+                                              d_counts, (long long)n_orfs, plan, ws, rp::PiecePlan{}));
     RP_HIP(hipGetLastError());
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));
     // 3. one thread per ORF: add its records, score, filter, store
@@ -750,6 +739,38 @@ int rp_coverage_build_dev(int device, const int32_t *d_group, const int64_t *d_p
     (void)hipFree(d_err);
     if (e != hipSuccess) return fail(RP_ERR_HIP, "coverage build: %s", hipGetErrorString(e));
     if (h_err) return fail(RP_ERR_COUNTS, "an accumulated P-site count left [0, %d]", RP_MAX_COUNT);
+    return RP_OK;
+}
+
+int rp_coverage_build_rows_dev(int device, const uint8_t *d_strand, const int32_t *d_chrom, const int64_t *d_pos,
+                               const int64_t *d_count, int64_t n_rows, const int32_t *d_lut, int32_t n_chroms,
+                               const int64_t *d_group_start, const int64_t *d_group_lo, const int64_t *d_group_hi,
+                               int32_t n_groups, int32_t *d_coverage, int64_t coverage_len, void *hip_stream)
+{
+    if (n_rows < 0 || coverage_len < 0 || n_groups < 0 || n_chroms < 0) return fail(RP_ERR_SIZE, "negative size");
+    if (n_rows > 0 && (!d_strand || !d_chrom || !d_pos || !d_count || !d_lut || !d_group_start || !d_group_lo || !d_group_hi))
+        return fail(RP_ERR_NULL, "row columns, lookup table and group tables must be non-null");
+    if (coverage_len > 0 && !d_coverage) return fail(RP_ERR_NULL, "d_coverage is null");
+    RP_ON_DEVICE(device);
+    if (n_rows == 0) return RP_OK;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    int *d_err = nullptr;  // 4-byte scratch word for the range check (once per sample, not the hot path)
+    RP_HIP(hipMalloc(&d_err, sizeof(int)));
+    hipError_t e = hipMemsetAsync(d_err, 0, sizeof(int), stream);
+    int h_err = 0;
+    if (e == hipSuccess) {
+        long long blocks = (n_rows + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(rp::k_coverage_build_rows, dim3((unsigned)blocks), dim3(256), 0, stream, d_strand, d_chrom, d_pos, d_count,
+                           (long long)n_rows, d_lut, (int)n_chroms, d_group_start, d_group_lo, d_group_hi, (int)n_groups, d_coverage,
+                           (long long)coverage_len, d_err);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_err);
+    if (e != hipSuccess) return fail(RP_ERR_HIP, "coverage build: %s", hipGetErrorString(e));
+    if (h_err) return fail(RP_ERR_COUNTS, "a P-site count (or an accumulated sum) left [0, %d]", RP_MAX_COUNT);
     return RP_OK;
 }
 

@@ -39,6 +39,37 @@ __global__ void k_coverage_build(const int32_t *__restrict__ group, const int64_
     }
 }
 
+// The same straight from the columns merge_read_lengths hands over -- strand uint8, chromosome code
+// int32, position int64, count int64 -- with the (strand, chromosome) -> group lookup done here
+// (lut[strand * n_chroms + chrom], -1: no ORF lives there): no per-row work is left on the host.
+// err |= 1: an accumulated count left [0, RP_MAX_COUNT]; only rows that land inside a group's
+// extent take part -- the reference never looks the others up (detect_orfs.py:176-187).
+__global__ void k_coverage_build_rows(const uint8_t *__restrict__ strand, const int32_t *__restrict__ chrom,
+                                      const int64_t *__restrict__ pos, const int64_t *__restrict__ count, long long n,
+                                      const int32_t *__restrict__ lut, int n_chroms, const int64_t *__restrict__ group_start,
+                                      const int64_t *__restrict__ group_lo, const int64_t *__restrict__ group_hi, int n_groups,
+                                      int32_t *__restrict__ coverage, long long coverage_len, int *__restrict__ err)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        const int s = strand[k], c = chrom[k];
+        if (s > 1 || c < 0 || c >= n_chroms) continue;
+        const int g = lut[s * n_chroms + c];
+        if (g < 0 || g >= n_groups) continue;
+        const long long p = pos[k];
+        if (p < group_lo[g] || p > group_hi[g]) continue;
+        const long long idx = group_start[g] + (p - group_lo[g]);
+        if (idx < 0 || idx >= coverage_len) continue;
+        const long long cnt = count[k];
+        if (cnt < 0 || cnt > RP_MAX_COUNT) {
+            atomicOr(err, 1);
+            continue;
+        }
+        const int before = atomicAdd(&coverage[idx], (int)cnt);
+        if ((long long)before + cnt > RP_MAX_COUNT) atomicOr(err, 1);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Metagene profiles (metagene_coverage, ribotricer/metagene.py:160-265), one read length.
 // Input: the leader + ORF + trailer profiles of the annotated ORFs, already truncated to

@@ -23,30 +23,58 @@
 #include <string>
 #include <string_view>
 #include <thread>
+#include <type_traits>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 namespace rpidx {
 
 enum ParseError : int { kOk = 0, kColumns = 1, kCoordinate = 2 };
 
+// std::vector / byte buffer whose resize() leaves new elements uninitialised: the stitched arrays of
+// an 11 M-line index are 2 GB that would otherwise be zero-filled by one thread before the parser
+// threads overwrite every byte of them.
+template <typename T>
+struct DefaultInitAlloc : std::allocator<T> {
+    template <typename U>
+    struct rebind {
+        using other = DefaultInitAlloc<U>;
+    };
+    using std::allocator<T>::allocator;
+    template <typename U>
+    void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value)
+    {
+        ::new (static_cast<void *>(p)) U;
+    }
+    template <typename U, typename... A>
+    void construct(U *p, A &&...a)
+    {
+        ::new (static_cast<void *>(p)) U(std::forward<A>(a)...);
+    }
+};
+template <typename T>
+using Vec = std::vector<T, DefaultInitAlloc<T>>;
+
+inline void append(Vec<char> &dst, std::string_view s) { dst.insert(dst.end(), s.begin(), s.end()); }
+
 struct Index {
     // per ORF
-    std::vector<int64_t> orf_iv;    // [n + 1] first interval of each ORF
-    std::vector<int64_t> length;    // [n] sum of interval lengths
-    std::vector<int32_t> group;     // [n] index into the (strand, chrom) groups
-    std::vector<uint8_t> reverse;   // [n] 1 for '-' strand
+    Vec<int64_t> orf_iv;    // [n + 1] first interval of each ORF
+    Vec<int64_t> length;    // [n] sum of interval lengths
+    Vec<int32_t> group;     // [n] index into the (strand, chrom) groups
+    Vec<uint8_t> reverse;   // [n] 1 for '-' strand
     // per interval, ascending by start inside each ORF, 1-based closed
-    std::vector<int64_t> iv_start, iv_end;
+    Vec<int64_t> iv_start, iv_end;
     // (strand, chrom) groups in order of first appearance
     std::string group_names;             // "strand\tchrom" concatenated
     std::vector<int64_t> group_off;      // [g + 1]
     std::vector<int64_t> group_lo, group_hi;  // extent of the ORFs of each group
     // string tables for the TSV writer
-    std::string head;  // "ORF_ID\tORF_type"
-    std::vector<int64_t> head_off;
-    std::string tail;  // "transcript_id\ttranscript_type\tgene_id\tgene_name\tgene_type\tchrom\tstrand\tstart_codon"
-    std::vector<int64_t> tail_off;
+    Vec<char> head;  // "ORF_ID\tORF_type"
+    Vec<int64_t> head_off;
+    Vec<char> tail;  // "transcript_id\ttranscript_type\tgene_id\tgene_name\tgene_type\tchrom\tstrand\tstart_codon"
+    Vec<int64_t> tail_off;
     // diagnostics
     int64_t error_line = 0;  // 1-based line number of the first malformed line
 };
@@ -71,7 +99,7 @@ inline bool parse_int(std::string_view t, int64_t &out)
     return true;
 }
 
-inline void append_int(std::string &s, int64_t v)
+inline void append_int(Vec<char> &s, int64_t v)
 {
     char tmp[24];
     int n = 0;
@@ -211,7 +239,7 @@ inline int parse_run(const char *text, size_t len, bool skip_header, Index &ix)
         }
         ix.group.push_back(gid);
         // head: ORF_ID \t ORF_type
-        ix.head.append(f[2]);
+        append(ix.head, f[2]);
         ix.head.push_back('_');
         append_int(ix.head, first);
         ix.head.push_back('_');
@@ -219,14 +247,14 @@ inline int parse_run(const char *text, size_t len, bool skip_header, Index &ix)
         ix.head.push_back('_');
         append_int(ix.head, length);
         ix.head.push_back('\t');
-        ix.head.append(f[1]);
+        append(ix.head, f[1]);
         ix.head_off.push_back((int64_t)ix.head.size());
         // tail: fields 2..8 then the start codon
         for (int k = 2; k <= 8; ++k) {
-            ix.tail.append(f[k]);
+            append(ix.tail, f[k]);
             ix.tail.push_back('\t');
         }
-        ix.tail.append(start_codon(f[9]));
+        append(ix.tail, start_codon(f[9]));
         ix.tail_off.push_back((int64_t)ix.tail.size());
     }
     return kOk;
@@ -244,22 +272,15 @@ inline int64_t count_lines(const char *text, size_t len)
     return n;
 }
 
-template <typename T>
-inline void append_shifted(std::vector<T> &dst, const std::vector<T> &src, size_t skip, T shift)
-{
-    const size_t at = dst.size();
-    dst.resize(at + src.size() - skip);
-    for (size_t k = skip; k < src.size(); ++k) dst[at + k - skip] = src[k] + shift;
-}
-
 // The whole index text: cut into runs of whole lines, one per thread, parsed independently and
 // stitched together in file order -- same arrays, same group numbering (first appearance in the
-// file) and the same first malformed line as one sequential pass.
+// file) and the same first malformed line as one sequential pass.  The stitch runs on the same
+// threads: every run copies itself to its place in the final arrays.
 inline int parse(const char *text, size_t len, bool skip_header, Index &ix, int threads = 0)
 {
     if (threads <= 0) {
         threads = (int)std::thread::hardware_concurrency();
-        threads = threads > 8 ? 8 : (threads < 1 ? 1 : threads);
+        threads = threads > 32 ? 32 : (threads < 1 ? 1 : threads);
     }
     const size_t min_run = (size_t)4 << 20;
     if ((size_t)threads > len / min_run) threads = (int)(len / min_run);
@@ -287,60 +308,77 @@ inline int parse(const char *text, size_t len, bool skip_header, Index &ix, int 
             return rc[t];
         }
     }
-    size_t n = 0, n_iv = 0, n_head = 0, n_tail = 0;
-    for (const Index &p : part) {
-        n += p.length.size();
-        n_iv += p.iv_start.size();
-        n_head += p.head.size();
-        n_tail += p.tail.size();
+    // where every run goes
+    std::vector<size_t> at_orf(threads + 1, 0), at_iv(threads + 1, 0), at_head(threads + 1, 0), at_tail(threads + 1, 0);
+    for (int t = 0; t < threads; ++t) {
+        at_orf[t + 1] = at_orf[t] + part[t].length.size();
+        at_iv[t + 1] = at_iv[t] + part[t].iv_start.size();
+        at_head[t + 1] = at_head[t] + part[t].head.size();
+        at_tail[t + 1] = at_tail[t] + part[t].tail.size();
     }
-    ix.orf_iv.reserve(n + 1);
-    ix.length.reserve(n);
-    ix.group.reserve(n);
-    ix.reverse.reserve(n);
-    ix.iv_start.reserve(n_iv);
-    ix.iv_end.reserve(n_iv);
-    ix.head.reserve(n_head);
-    ix.tail.reserve(n_tail);
-    ix.head_off.reserve(n + 1);
-    ix.tail_off.reserve(n + 1);
-    ix.orf_iv.push_back(0);
-    ix.head_off.push_back(0);
-    ix.tail_off.push_back(0);
+    const size_t n = at_orf[threads];
+    ix.orf_iv.resize(n + 1);
+    ix.length.resize(n);
+    ix.group.resize(n);
+    ix.reverse.resize(n);
+    ix.iv_start.resize(at_iv[threads]);
+    ix.iv_end.resize(at_iv[threads]);
+    ix.head.resize(at_head[threads]);
+    ix.tail.resize(at_tail[threads]);
+    ix.head_off.resize(n + 1);
+    ix.tail_off.resize(n + 1);
+    ix.orf_iv[0] = 0;
+    ix.head_off[0] = 0;
+    ix.tail_off[0] = 0;
     ix.group_off.push_back(0);
+    // the runs' groups, in file order of first appearance, against the file-wide numbering (a few dozen keys)
     std::unordered_map<std::string, int32_t> groups;
-    for (Index &p : part) {
-        // this run's groups, in its order of first appearance, against the file-wide numbering
-        std::vector<int32_t> remap(p.group_lo.size());
-        for (size_t g = 0; g < remap.size(); ++g) {
+    std::vector<std::vector<int32_t>> remap(threads);
+    for (int t = 0; t < threads; ++t) {
+        const Index &p = part[t];
+        remap[t].resize(p.group_lo.size());
+        for (size_t g = 0; g < remap[t].size(); ++g) {
             const std::string key = p.group_names.substr((size_t)p.group_off[g], (size_t)(p.group_off[g + 1] - p.group_off[g]));
             auto it = groups.find(key);
             if (it == groups.end()) {
-                remap[g] = (int32_t)groups.size();
-                groups.emplace(key, remap[g]);
+                remap[t][g] = (int32_t)groups.size();
+                groups.emplace(key, remap[t][g]);
                 ix.group_names.append(key);
                 ix.group_off.push_back((int64_t)ix.group_names.size());
                 ix.group_lo.push_back(p.group_lo[g]);
                 ix.group_hi.push_back(p.group_hi[g]);
             } else {
-                remap[g] = it->second;
-                ix.group_lo[remap[g]] = std::min(ix.group_lo[remap[g]], p.group_lo[g]);
-                ix.group_hi[remap[g]] = std::max(ix.group_hi[remap[g]], p.group_hi[g]);
+                remap[t][g] = it->second;
+                ix.group_lo[remap[t][g]] = std::min(ix.group_lo[remap[t][g]], p.group_lo[g]);
+                ix.group_hi[remap[t][g]] = std::max(ix.group_hi[remap[t][g]], p.group_hi[g]);
             }
         }
-        append_shifted(ix.orf_iv, p.orf_iv, 1, (int64_t)ix.iv_start.size());
-        append_shifted(ix.head_off, p.head_off, 1, (int64_t)ix.head.size());
-        append_shifted(ix.tail_off, p.tail_off, 1, (int64_t)ix.tail.size());
-        ix.length.insert(ix.length.end(), p.length.begin(), p.length.end());
-        ix.reverse.insert(ix.reverse.end(), p.reverse.begin(), p.reverse.end());
-        ix.iv_start.insert(ix.iv_start.end(), p.iv_start.begin(), p.iv_start.end());
-        ix.iv_end.insert(ix.iv_end.end(), p.iv_end.begin(), p.iv_end.end());
-        ix.head.append(p.head);
-        ix.tail.append(p.tail);
-        const size_t at = ix.group.size();
-        ix.group.resize(at + p.group.size());
-        for (size_t k = 0; k < p.group.size(); ++k) ix.group[at + k] = remap[(size_t)p.group[k]];
-        p = Index();  // release the run's copy as soon as it is stitched in
+    }
+    {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t)
+            pool.emplace_back([&, t] {
+                Index &p = part[t];
+                const size_t o = at_orf[t], m = p.length.size();
+                for (size_t k = 0; k < m; ++k) {
+                    ix.orf_iv[o + 1 + k] = p.orf_iv[k + 1] + (int64_t)at_iv[t];
+                    ix.head_off[o + 1 + k] = p.head_off[k + 1] + (int64_t)at_head[t];
+                    ix.tail_off[o + 1 + k] = p.tail_off[k + 1] + (int64_t)at_tail[t];
+                    ix.group[o + k] = remap[t][(size_t)p.group[k]];
+                }
+                if (m) {
+                    std::memcpy(ix.length.data() + o, p.length.data(), m * sizeof(int64_t));
+                    std::memcpy(ix.reverse.data() + o, p.reverse.data(), m);
+                }
+                if (!p.iv_start.empty()) {
+                    std::memcpy(ix.iv_start.data() + at_iv[t], p.iv_start.data(), p.iv_start.size() * sizeof(int64_t));
+                    std::memcpy(ix.iv_end.data() + at_iv[t], p.iv_end.data(), p.iv_end.size() * sizeof(int64_t));
+                }
+                if (!p.head.empty()) std::memcpy(ix.head.data() + at_head[t], p.head.data(), p.head.size());
+                if (!p.tail.empty()) std::memcpy(ix.tail.data() + at_tail[t], p.tail.data(), p.tail.size());
+                p = Index();  // release the run's copy as soon as it is stitched in
+            });
+        for (auto &th : pool) th.join();
     }
     return kOk;
 }

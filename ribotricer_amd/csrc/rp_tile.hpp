@@ -83,24 +83,20 @@ struct TilePlan {
     int mis;  // (counts address / 4) % 4: tiles live on the 16-byte aligned grid
 };
 
-// One record per (ORF, tile) segment OF AN ORF THAT SPANS TILES: the sums over the triplets of
-// the ORF that the tile owns.  (An ORF that lies inside one tile -- nearly all of them -- is
-// finished by the scoring kernel itself and leaves no record, see record_stage.)  Indexed by
-// orf + tile : an ORF spanning tiles s..e owns the ids orf+s .. orf+e, and the next ORF starts
-// in a tile >= e, so ids never collide.  48 bytes as three 16-byte words in three planes
-// (rec[f * n_rec + id]), one per reading frame -- wave f of the scoring kernel sums, scores and
-// writes frame f:
+// One record per (ORF, tile) segment: the sums over the triplets of the ORF that the tile
+// owns.  Indexed by  orf + tile : an ORF spanning tiles s..e owns the ids orf+s .. orf+e, and
+// the next ORF starts in a tile >= e, so ids never collide.  48 bytes as three 16-byte words
+// in three planes (rec[f * n_rec + id]), one per reading frame: writers (wave f of the scoring
+// kernel, a thread per segment) and readers (a thread per ORF) touch consecutive words with
+// consecutive threads.
 //   plane f  p[f]  q[f]  n_f | m_f << 16  extra_f     p, q fp32: the float64 sum of <= 11 fp32 row
 //            records, rounded once; extra_0 = count.lo, extra_1 = count.hi, extra_2 = min_codon
 //            (a tile owns < 2^16 triplets)
+// (Finishing the ORFs that lie inside one tile in the scoring kernel itself -- no record, no
+// round trip -- was built and measured in round 3: the float64 chain at the end of every
+// workgroup costs the scoring kernel +12 %, three times what the round trip costs;
+// profiles/r03_ab_inkernel_finish.txt.)
 constexpr size_t kRecordBytes = 48;
-// flags[i] of an ORF the scoring kernel has seen whole but could not settle (fp32 frame decision
-// or cutoff comparison too close to call): k_orf_finish re-walks it in float64 and overwrites the
-// flag.  Never visible to the caller.
-constexpr unsigned kFlagPending = 0x80u;
-#ifndef RP_INKERNEL_FINISH
-#define RP_INKERNEL_FINISH 0  // 1: whole ORFs finished by the scoring kernel (measured slower); 0: every segment leaves a record and k_orf_finish finishes every ORF (round 2's flow; A/B)
-#endif
 
 // One descriptor per segment id, derived from the offsets alone (k_tile_desc): where the
 // segment's triplets lie inside its tile's LDS image and how many lanes walk them.
@@ -110,7 +106,6 @@ constexpr unsigned kFlagPending = 0x80u;
 //   bits 38-50  tail     LDS index of an owned partial last codon (L % 3 != 0) ...
 //   bits 51-52  part     ... and its length (0 = none)
 //   bits 53-60  lanes    ceil(ntrip / kRun)
-//   bit  62     whole    the segment is the whole ORF (it starts and ends inside this tile)
 //   bit  63     live     0 = this id is a gap (no segment: empty ORF, or an unused id)
 typedef unsigned long long seg_desc_t;
 static_assert(kTile + kHalo < 8192 && kTile / 3 < 4096 && (kTile / 3 + kRun - 1) / kRun < 256, "descriptor field widths");
@@ -123,7 +118,11 @@ static_assert(kTileSmall <= kTile && kTileSmall % 256 == 0, "the small tile reus
 // row with loads that depend on nothing but blockIdx, so every wave knows which triplets its
 // lanes walk before the tile data has landed; only tiles with more segments than kHeadSlots
 // (short-ORF batches) take the dependent path through the per-segment array and a table in LDS.
-constexpr int kHeadSlots = 46;
+#ifndef RP_HEAD_SLOTS
+#define RP_HEAD_SLOTS 64
+#endif
+constexpr int kHeadSlots = RP_HEAD_SLOTS;
+static_assert(kHeadSlots <= kWave, "one head-row descriptor per lane");
 constexpr int kHeadMapAt = 2 + kHeadSlots;    // 8-byte index where the lane map starts
 constexpr int kHeadRow = kHeadMapAt + 256 / 8;  // 8-byte entries per row (640 B per 31 KiB tile)
 static_assert(kTile / (3 * kRun) + kHeadSlots + 1 <= 256, "a head-row tile must fit one pass per wave");
@@ -287,40 +286,76 @@ __global__ void k_tile_desc(const int64_t *__restrict__ offsets, long long n_orf
             }
         }
         const int lanes = (ntrip + kRun - 1) / kRun;
-        const seg_desc_t whole = (RP_INKERNEL_FINISH && b_first == b_last) ? 1ull : 0ull;
         const seg_desc_t d = (seg_desc_t)qfirst | ((seg_desc_t)endq << 13) | ((seg_desc_t)ntrip << 26) |
-                             ((seg_desc_t)tail << 38) | ((seg_desc_t)part << 51) | ((seg_desc_t)lanes << 53) | (whole << 62) | (1ull << 63);
+                             ((seg_desc_t)tail << 38) | ((seg_desc_t)part << 51) | ((seg_desc_t)lanes << 53) | (1ull << 63);
         desc[orf + b] = d;
         const long long slot = orf - (tile_first[b] - 1);  // slot 0 = the ORF straddling in from the left
         if (slot >= 0 && slot < kHeadSlots) head[b * kHeadRow + 2 + slot] = d;
     }
 }
 
-// the [a0, a1) header and the lane map of every head row (64 threads per tile, one per four
-// virtual lanes; after k_tile_desc)
-__global__ void k_tile_head(long long n_tiles, const long long *__restrict__ tile_first, seg_desc_t *__restrict__ head)
+// The [a0, a1) header and the lane map of every head row (after k_tile_desc): one wave per tile.
+// Lane = slot reads its descriptor, a wave-wide scan gives every segment's first virtual lane, the
+// segment marks it in a 256-entry LDS strip (entry v = virtual lane v), and a max-scan over the
+// strip -- four entries per lane, then across lanes -- names the segment of every virtual lane.
+// (The first version walked the 46 slots once per thread with dependent loads: 0.93 ms for the
+// 500 000 tiles of an 11 M-ORF index, most of a plan build; this one is bandwidth-bound.)
+constexpr int kHeadBlock = 256;
+
+__device__ __forceinline__ int wave_max_scan_head(int x)  // inclusive max-scan over the wave, values >= 0
 {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long b = t >> 6;
-    const int j = (int)(t & 63);
-    if (b >= n_tiles) return;
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));
+    return x;
+}
+
+__global__ __launch_bounds__(kHeadBlock) void k_tile_head(long long n_tiles, const long long *__restrict__ tile_first,
+                                                          seg_desc_t *__restrict__ head)
+{
+    __shared__ __attribute__((aligned(16))) int s_mark[kHeadBlock / 64][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long b = (long long)blockIdx.x * (kHeadBlock / 64) + w;
+    if (b >= n_tiles) return;  // (wave-uniform; no workgroup barrier below)
     seg_desc_t *row = head + b * kHeadRow;
-    if (j == 0) {
+    const seg_desc_t d = lane < kHeadSlots ? row[2 + lane] : 0;
+    if (lane == 0) {
         row[0] = (seg_desc_t)tile_first[b];
         row[1] = (seg_desc_t)tile_first[b + 1];
     }
-    unsigned out = 0xffffffffu;
-    int vs = 0;
-    for (int slot = 0; slot < kHeadSlots; ++slot) {
-        const int ve = vs + ((int)(row[2 + slot] >> 53) & 0xff);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int v = 4 * j + k;
-            if (v >= vs && v < ve) out = (out & ~(0xffu << (8 * k))) | ((unsigned)slot << (8 * k));
-        }
-        vs = ve;
-    }
-    reinterpret_cast<unsigned *>(row + kHeadMapAt)[j] = out;
+    const int lanes_i = (int)(d >> 53) & 0xff;
+    int incl = lanes_i;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);
+    const int vs = incl - lanes_i;
+    const int total = __builtin_amdgcn_readlane(incl, 63);  // <= 256 (static_assert at kHeadSlots)
+    int *mk = s_mark[w];
+    *reinterpret_cast<int4 *>(mk + 4 * lane) = make_int4(0, 0, 0, 0);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its LDS operations complete in order)
+    if (lanes_i > 0 && vs < 256) mk[vs] = lane + 1;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int4 m = *reinterpret_cast<const int4 *>(mk + 4 * lane);
+    m.y = max(m.x, m.y);
+    m.z = max(m.y, m.z);
+    m.w = max(m.z, m.w);
+    const int scan = wave_max_scan_head(m.w);
+    int before = __builtin_amdgcn_ds_bpermute(((lane + 63) & 63) << 2, scan);  // the previous lane's inclusive value
+    if (lane == 0) before = 0;
+    const int v0 = 4 * lane;
+    const unsigned b0 = v0 + 0 < total ? (unsigned)(max(m.x, before) - 1) & 0xffu : 0xffu;
+    const unsigned b1 = v0 + 1 < total ? (unsigned)(max(m.y, before) - 1) & 0xffu : 0xffu;
+    const unsigned b2 = v0 + 2 < total ? (unsigned)(max(m.z, before) - 1) & 0xffu : 0xffu;
+    const unsigned b3 = v0 + 3 < total ? (unsigned)(max(m.w, before) - 1) & 0xffu : 0xffu;
+    reinterpret_cast<unsigned *>(row + kHeadMapAt)[lane] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
 }
 
 // ---------------------------------------------------------------------------
@@ -698,100 +733,44 @@ __device__ __forceinline__ void tile_pass(const int *__restrict__ s_counts, SegI
     }
 }
 
-// what the record stage keeps per slot: bit 0 live, bit 1 whole ORF, bits 2.. its length (endq - qfirst, unclamped then)
-__device__ __forceinline__ int live_word(seg_desc_t d)
-{
-    const int live = (int)(d >> 63), whole = (int)(d >> 62) & 1;
-    const int len = (((int)(d >> 13)) & 0x1fff) - ((int)d & 0x1fff);
-    return live | (whole << 1) | (whole ? len << 2 : 0);
-}
-
-// Record stage, after the lane runs of a round: row records + integer sums -> per segment, either
-//   * the finished ORF, when the segment IS the whole ORF (it starts and ends in this tile): frame
-//     scores -> state machine -> filters -> the six outputs, straight from here -- no record, no
-//     round trip through k_orf_finish (which, at 11 M ORFs, spent 0.16 ms reading 48-byte records
-//     back and the scoring kernel 0.1 ms writing them); an ORF whose fp32 frame decision or cutoff
-//     comparison is too close to call only gets flags = kFlagPending and is re-walked in float64
-//     by k_orf_finish, as before;
-//   * or ONE 48-byte record (an ORF that spans tiles), summed up by k_orf_finish.
-// Wave f < 3 takes reading frame f for all 64 slots (thread = slot): sums the row records of
-// (P_f, Q_f) in float64, and either writes plane f of the record or scores the frame
-// (frame_score, the float64 chain of the stage) -- three short chains side by side on three SIMDs;
-// after one more barrier wave 0 combines the three scores of every whole ORF.  The arithmetic is
-// operation for operation what k_orf_finish does with a single record (P, Q rounded to fp32 once,
-// then float64), so both routes give the same bits.
+// Record stage: row records + integer sums -> ONE record per live segment.  The three words
+// of a record live in three planes (rec[f * n_rec + id]), one per reading frame; wave f < 3
+// writes plane f for all 64 slots (thread = slot), so the three short dependency chains run
+// side by side on three SIMDs and every store instruction covers consecutive 16-byte words.
 __device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, const SegInts *__restrict__ s_ints,
                                              const RunRec *__restrict__ s_rec, const int *__restrict__ s_vlstart,
                                              const int *__restrict__ s_tail, const int *__restrict__ s_live,
-                                             double (*__restrict__ s_score)[kSegChunk], uint4 *__restrict__ rec, long long n_rec,
-                                             long long id0, long long orf0, int wave, int seg, const OrfOutputs &out,
-                                             const FilterParams &fp)
+                                             uint4 *__restrict__ rec, long long n_rec, long long id0, int wave, int seg)
 {
-    const int live = s_live[seg];  // bit 0: the slot holds a segment; bit 1: it is a whole ORF, whose length sits in bits 2..
-    const bool whole = (live & 2) != 0;
+    if (wave >= 3 || !s_live[seg]) return;
     const int vs = s_vlstart[seg];
     const int ve = s_vlstart[seg + 1];
+    const int w_first = vs >> 4;
+    const int w_last = ve > vs ? (ve - 1) >> 4 : w_first - 1;
     const int tail = s_tail[seg];
+    double a0 = 0.0, a1 = 0.0;
+    for (int w = w_first; w <= w_last; ++w) {
+        const RunRec &r = s_rec[seg + w];
+        a0 += (double)(wave == 0 ? r.p[0] : wave == 1 ? r.p[1] : r.p[2]);
+        a1 += (double)(wave == 0 ? r.q[0] : wave == 1 ? r.q[1] : r.q[2]);
+    }
+    unsigned n = 0, m = 0;
     unsigned long long count = 0;
     unsigned min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
-    if (live != 0 && (wave < 3)) {
-        unsigned codon = 0;
-        if (tail >= 0) {
-            codon = (unsigned)s_counts[tail & 0xffff];
-            if ((tail >> 16) == 2) codon += (unsigned)s_counts[(tail & 0xffff) + 1];
-        }
-        if (ve > vs) {
-            count = s_ints[seg].count;
-            min_codon = s_ints[seg].min_codon;
-        }
-        if (tail >= 0) {
-            count += codon;
-            min_codon = min(min_codon, codon);
-        }
-        const int w_first = vs >> 4;
-        const int w_last = ve > vs ? (ve - 1) >> 4 : w_first - 1;
-        double a0 = 0.0, a1 = 0.0;
-        for (int w = w_first; w <= w_last; ++w) {
-            const RunRec &r = s_rec[seg + w];
-            a0 += (double)(wave == 0 ? r.p[0] : wave == 1 ? r.p[1] : r.p[2]);
-            a1 += (double)(wave == 0 ? r.q[0] : wave == 1 ? r.q[1] : r.q[2]);
-        }
-        const float pf = (float)a0, qf = (float)a1;
-        unsigned n = 0, m = 0;
-        if (ve > vs) {
-            n = (unsigned)(s_ints[seg].nn >> (16 * wave)) & 0xffffu;
-            m = (unsigned)(s_ints[seg].mm >> (16 * wave)) & 0xffffu;
-        }
-        if (!whole) {
-            const unsigned extra = wave == 0 ? (unsigned)count : wave == 1 ? (unsigned)(count >> 32) : min_codon;
-            rec[wave * n_rec + id0 + seg] = make_uint4(__float_as_uint(pf), __float_as_uint(qf), n | (m << 16), extra);
-        } else {
-            s_score[wave][seg] = frame_score((double)pf, (double)qf, (int)n, (int)m).score;
-        }
+    if (ve > vs) {
+        n = (unsigned)(s_ints[seg].nn >> (16 * wave)) & 0xffffu;
+        m = (unsigned)(s_ints[seg].mm >> (16 * wave)) & 0xffffu;
+        count = s_ints[seg].count;
+        min_codon = s_ints[seg].min_codon;
     }
-#if RP_INKERNEL_FINISH
-    __syncthreads();  // barrier 3: the three frames' scores are in LDS
-    if (wave == 0 && whole) {
-        FrameScore fr[3];
-#pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            fr[f].score = s_score[f][seg];
-            fr[f].n = ve > vs ? (int)((s_ints[seg].nn >> (16 * f)) & 0xffffu) : 0;
-            fr[f].m = ve > vs ? (int)((s_ints[seg].mm >> (16 * f)) & 0xffffu) : 0;
-        }
-        double phase;
-        int valid;
-        unsigned flags;
-        combine_frames(fr, phase, valid, flags);
-        const long long orf = orf0 + seg;
-        if (fp32_decision_unsafe(fr, /*tile_sums=*/true) || near_cutoff(fp, phase)) {
-            out.flags[orf] = (uint8_t)kFlagPending;
-        } else {
-            const long long length = live >> 2;
-            store_orf(out, fp, orf, phase, valid, (long long)count, (int)min_codon, flags, length);
-        }
+    if (tail >= 0) {  // an owned partial last codon (L % 3 != 0): common.py:164-180 still sums it
+        unsigned codon = (unsigned)s_counts[tail & 0xffff];
+        if ((tail >> 16) == 2) codon += (unsigned)s_counts[(tail & 0xffff) + 1];
+        count += codon;
+        min_codon = min(min_codon, codon);
     }
-#endif
+    const unsigned extra = wave == 0 ? (unsigned)count : wave == 1 ? (unsigned)(count >> 32) : min_codon;
+    rec[wave * n_rec + id0 + seg] = make_uint4(__float_as_uint((float)a0), __float_as_uint((float)a1), n | (m << 16), extra);
 }
 
 // One round of the short-ORF path: the 64 segments whose descriptors the lanes hold (`dc`), walked
@@ -842,7 +821,7 @@ __device__ __forceinline__ void short_round(seg_desc_t dc, const int *s_counts, 
         s_vlstart[lane] = vs_i;
         if (lane == kWave - 1) s_vlstart[kSegChunk] = incl;
         s_tail[lane] = part ? (((int)(dc >> 38) & 0x1fff) | (part << 16)) : -1;
-        s_live[lane] = live_word(dc);
+        s_live[lane] = (int)(dc >> 63);
     }
     __syncthreads();  // tables and cleared accumulators are in place
     if (pass) tile_pass<KRUN>(s_counts, s_ints, s_rec, q0, lim, active, seg, vl);
@@ -854,8 +833,7 @@ __device__ __forceinline__ void short_round(seg_desc_t dc, const int *s_counts, 
 template <bool FUSED, int TILE>
 __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const int32_t *__restrict__ counts,
                                                            long long n_orfs, TilePlan plan,
-                                                           TileWorkspace ws, PiecePlan pp, OrfOutputs out,
-                                                           FilterParams fp)
+                                                           TileWorkspace ws, PiecePlan pp)
 {
     __shared__ __attribute__((aligned(16))) int s_counts[lds_counts<TILE>()];
     __shared__ int s_live[kSegChunk];     // the slot holds a segment of this tile
@@ -864,7 +842,6 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
     __shared__ int s_owner[kTileBlock];   // short-ORF path: 64 private words per wave for the segment marks
     __shared__ RunRec s_rec[kMaxRecs];
     __shared__ SegInts s_ints[kSegChunk];
-    __shared__ double s_score[3][kSegChunk];  // the frame scores of the round's whole ORFs (record_stage)
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -958,7 +935,7 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
             s_vlstart[lane] = vs_i;
             if (lane == kWave - 1) s_vlstart[kSegChunk] = incl;
             s_tail[lane] = part ? (((int)(d >> 38) & 0x1fff) | (part << 16)) : -1;
-            s_live[lane] = live_word(d);
+            s_live[lane] = (int)(d >> 63);
         }
         RP_STAMP();  // 3: mapped, arrived at barrier 1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is tracked by vmcnt only
@@ -968,7 +945,7 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
         RP_STAMP();  // 5: this wave's lane runs done
         __syncthreads();
         RP_STAMP();  // 6: all lane runs done (barrier 2)
-        record_stage(s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, s_score, ws.rec, ws.n_rec, a0 - 1 + b, a0 - 1, wave, lane, out, fp);
+        record_stage(s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, ws.rec, ws.n_rec, a0 - 1 + b, wave, lane);
         RP_STAMP();  // 7: records stored
         RP_STAMP_FLUSH();
         return;
@@ -1015,7 +992,7 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
 #ifdef RP_STAMPS
         if (n_stamp_ < 7) RP_STAMP();  // short path: 2, 4, 6 = after barrier 2 of rounds 0, 1, 2
 #endif
-        record_stage(s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, s_score, ws.rec, ws.n_rec, a0 - 1 + c0 + b, a0 - 1 + c0, wave, lane, out, fp);
+        record_stage(s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, ws.rec, ws.n_rec, a0 - 1 + c0 + b, wave, lane);
 #ifdef RP_STAMPS
         if (n_stamp_ < 7) RP_STAMP();  // short path: 3, 5, 7 = records of rounds 0, 1, 2 stored
 #endif
@@ -1025,12 +1002,58 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
 
 // ---------------------------------------------------------------------------
 // pass 3: one thread per ORF -- add the records of the tiles it spans, score, filter,
-// store.  Too-close-to-call ORFs (~0.7 %) are queued per workgroup and re-walked in float64
-// from global memory: short ones by one wave each, long ones by all four waves.  (A global
-// queue drained by a fourth kernel was measured slower: the single contended atomic alone
-// cost more than the re-walks.)
+// store.  Too-close-to-call ORFs (~0.4 %) are re-walked in float64 by the wave that found
+// them, one after the other: short ones on the spot, long ones queued for pass 4.
+// (Measured alternatives, both slower: a global queue filled with one atomicAdd per wave and
+// drained by a wave-per-ORF kernel -- 40 000 atomics on one word cost 0.46 ms at 11 M ORFs,
+// profiles/r03_ab_finish_split.txt; finishing one-tile ORFs inside the scoring kernel -- +12 %
+// on that kernel, profiles/r03_ab_inkernel_finish.txt.)
+// The fused path (CoverageSource) first copies the ORF's profile out of the coverage into LDS,
+// piece by piece and coalesced ('-' strand pieces backwards): walk and replay then read plain
+// LDS instead of finding the piece of every position they touch.
 // ---------------------------------------------------------------------------
 constexpr int kFinishBlock = kWave;  // one wave per workgroup: a re-walk holds up nobody else
+constexpr int kStageNt = 2040;       // fused path: profiles up to this long are copied to LDS first (8 KB per wave)
+
+// copy the profile of ORF `orf` out of the coverage into `stage`, piece by piece, coalesced
+__device__ __forceinline__ void stage_profile(const CoverageSource &source, long long orf, long long beg, int *stage, int lane)
+{
+    const PiecePlan &pp = source.pp;
+    const long long j0 = pp.orf_piece[orf], j1 = pp.orf_piece[orf + 1];
+    for (long long j = j0; j < j1; ++j) {  // wave-uniform
+        const unsigned long long sw = pp.start[j];
+        const long long s = (long long)(sw & ~kPieceNeg);
+        const long long e = (long long)(pp.start[j + 1] & ~kPieceNeg);
+        const long long base = pp.base[j];
+        const bool neg = (sw & kPieceNeg) != 0;
+        for (long long pos = s + lane; pos < e; pos += kWave) stage[pos - beg] = source.cov[neg ? base - pos : base + pos];
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (one wave: its LDS operations complete in order)
+}
+
+// float64 walk of one too-close-to-call ORF by one wave, the tie replay if need be, and the stores
+// (the integer results of the fp32 pass stand: they are exact)
+template <typename Counts>
+__device__ __forceinline__ void finish_unsafe(Counts v, long long orf, long long len, long long count, int min_codon, unsigned split,
+                                              int lane, ReplayLds *replay, const OrfOutputs &out, const FilterParams &fp)
+{
+    WalkResult<double> w;
+    wave_walk<double>(v, len, lane, w);
+    FrameScore fr2[3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f)
+        fr2[f] = frame_score(wave_sum(w.acc[f].p), wave_sum(w.acc[f].q), wave_sum(w.acc[f].n), wave_sum(w.acc[f].m));
+    double phase;
+    int valid;
+    unsigned flags;
+    combine_frames(fr2, phase, valid, flags);
+    if (flags & RP_FLAG_TIE) {
+        const bool big = replay_tie_wave(v, len, lane, phase, valid, replay);
+        flags |= RP_FLAG_REPLAY | (big ? RP_FLAG_BIGTIE : 0u);
+    }
+    if (lane == 0) store_orf(out, fp, orf, phase, valid, count, min_codon, flags | split | RP_FLAG_RECHECK64, len);
+}
 
 template <int TILE, typename Source>
 __global__ __launch_bounds__(kFinishBlock) void k_orf_finish(Source source,
@@ -1039,64 +1062,52 @@ __global__ __launch_bounds__(kFinishBlock) void k_orf_finish(Source source,
                                                              TileWorkspace ws, OrfOutputs out,
                                                              FilterParams fp)
 {
+    constexpr bool kStaged = sizeof(Source) != sizeof(CsrSource);  // the fused path reads through the gather plan
     __shared__ ReplayLds s_replay;  // (one wave per workgroup)
+    __shared__ int s_stage[kStaged ? kStageNt + 8 : 1];
     const int lane = threadIdx.x;
     const long long orf = (long long)blockIdx.x * kFinishBlock + lane;
     long long beg = 0, len = 0, count = 0;
     int min_codon = RP_MIN_CODON_COV_EMPTY;
     unsigned split = 0;
     bool unsafe = false;
-    bool walked = false;  // no record was read: read count and minimum codon come from the re-walk
     if (orf < n_orfs) {
         beg = offsets[orf];
         len = (long long)offsets[orf + 1] - beg;
         double p[3] = {0, 0, 0}, q[3] = {0, 0, 0};
         int n[3] = {0, 0, 0}, m[3] = {0, 0, 0};
-        bool settled = false;  // the scoring kernel has stored this ORF's outputs already
         if (len > 0) {
             const long long b_first = (beg + plan.mis) / TILE;
             const long long b_last = (beg + len - 1 + plan.mis) / TILE;
-            if (RP_INKERNEL_FINISH && b_first == b_last) {
-                // an ORF inside one tile: finished by k_tile_score, unless too close to call there
-                // (then nothing but the pending mark exists: the re-walk below supplies everything)
-                walked = true;
-                if (out.flags[orf] == (uint8_t)kFlagPending)
-                    unsafe = true;
-                else
-                    settled = true;
-            } else {
-                for (long long b = b_first; b <= b_last; ++b) {  // tile order: deterministic sums
-                    const uint4 w0 = ws.rec[orf + b], w1 = ws.rec[ws.n_rec + orf + b], w2 = ws.rec[2 * ws.n_rec + orf + b];
-                    p[0] += (double)__uint_as_float(w0.x);
-                    q[0] += (double)__uint_as_float(w0.y);
-                    p[1] += (double)__uint_as_float(w1.x);
-                    q[1] += (double)__uint_as_float(w1.y);
-                    p[2] += (double)__uint_as_float(w2.x);
-                    q[2] += (double)__uint_as_float(w2.y);
-                    n[0] += (int)(w0.z & 0xffffu);
-                    m[0] += (int)(w0.z >> 16);
-                    n[1] += (int)(w1.z & 0xffffu);
-                    m[1] += (int)(w1.z >> 16);
-                    n[2] += (int)(w2.z & 0xffffu);
-                    m[2] += (int)(w2.z >> 16);
-                    count += (long long)(((unsigned long long)w1.w << 32) | w0.w);
-                    min_codon = min(min_codon, (int)w2.w);
-                }
-                if (b_last > b_first) split = RP_FLAG_SPLIT;
+            for (long long b = b_first; b <= b_last; ++b) {  // tile order: deterministic sums
+                const uint4 w0 = ws.rec[orf + b], w1 = ws.rec[ws.n_rec + orf + b], w2 = ws.rec[2 * ws.n_rec + orf + b];
+                p[0] += (double)__uint_as_float(w0.x);
+                q[0] += (double)__uint_as_float(w0.y);
+                p[1] += (double)__uint_as_float(w1.x);
+                q[1] += (double)__uint_as_float(w1.y);
+                p[2] += (double)__uint_as_float(w2.x);
+                q[2] += (double)__uint_as_float(w2.y);
+                n[0] += (int)(w0.z & 0xffffu);
+                m[0] += (int)(w0.z >> 16);
+                n[1] += (int)(w1.z & 0xffffu);
+                m[1] += (int)(w1.z >> 16);
+                n[2] += (int)(w2.z & 0xffffu);
+                m[2] += (int)(w2.z >> 16);
+                count += (long long)(((unsigned long long)w1.w << 32) | w0.w);
+                min_codon = min(min_codon, (int)w2.w);
             }
+            if (b_last > b_first) split = RP_FLAG_SPLIT;
         }
-        if (!settled && !unsafe) {
-            FrameScore fr[3];
+        FrameScore fr[3];
 #pragma unroll
-            for (int f = 0; f < 3; ++f) fr[f] = frame_score(p[f], q[f], n[f], m[f]);
-            double phase;
-            int valid;
-            unsigned flags;
-            combine_frames(fr, phase, valid, flags);
-            // re-walk in float64 when the frame decision OR the cutoff comparison is too close to call
-            unsafe = fp32_decision_unsafe(fr, /*tile_sums=*/true) || near_cutoff(fp, phase);
-            if (!unsafe) store_orf(out, fp, orf, phase, valid, count, min_codon, flags | split, len);
-        }
+        for (int f = 0; f < 3; ++f) fr[f] = frame_score(p[f], q[f], n[f], m[f]);
+        double phase;
+        int valid;
+        unsigned flags;
+        combine_frames(fr, phase, valid, flags);
+        // re-walk in float64 when the frame decision OR the cutoff comparison is too close to call
+        unsafe = fp32_decision_unsafe(fr, /*tile_sums=*/true) || near_cutoff(fp, phase);
+        if (!unsafe) store_orf(out, fp, orf, phase, valid, count, min_codon, flags | split, len);
     }
 
     // The too-close-to-call ORFs of this wave (~0.4 %), one after the other, by the whole wave:
@@ -1109,34 +1120,22 @@ __global__ __launch_bounds__(kFinishBlock) void k_orf_finish(Source source,
         const long long orf_s = readlane64(orf, l);
         const long long beg_s = readlane64(beg, l);
         const long long len_s = readlane64(len, l);
-        long long count_s = readlane64(count, l);
-        int min_s = __builtin_amdgcn_readlane(min_codon, l);
+        const long long count_s = readlane64(count, l);
+        const int min_s = __builtin_amdgcn_readlane(min_codon, l);
         const unsigned split_s = (unsigned)__builtin_amdgcn_readlane((int)split, l);
-        const bool walked_s = __builtin_amdgcn_readlane((int)walked, l) != 0;
         if (len_s > kLongWalk) {  // a whole workgroup takes it (k_rewalk_long)
             if (lane == 0) ws.long_list[atomicAdd(ws.long_count, 1)] = orf_s;
             continue;
         }
-        WalkResult<double> w;
-        wave_walk<double>(source.orf(orf_s, beg_s), len_s, lane, w);
-        if (walked_s) {  // (wave-uniform) an ORF the scoring kernel left pending: the walk's own integer sums
-            count_s = wave_sum(w.count);
-            min_s = wave_min(w.min_codon);
+        if constexpr (kStaged) {
+            if (len_s <= kStageNt) {
+                stage_profile(source, orf_s, beg_s, s_stage, lane);
+                finish_unsafe(static_cast<const int *>(s_stage), orf_s, len_s, count_s, min_s, split_s, lane, &s_replay, out, fp);
+                __builtin_amdgcn_wave_barrier();  // (the stage is rewritten by the next item)
+                continue;
+            }
         }
-        FrameScore fr2[3];
-#pragma unroll
-        for (int f = 0; f < 3; ++f)
-            fr2[f] = frame_score(wave_sum(w.acc[f].p), wave_sum(w.acc[f].q), wave_sum(w.acc[f].n), wave_sum(w.acc[f].m));
-        double phase;
-        int valid;
-        unsigned flags;
-        combine_frames(fr2, phase, valid, flags);
-        if (flags & RP_FLAG_TIE) {
-            const bool big = replay_tie_wave(source.orf(orf_s, beg_s), len_s, lane, phase, valid, &s_replay);
-            flags |= RP_FLAG_REPLAY | (big ? RP_FLAG_BIGTIE : 0u);
-        }
-        if (lane == 0)
-            store_orf(out, fp, orf_s, phase, valid, count_s, min_s, flags | split_s | RP_FLAG_RECHECK64, len_s);
+        finish_unsafe(source.orf(orf_s, beg_s), orf_s, len_s, count_s, min_s, split_s, lane, &s_replay, out, fp);
     }
 }
 

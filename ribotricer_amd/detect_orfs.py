@@ -249,8 +249,13 @@ def export_orf_coverages(
     min_density_over_orf: float = MINIMUM_DENSITY_OVER_ORF,
     report_all: bool = False,
     devices=None,
+    timings: dict | None = None,
 ) -> None:
     """Write ``{prefix}_translating_ORFs.tsv`` -- drop-in for detect_orfs.py:206-324.
+
+    ``timings`` (beyond the reference's signature): a dict that receives the wall time of every
+    stage in seconds (index parse, coverage build, interval table + plans, device scoring, profiles
+    back to the host, TSV rendering + write) -- what scripts/bench_export_big.py reports.
 
     ``devices`` (beyond the reference's signature; default: ``RIBOTRICER_AMD_DEVICES`` or the
     current GPU): the GPUs to shard the candidate ORFs over -- contiguous nt-balanced slices of
@@ -266,23 +271,31 @@ def export_orf_coverages(
     from . import tsv
     from .index import NativeIndex
 
+    import time
+
+    t0 = time.perf_counter()
     index = NativeIndex.from_file(ribotricer_index)
+    if timings is not None:
+        timings["index_parse"] = time.perf_counter() - t0
     if devices is None:
         devices = _devices_from_env()
     counts, offsets, res = score_index(
         index, merged_alignments, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
-        min_valid_codons_ratio, min_density_over_orf, report_all, devices,
+        min_valid_codons_ratio, min_density_over_orf, report_all, devices, timings=timings,
     )
+    t0 = time.perf_counter()
     with open(f"{prefix}_translating_ORFs.tsv", "wb") as output:
         output.write(("\t".join(COLUMNS) + "\n").encode("utf-8"))
         for chunk in tsv.format_rows_native(
-            counts, offsets, res["phase"], res["valid"], res["read_count"], res["status"], index.tables, report_all
+            counts, offsets, res["phase"], res["valid"], res["read_count"], res["status"], index.tables_native, report_all
         ):
             output.write(chunk)
+    if timings is not None:
+        timings["tsv_render_write"] = time.perf_counter() - t0
 
 
 def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
-                min_valid_codons_ratio, min_density_over_orf, report_all: bool, devices=None):
+                min_valid_codons_ratio, min_density_over_orf, report_all: bool, devices=None, timings=None):
     """Gather + score for a natively parsed index: ``(counts, offsets, results)`` as host arrays,
     ready for the row formatter.
 
@@ -300,10 +313,21 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     from .engine import resolve_big_ties
     from .gather import coverage_profiles_of, gather_profiles_device, interval_table_from_index, make_gather_plan, select_orfs
 
+    import time
+
+    def lap(name, since):
+        if timings is not None:
+            torch.cuda.synchronize()
+            timings[name] = timings.get(name, 0.0) + time.perf_counter() - since
+        return time.perf_counter()
+
     device = None if not devices else f"cuda:{int(devices[0])}"
+    t = time.perf_counter()
     coverage, base = build_coverage_device(merged_alignments, index, device)
+    t = lap("coverage_build", t)
     table = interval_table_from_index(index, base)
     plan = make_gather_plan(table, coverage.numel(), device)
+    t = lap("interval_table_gather_plan", t)
     sharded = devices is not None and len(devices) > 1
     if plan is None or report_all:
         d_counts, d_offsets = gather_profiles_device(coverage, table, device, plan=plan)
@@ -311,7 +335,10 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
             d_counts, d_offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
             min_valid_codons_ratio, min_density_over_orf, device=device, devices=devices,
         )
-        return d_counts.cpu().numpy(), d_offsets.cpu().numpy(), res
+        t = lap("gather_score_results_d2h", t)
+        out = d_counts.cpu().numpy(), d_offsets.cpu().numpy(), res
+        lap("profiles_d2h", t)
+        return out
     thresholds = make_filter(
         phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio, min_density_over_orf
     )
@@ -326,12 +353,15 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
         torch.cuda.synchronize(eng.device)
         res = res.cpu_numpy()
         resolve_big_ties(res, coverage_profiles_of(coverage, table, device), thresholds)
+    t = lap("fused_score_results_d2h", t)
     keep = res["status"] != 0
     chosen = np.flatnonzero(keep)
     d_counts, _ = gather_profiles_device(coverage, select_orfs(table, chosen), device)
     offsets = np.zeros(index.n_orfs + 1, np.int64)
     np.cumsum(np.where(keep, np.diff(table.offsets), 0), out=offsets[1:])
-    return d_counts.cpu().numpy(), offsets, res
+    out = d_counts.cpu().numpy(), offsets, res
+    lap("translating_profiles_gather_d2h", t)
+    return out
 
 
 def export_wig(merged_alignments, prefix: str) -> None:

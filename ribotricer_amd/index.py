@@ -34,12 +34,23 @@ def _array(ptr, n, dtype):
     return np.frombuffer(buf, dtype=dtype, count=n).copy()
 
 
+def _view(ptr, n, dtype):
+    """numpy view (no copy) of n items of the library's memory at ptr -- valid while the owner lives"""
+    if n == 0:
+        return np.zeros(0, dtype)
+    buf = (ctypes.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    a = np.frombuffer(buf, dtype=dtype, count=n)
+    a.flags.writeable = False
+    return a
+
+
 def _bytes(ptr, n):
     return ctypes.string_at(ptr, n) if n else b""
 
 
 class NativeIndex:
-    """Arrays of a parsed index (host numpy copies; the C++ object is freed at once)."""
+    """Arrays of a parsed index.  The arrays are VIEWS of the C++ object's memory (an 11 M-line index
+    is 2 GB of them: no second copy), which lives as long as this object does."""
 
     def __init__(self, text: bytes, skip_header: bool = True):
         lib = _lib.load()
@@ -54,30 +65,49 @@ class NativeIndex:
                 )
             )
         _lib.check(rc)
-        try:
-            v = _View()
-            _lib.check(lib.rp_index_view_host(handle, ctypes.byref(v)))
-            n, m, g = v.n_orfs, v.n_intervals, v.n_groups
-            self.n_orfs = int(n)
-            self.orf_iv = _array(v.orf_iv, n + 1, np.int64)
-            self.length = _array(v.length, n, np.int64)
-            self.group = _array(v.group, n, np.int32)
-            self.reverse = _array(v.reverse, n, np.uint8)
-            self.iv_start = _array(v.iv_start, m, np.int64)
-            self.iv_end = _array(v.iv_end, m, np.int64)
-            group_off = _array(v.group_off, g + 1, np.int64)
-            names = _bytes(v.group_names, int(group_off[-1]))
-            self.group_keys = [
-                tuple(names[group_off[k] : group_off[k + 1]].decode("utf-8").split("\t", 1)) for k in range(g)
-            ]  # (strand, chrom)
-            self.group_lo = _array(v.group_lo, g, np.int64)
-            self.group_hi = _array(v.group_hi, g, np.int64)
-            self.head_off = _array(v.head_off, n + 1, np.int64)
-            self.head = _bytes(v.head, int(self.head_off[-1]))
-            self.tail_off = _array(v.tail_off, n + 1, np.int64)
-            self.tail = _bytes(v.tail, int(self.tail_off[-1]))
-        finally:
-            lib.rp_index_free(handle)
+        self._handle = handle
+        v = _View()
+        _lib.check(lib.rp_index_view_host(handle, ctypes.byref(v)))
+        n, m, g = v.n_orfs, v.n_intervals, v.n_groups
+        self.n_orfs = int(n)
+        self.orf_iv = _view(v.orf_iv, n + 1, np.int64)
+        self.length = _view(v.length, n, np.int64)
+        self.group = _view(v.group, n, np.int32)
+        self.reverse = _view(v.reverse, n, np.uint8)
+        self.iv_start = _view(v.iv_start, m, np.int64)
+        self.iv_end = _view(v.iv_end, m, np.int64)
+        group_off = _array(v.group_off, g + 1, np.int64)
+        names = _bytes(v.group_names, int(group_off[-1]))
+        self.group_keys = [
+            tuple(names[group_off[k] : group_off[k + 1]].decode("utf-8").split("\t", 1)) for k in range(g)
+        ]  # (strand, chrom)
+        self.group_lo = _array(v.group_lo, g, np.int64)
+        self.group_hi = _array(v.group_hi, g, np.int64)
+        self.head_off = _view(v.head_off, n + 1, np.int64)
+        self.tail_off = _view(v.tail_off, n + 1, np.int64)
+        self._head_ptr, self._tail_ptr = v.head, v.tail
+        self._head = self._tail = None
+
+    def __del__(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            try:
+                _lib.load().rp_index_free(h)
+            except Exception:  # pragma: no cover - interpreter shutdown
+                pass
+
+    @property
+    def head(self) -> bytes:
+        """``ORF_ID\\tORF_type`` of every ORF, concatenated (a copy: tests and small inputs)."""
+        if self._head is None:
+            self._head = _bytes(self._head_ptr, int(self.head_off[-1]) if self.n_orfs else 0)
+        return self._head
+
+    @property
+    def tail(self) -> bytes:
+        if self._tail is None:
+            self._tail = _bytes(self._tail_ptr, int(self.tail_off[-1]) if self.n_orfs else 0)
+        return self._tail
 
     @classmethod
     def from_file(cls, path: str) -> "NativeIndex":
@@ -86,8 +116,20 @@ class NativeIndex:
 
     @property
     def tables(self):
-        """(head, head_off, tail, tail_off) as ``tsv.format_rows_native`` takes them."""
+        """(head, head_off, tail, tail_off) as ``tsv.format_rows_native`` takes them (byte copies)."""
         return self.head, self.head_off, self.tail, self.tail_off
+
+    @property
+    def tables_native(self):
+        """The same without copying the two string tables (700 MB for an 11 M-line index): ctypes
+        views of the library's memory; they keep this object alive."""
+        out = []
+        for ptr, off in ((self._head_ptr, self.head_off), (self._tail_ptr, self.tail_off)):
+            n = int(off[-1]) if self.n_orfs else 0
+            buf = (ctypes.c_char * max(1, n)).from_address(ptr) if n else ctypes.create_string_buffer(1)
+            buf._owner = self
+            out += [buf, off]
+        return tuple(out)
 
     @property
     def extents(self) -> dict:

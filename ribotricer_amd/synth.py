@@ -11,6 +11,7 @@ gencode  a candidate-index-like law (prepare_orfs.py:217 emits every uORF / dORF
       ORF >= --min_orf_length, cli.py:64-69): 60 % of the ORFs short, uniform 20..50 codons
       (60-150 nt), the rest cfg3's lognormal with median 120 codons.
 gencode_short  the same with 70 % short ORFs (a uORF / dORF-dominated candidate set): mean ~200 nt.
+short150  every ORF 60-150 nt (uniform).
 orf60  every ORF 60 nt, the CLI minimum: the worst case for per-segment overheads.
 
 Lengths always come from numpy (identical on every machine for a given seed).  Counts
@@ -28,6 +29,7 @@ CONFIGS = {
     "cfg5": dict(sigma=0.7, median_codons=78, frac_non_mult3=0.01, pareto_frac=0.02),
     "gencode": dict(sigma=0.9, median_codons=120, frac_non_mult3=0.01, pareto_frac=0.0, short_frac=0.6),
     "gencode_short": dict(sigma=0.9, median_codons=100, frac_non_mult3=0.01, pareto_frac=0.0, short_frac=0.7),
+    "short150": dict(sigma=0.9, median_codons=80, frac_non_mult3=0.0, pareto_frac=0.0, short_frac=1.0),
     "orf60": dict(sigma=0.9, median_codons=80, frac_non_mult3=0.0, pareto_frac=0.0, short_frac=1.0, short_codons=(20, 21)),
 }
 LAMBDAS = np.array([0.0, 0.05, 0.3, 2.0])

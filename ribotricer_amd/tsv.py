@@ -117,8 +117,12 @@ def format_rows_native(
     last = n if last is None else last
     if not (phase.size == valid.size == read_count.size == status.size == n == head_off.size - 1 == tail_off.size - 1):
         raise ValueError("per-ORF arrays and string tables must all have n_orfs entries")
-    head_buf = ctypes.create_string_buffer(head, len(head)) if head else ctypes.create_string_buffer(1)
-    tail_buf = ctypes.create_string_buffer(tail, len(tail)) if tail else ctypes.create_string_buffer(1)
+    def c_buffer(table):  # bytes are copied once; a ctypes view (NativeIndex.tables_native) is used as it is
+        if isinstance(table, (bytes, bytearray)):
+            return ctypes.create_string_buffer(bytes(table), len(table)) if table else ctypes.create_string_buffer(1)
+        return table
+
+    head_buf, tail_buf = c_buffer(head), c_buffer(tail)
     arrays = (counts, offsets, phase, valid, read_count, status)
     tables_c = (head_buf, np.ascontiguousarray(head_off, dtype=np.int64), tail_buf, np.ascontiguousarray(tail_off, dtype=np.int64))
     total_nt = int(offsets[last] - offsets[first]) if last > first else 0

@@ -19,7 +19,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def one(cfg, n_orfs, calls):
+def one(cfg, n_orfs, calls, fused=False):
     sys.path.insert(0, REPO)
     import numpy as np
     import torch
@@ -59,9 +59,25 @@ def one(cfg, n_orfs, calls):
         eng.score(counts, offsets, thresholds=th, algo="tile", reuse_outputs=True)
     e1.record()
     torch.cuda.synchronize()
-    print(json.dumps({"ok": ok, "msg": msg, "main_ms": statistics.median(x[1] for x in t),
-                      "finish_ms": statistics.median(x[2] for x in t), "step_ms": e0.elapsed_time(e1) / calls,
-                      "nt": counts.numel(), "n": offsets.numel() - 1}))
+    res = {"ok": ok, "msg": msg, "main_ms": statistics.median(x[1] for x in t),
+           "finish_ms": statistics.median(x[2] for x in t), "step_ms": e0.elapsed_time(e1) / calls,
+           "nt": counts.numel(), "n": offsets.numel() - 1}
+    if fused:  # the fused gather + score on an exon layout of the same length law (synth_exon_layout)
+        from ribotricer_amd.gather import GatherPlan, IntervalTable
+        from ribotricer_amd.synth import orf_lengths, synth_coverage_device, synth_exon_layout
+
+        del counts
+        lay = synth_exon_layout(orf_lengths(n_orfs, 20260213, cfg), 20260213)
+        cov = synth_coverage_device(lay[5], 20260213, device="cuda:0")
+        gplan = GatherPlan(IntervalTable(*lay[:5]), lay[5], "cuda:0")
+        for _ in range(5):
+            eng.score_coverage(cov, gplan, thresholds=th, reuse_outputs=True)
+        tf = []
+        for _ in range(calls):
+            eng.score_coverage(cov, gplan, thresholds=th, reuse_outputs=True, timings=tf)
+        res["fused_main_ms"] = statistics.median(x[1] for x in tf)
+        res["fused_finish_ms"] = statistics.median(x[2] for x in tf)
+    print(json.dumps(res))
 
 
 def main():
@@ -71,9 +87,10 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--calls", type=int, default=40)
     ap.add_argument("--one", nargs=2)
+    ap.add_argument("--fused", action="store_true", help="also time the fused gather + score on an exon layout of the same law")
     a = ap.parse_args()
     if a.one:
-        one(a.one[0], int(a.one[1]), a.calls)
+        one(a.one[0], int(a.one[1]), a.calls, a.fused)
         return
     variants = [v.split("=", 1) for v in a.variants]
     cfgs = [c.split(":") for c in a.cfgs.split(",")]
@@ -82,7 +99,7 @@ def main():
         for name, path in variants:
             for cfg, n in cfgs:
                 env = dict(os.environ, RIBOPHASE_LIB=os.path.abspath(path))
-                out = subprocess.run([sys.executable, __file__, "--one", cfg, n, "--calls", str(a.calls)], env=env,
+                out = subprocess.run([sys.executable, __file__, "--one", cfg, n, "--calls", str(a.calls)] + (["--fused"] if a.fused else []), env=env,
                                      capture_output=True, text=True, timeout=600)
                 line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
                 if out.returncode != 0 or not line:
@@ -104,6 +121,7 @@ def main():
         par = "ok" if all(x["ok"] for x in good) else "BAD"
         print(f"{name:<14} {cfg:<6} {par:<7} {' '.join(f'{m:.4f}' for m in mains):<34} {best:8.4f} {gbs:7.0f} {gbs / 8000:6.3f} "
               f"{min(x['finish_ms'] for x in good):8.4f} {min(x['step_ms'] for x in good):8.4f}"
+              + (f"   fused {min(x['fused_main_ms'] for x in good):8.4f} + {min(x['fused_finish_ms'] for x in good):7.4f}" if "fused_main_ms" in good[0] else "")
               + ("   " + good[0]["msg"] if par == "BAD" else ""), flush=True)
 
 

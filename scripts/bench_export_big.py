@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Human-scale end-to-end run of the drop-in `export_orf_coverages` (detect_orfs.py:206-324) on the
+GPU box: an 11 M-line synthetic candidate index (scripts/gen_big_index.cpp: transcripts with nested
+candidate ORFs, 65 % of them 60-150 nt) + 1e8 merged alignment entries, default mode and
+`report_all`; per-stage wall times as JSON.
+usage: python scripts/bench_export_big.py [n_orfs] [n_alignment_entries] [out.json]"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from ribotricer_amd import detect_orfs as d  # noqa: E402
+from ribotricer_amd.alignments import MergedColumns  # noqa: E402
+
+n_orfs = int(sys.argv[1]) if len(sys.argv) > 1 else 11_000_000
+n_align = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000_000
+out_json = sys.argv[3] if len(sys.argv) > 3 else None
+tmp = tempfile.mkdtemp(prefix="rpbig_")
+exe = os.path.join(tmp, "gen_big_index")
+subprocess.check_call(["g++", "-O2", "-o", exe, os.path.join(REPO, "scripts", "gen_big_index.cpp")])
+prefix = os.path.join(tmp, "big")
+t0 = time.perf_counter()
+subprocess.check_call([exe, prefix, str(n_orfs)])
+gen_s = time.perf_counter() - t0
+index_path = prefix + "_candidate_orfs.tsv"
+# alignment entries: positions drawn on the exons of random ORFs (12 bytes of histogram row each)
+ex = np.fromfile(prefix + "_exons.bin", dtype=np.dtype([("chrom", "<i4"), ("strand", "<i4"), ("start", "<i8"), ("end", "<i8")]))
+rng = np.random.default_rng(3)
+pick = rng.integers(0, ex.size, n_align)
+pos = ex["start"][pick] + (rng.random(n_align) * (ex["end"][pick] - ex["start"][pick] + 1)).astype(np.int64)
+cols = MergedColumns(ex["strand"][pick].astype(np.uint8), ex["chrom"][pick].astype(np.int32), pos, np.ones(n_align, np.int64) + (rng.random(n_align) < 0.2),
+                     [f"chr{k}" for k in range(1, 25)])
+del ex, pick, pos
+torch.zeros(1, device="cuda")
+report = {"n_orfs": n_orfs, "alignment_entries": n_align, "index_bytes": os.path.getsize(index_path), "generate_index_s": gen_s,
+          "host_cores": len(os.sched_getaffinity(0))}
+for mode, report_all in (("default", False), ("report_all", True)):
+    tm: dict = {}
+    t0 = time.perf_counter()
+    d.export_orf_coverages(index_path, cols, prefix + "_" + mode, report_all=report_all, timings=tm)
+    wall = time.perf_counter() - t0
+    out_path = prefix + "_" + mode + "_translating_ORFs.tsv"
+    with open(out_path, "rb") as fh:
+        rows = sum(buf.count(b"\n") for buf in iter(lambda: fh.read(1 << 26), b"")) - 1
+    report[mode] = {"wall_s": wall, "stages_s": tm, "tsv_bytes": os.path.getsize(out_path), "rows": rows}
+    os.remove(out_path)
+# the device work alone, for the ratio: fused score of the whole index (HIP events inside the library)
+from ribotricer_amd.alignments import build_coverage_device  # noqa: E402
+from ribotricer_amd.engine import get_engine, make_filter  # noqa: E402
+from ribotricer_amd.gather import interval_table_from_index, make_gather_plan  # noqa: E402
+from ribotricer_amd.index import NativeIndex  # noqa: E402
+
+index = NativeIndex.from_file(index_path)
+coverage, base = build_coverage_device(cols, index)
+table = interval_table_from_index(index, base)
+plan = make_gather_plan(table, coverage.numel())
+eng = get_engine("cuda:0")
+tm = []
+for _ in range(5):
+    eng.score_coverage(coverage, plan, thresholds=make_filter(), reuse_outputs=True, timings=tm)
+report["device"] = {"fused_score_ms": min(t[3] for t in tm), "kernel_ms": min(t[1] for t in tm), "finish_ms": min(t[2] for t in tm),
+                    "total_nt": int(table.offsets[-1]), "coverage_positions": int(coverage.numel()), "exons": int(table.iv_start.size)}
+print(json.dumps(report, indent=1))
+if out_json:
+    with open(out_json, "w") as fh:
+        json.dump(report, fh, indent=1)
