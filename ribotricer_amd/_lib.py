@@ -185,3 +185,17 @@ def tie_replay_host(values, offsets):
     fn = load().rp_tie_replay_f64_host if is_float else load().rp_tie_replay_host
     check(fn(values.ctypes.data if values.size else None, offsets.ctypes.data, n, phase.ctypes.data, valid.ctypes.data))
     return phase, valid
+
+
+def usable_cores() -> int:
+    """Cores this process may really use: the scheduler affinity, capped by the cgroup CPU quota
+    (a container may show 256 CPUs and own 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)

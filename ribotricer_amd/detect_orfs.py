@@ -281,23 +281,70 @@ def export_orf_coverages(
         devices = _devices_from_env()
     counts, offsets, res = score_index(
         index, merged_alignments, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
-        min_valid_codons_ratio, min_density_over_orf, report_all, devices, timings=timings,
+        min_valid_codons_ratio, min_density_over_orf, report_all, devices, timings=timings, profiles_on_device=True,
     )
     t0 = time.perf_counter()
+    tables = index.tables_native
     with open(f"{prefix}_translating_ORFs.tsv", "wb") as output:
         output.write(("\t".join(COLUMNS) + "\n").encode("utf-8"))
-        for chunk in tsv.format_rows_native(
-            counts, offsets, res["phase"], res["valid"], res["read_count"], res["status"], index.tables_native, report_all
-        ):
-            output.write(chunk)
+        # the profiles come back from the device in slices (pinned staging buffers, the copy of slice
+        # k+1 behind the rendering of slice k): a human-sized `report_all` run prints 14 GB of them
+        for a, b, part in _profile_slices(counts, offsets):
+            sliced = (tables[0], tables[1][a : b + 1], tables[2], tables[3][a : b + 1])
+            for chunk in tsv.format_rows_native(
+                part, offsets[a : b + 1] - offsets[a], res["phase"][a:b], res["valid"][a:b], res["read_count"][a:b],
+                res["status"][a:b], sliced, report_all,
+            ):
+                output.write(chunk)
     if timings is not None:
-        timings["tsv_render_write"] = time.perf_counter() - t0
+        timings["profiles_d2h_tsv_render_write"] = time.perf_counter() - t0
+
+
+def _profile_slices(counts, offsets, slice_nt: int = 64 << 20):
+    """Yield ``(a, b, counts[offsets[a]:offsets[b]] as a host array)`` over consecutive ORF ranges of
+    about ``slice_nt`` nucleotides.  ``counts``: a host array (sliced in place) or a device tensor
+    (copied slice by slice through two pinned buffers, the next copy in flight while the caller works
+    on the current one)."""
+    import torch
+
+    n = offsets.size - 1
+    total = int(offsets[-1]) if n >= 0 else 0
+    if n <= 0:
+        return
+    cuts = np.searchsorted(offsets, np.arange(slice_nt, total, slice_nt), side="right") - 1
+    bounds = np.unique(np.concatenate(([0], cuts, [n]))).astype(np.int64)
+    ranges = [(int(a), int(b)) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+    if not isinstance(counts, torch.Tensor):
+        for a, b in ranges:
+            yield a, b, counts[int(offsets[a]) : int(offsets[b])]
+        return
+    widest = max(int(offsets[b] - offsets[a]) for a, b in ranges)
+    side = torch.cuda.Stream(device=counts.device)
+    side.wait_stream(torch.cuda.current_stream(counts.device))
+    bufs = [torch.empty(max(1, widest), dtype=torch.int32, pin_memory=True) for _ in range(2)]
+    done = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def fetch(k):
+        a, b = ranges[k]
+        lo, hi = int(offsets[a]), int(offsets[b])
+        with torch.cuda.stream(side):
+            bufs[k % 2][: hi - lo].copy_(counts[lo:hi], non_blocking=True)
+            done[k % 2].record(side)
+
+    fetch(0)
+    for k, (a, b) in enumerate(ranges):
+        done[k % 2].synchronize()
+        if k + 1 < len(ranges):
+            fetch(k + 1)
+        yield a, b, bufs[k % 2][: int(offsets[b] - offsets[a])].numpy()
 
 
 def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
-                min_valid_codons_ratio, min_density_over_orf, report_all: bool, devices=None, timings=None):
+                min_valid_codons_ratio, min_density_over_orf, report_all: bool, devices=None, timings=None,
+                profiles_on_device: bool = False):
     """Gather + score for a natively parsed index: ``(counts, offsets, results)`` as host arrays,
-    ready for the row formatter.
+    ready for the row formatter (``profiles_on_device``: ``counts`` stays a device tensor, for
+    ``_profile_slices``).
 
     ``report_all`` (every profile is printed, detect_orfs.py:301-324): the whole CSR counts array
     is gathered (tile kernel through the index's gather plan), scored, copied back.  Default mode
@@ -336,6 +383,8 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
             min_valid_codons_ratio, min_density_over_orf, device=device, devices=devices,
         )
         t = lap("gather_score_results_d2h", t)
+        if profiles_on_device:  # (the caller streams them back slice by slice: _profile_slices)
+            return d_counts, d_offsets.cpu().numpy(), res
         out = d_counts.cpu().numpy(), d_offsets.cpu().numpy(), res
         lap("profiles_d2h", t)
         return out
@@ -359,6 +408,9 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     d_counts, _ = gather_profiles_device(coverage, select_orfs(table, chosen), device)
     offsets = np.zeros(index.n_orfs + 1, np.int64)
     np.cumsum(np.where(keep, np.diff(table.offsets), 0), out=offsets[1:])
+    if profiles_on_device:
+        lap("translating_profiles_gather", t)
+        return d_counts, offsets, res
     out = d_counts.cpu().numpy(), offsets, res
     lap("translating_profiles_gather_d2h", t)
     return out

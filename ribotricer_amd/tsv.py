@@ -105,7 +105,7 @@ def format_rows_native(
     ``chunk_bytes`` (a single longer row gets a buffer of its own).
 
     ``threads`` > 1 renders disjoint ORF ranges concurrently (the C call holds no shared
-    state and ctypes drops the GIL); default: up to 8, one for small batches."""
+    state and ctypes drops the GIL); default: the usable cores (at most 32), one for small batches."""
     counts = np.ascontiguousarray(counts, dtype=np.int32)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     phase = np.ascontiguousarray(phase, dtype=np.float64)
@@ -127,7 +127,7 @@ def format_rows_native(
     tables_c = (head_buf, np.ascontiguousarray(head_off, dtype=np.int64), tail_buf, np.ascontiguousarray(tail_off, dtype=np.int64))
     total_nt = int(offsets[last] - offsets[first]) if last > first else 0
     if threads is None:
-        threads = min(8, os.cpu_count() or 1) if total_nt > (4 << 20) else 1
+        threads = min(32, _lib.usable_cores()) if total_nt > (4 << 20) else 1
     if threads <= 1 or last - first < 2:
         yield from _format_range(arrays, tables_c, report_all, first, last, chunk_bytes)
         return
