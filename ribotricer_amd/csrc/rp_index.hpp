@@ -161,6 +161,8 @@ inline int parse_run(const char *text, size_t len, bool skip_header, Index &ix)
     std::unordered_map<std::string, int32_t> groups;
     std::vector<std::pair<int64_t, int64_t>> blocks;
     std::string key;
+    std::string_view last_strand, last_chrom;
+    int32_t last_gid = -1;
     size_t pos = 0;
     int64_t line_no = 0;
     while (pos < len) {
@@ -219,23 +221,33 @@ inline int parse_run(const char *text, size_t len, bool skip_header, Index &ix)
         ix.length.push_back(length);
         const std::string_view chrom = f[7], strand = f[8];
         ix.reverse.push_back(strand == "-" ? 1 : 0);
-        // (strand, chrom) group
-        key.assign(strand);
-        key.push_back('\t');
-        key.append(chrom);
-        auto it = groups.find(key);
+        // (strand, chrom) group; an index lists the ORFs of a transcript -- of a chromosome -- together,
+        // so the previous line's group is nearly always this line's: no hashing then
         int32_t gid;
-        if (it == groups.end()) {
-            gid = (int32_t)groups.size();
-            groups.emplace(key, gid);
-            ix.group_names.append(key);
-            ix.group_off.push_back((int64_t)ix.group_names.size());
-            ix.group_lo.push_back(first);
-            ix.group_hi.push_back(last);
-        } else {
-            gid = it->second;
+        if (last_gid >= 0 && strand == last_strand && chrom == last_chrom) {
+            gid = last_gid;
             ix.group_lo[gid] = std::min(ix.group_lo[gid], first);
             ix.group_hi[gid] = std::max(ix.group_hi[gid], last);
+        } else {
+            key.assign(strand);
+            key.push_back('\t');
+            key.append(chrom);
+            auto it = groups.find(key);
+            if (it == groups.end()) {
+                gid = (int32_t)groups.size();
+                groups.emplace(key, gid);
+                ix.group_names.append(key);
+                ix.group_off.push_back((int64_t)ix.group_names.size());
+                ix.group_lo.push_back(first);
+                ix.group_hi.push_back(last);
+            } else {
+                gid = it->second;
+                ix.group_lo[gid] = std::min(ix.group_lo[gid], first);
+                ix.group_hi[gid] = std::max(ix.group_hi[gid], last);
+            }
+            last_gid = gid;
+            last_strand = strand;  // (views into `text`, which outlives the run)
+            last_chrom = chrom;
         }
         ix.group.push_back(gid);
         // head: ORF_ID \t ORF_type

@@ -52,11 +52,18 @@ class NativeIndex:
     """Arrays of a parsed index.  The arrays are VIEWS of the C++ object's memory (an 11 M-line index
     is 2 GB of them: no second copy), which lives as long as this object does."""
 
-    def __init__(self, text: bytes, skip_header: bool = True):
+    def __init__(self, text, skip_header: bool = True):
+        """``text``: the index file as bytes, or anything with the buffer protocol (``from_file`` maps
+        the file: the parser threads then read it straight out of the page cache)."""
         lib = _lib.load()
         handle = ctypes.c_void_p()
         bad_line = ctypes.c_int64(0)
-        rc = lib.rp_index_parse_host(text, len(text), int(skip_header), ctypes.byref(handle), ctypes.byref(bad_line))
+        if isinstance(text, (bytes, bytearray)):
+            src, n_text = bytes(text), len(text)
+        else:
+            flat = np.frombuffer(text, dtype=np.uint8)
+            src, n_text = ctypes.c_void_p(flat.ctypes.data if flat.size else 0), int(flat.size)
+        rc = lib.rp_index_parse_host(src, n_text, int(skip_header), ctypes.byref(handle), ctypes.byref(bad_line))
         if rc == RP_ERR_INDEX_COLUMNS:  # what ORF.from_string does (orf.py:143-152)
             sys.exit(
                 "{}\n{}".format(
@@ -111,8 +118,14 @@ class NativeIndex:
 
     @classmethod
     def from_file(cls, path: str) -> "NativeIndex":
+        import mmap
+        import os
+
         with open(path, "rb") as fh:
-            return cls(fh.read(), skip_header=True)  # header line skipped: detect_orfs.py:273
+            if os.fstat(fh.fileno()).st_size == 0:
+                return cls(b"", skip_header=True)
+            with mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+                return cls(mm, skip_header=True)  # header line skipped: detect_orfs.py:273
 
     @property
     def tables(self):
