@@ -14,7 +14,8 @@ A "step" is one pass of the hot path over the rank's slice: libribophase
 rp_phase_score_csr_plan_dev = scoring kernel (rp::k_tile_score) + per-ORF finish kernel.
 The tile plan (tile index + offsets validation, rp_plan_create_dev) depends on the index
 only and is built once before the steps, the way `detect-orfs` reuses one index for every
-sample; its time is reported as `plan_build_ms`.
+sample; its time is reported as `plan_build_ms`, and `value_single_sample` is the rate with
+the plan rebuilt inside every step (an index used for ONE sample).
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
@@ -24,6 +25,11 @@ Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (algorithmic
 B = 4*sum(L) + 8*(n+1) + 24*n per launch over its HIP-event duration, vs the 8 TB/s
 HBM peak); `cpu_baseline` is the literal scipy restatement of the reference's phasescore
 (oracle/phasescore_literal.py) on all host cores, on a bounded sample of the same set.
+AFTER the timed region (N = 1): `verify` -- head / middle / tail slices of 20 000 ORFs and the
+ORFs around 2^31 / 2^32 nt of what the steps computed, against the C oracle on the same bytes
+(integers bit-exact, phase <= 1e-6, exact frame ties bit for bit) -- and `fused` -- the kernel
+the drop-in export path runs by default (gather + score fused, rp::k_tile_score<true>) on an
+exon layout of the same length law, with its own `verify`.
 """
 
 from __future__ import annotations

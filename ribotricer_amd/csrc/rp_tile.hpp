@@ -952,6 +952,9 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
     }
 
     // ---- many short ORFs: > kHeadSlots segments, 64 slots at a time ------------------------------
+    // (128 slots a round -- two table sets, waves {0,1} and {2,3} each walking 64 slots side by side --
+    // was built and measured in round 3: no gain on all-60-nt tiles, the longer runs eat the saved
+    // round, and the extra table indirection cost the common path 6 %: profiles/r03_ab_dual_rounds.txt)
     // Same scheme, minus the head row and the lane map: every wave reads the chunk's descriptors
     // from the per-segment array (slot L of chunk c = ORF a0 - 1 + 64 c + L) and finds its
     // lanes' segments through 64 private words of LDS (marks at the segments' first lanes, then
@@ -1015,18 +1018,25 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
 constexpr int kFinishBlock = kWave;  // one wave per workgroup: a re-walk holds up nobody else
 constexpr int kStageNt = 2040;       // fused path: profiles up to this long are copied to LDS first (8 KB per wave)
 
-// copy the profile of ORF `orf` out of the coverage into `stage`, piece by piece, coalesced
+// copy the profile of ORF `orf` out of the coverage into `stage`, piece by piece, coalesced; the
+// piece descriptors of up to 63 pieces are fetched lane-parallel first (one round trip, not one
+// per piece)
 __device__ __forceinline__ void stage_profile(const CoverageSource &source, long long orf, long long beg, int *stage, int lane)
 {
     const PiecePlan &pp = source.pp;
     const long long j0 = pp.orf_piece[orf], j1 = pp.orf_piece[orf + 1];
-    for (long long j = j0; j < j1; ++j) {  // wave-uniform
-        const unsigned long long sw = pp.start[j];
-        const long long s = (long long)(sw & ~kPieceNeg);
-        const long long e = (long long)(pp.start[j + 1] & ~kPieceNeg);
-        const long long base = pp.base[j];
-        const bool neg = (sw & kPieceNeg) != 0;
-        for (long long pos = s + lane; pos < e; pos += kWave) stage[pos - beg] = source.cov[neg ? base - pos : base + pos];
+    for (long long jb = j0; jb < j1; jb += kWave - 1) {  // wave-uniform
+        const int cnt = (int)(j1 - jb < kWave - 1 ? j1 - jb : kWave - 1);
+        const long long sw_l = lane <= cnt ? (long long)pp.start[jb + lane] : 0;  // (start[j1] exists: the next piece or the sentinel)
+        const long long bs_l = lane < cnt ? pp.base[jb + lane] : 0;
+        for (int t = 0; t < cnt; ++t) {
+            const unsigned long long sw = (unsigned long long)readlane64(sw_l, t);
+            const long long s = (long long)(sw & ~kPieceNeg);
+            const long long e = (long long)((unsigned long long)readlane64(sw_l, t + 1) & ~kPieceNeg);
+            const long long base = readlane64(bs_l, t);
+            const bool neg = (sw & kPieceNeg) != 0;
+            for (long long pos = s + lane; pos < e; pos += kWave) stage[pos - beg] = source.cov[neg ? base - pos : base + pos];
+        }
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (one wave: its LDS operations complete in order)
