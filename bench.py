@@ -129,7 +129,7 @@ def cpu_baseline(pool, counts_host, offsets_host, per_core):
     return base, one, extra
 
 
-def measured_traffic(cfg, n_orfs, algo, seed):
+def measured_traffic(cfg, n_orfs, algo, seed, kernel="rp::k_tile_score<false>"):
     """HBM bytes per launch of the dominant kernel, REPLAYED from the committed rocprofv3
     PMC passes of this very command (profiles/traffic.json: FETCH_SIZE and WRITE_SIZE in KiB
     from separate --pmc runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
@@ -140,7 +140,8 @@ def measured_traffic(cfg, n_orfs, algo, seed):
         return None, None
     with open(path) as fh:
         for rec in json.load(fh):
-            if rec["cfg"] == cfg and rec["orfs_per_gpu"] == n_orfs and rec["algo"] == algo and rec["seed"] == seed:
+            if (rec["cfg"] == cfg and rec["orfs_per_gpu"] == n_orfs and rec["algo"] == algo and rec["seed"] == seed
+                    and rec.get("kernel", "rp::k_tile_score<false>") == kernel):
                 return int((2 * rec["fetch_size_kib"] + rec["write_size_kib"]) * 1024), rec.get("source", "profiles/traffic.json")
     return None, None
 
@@ -208,14 +209,16 @@ def fused_section(args, eng, dev, thresholds, n_set, csr_out):
     gplan = GatherPlan(table, coverage_len, dev)
     torch.cuda.synchronize(dev)
     gplan_ms = 1e3 * (time.perf_counter() - t0)
-    for _ in range(3):
+    for _ in range(5):
         out = eng.score_coverage(cov, gplan, thresholds=thresholds, reuse_outputs=True)
     tm: list = []
     for _ in range(max(3, args.fused_steps)):
         out = eng.score_coverage(cov, gplan, thresholds=thresholds, reuse_outputs=True, timings=tm)
-    k_main = sum(t[1] for t in tm) / len(tm)
-    k_fin = sum(t[2] for t in tm) / len(tm)
-    k_all = sum(t[3] for t in tm) / len(tm)
+    import statistics
+
+    k_main = statistics.median(t[1] for t in tm)  # (medians: this section's clocks follow whatever ran before it)
+    k_fin = statistics.median(t[2] for t in tm)
+    k_all = statistics.median(t[3] for t in tm)
     n = offsets.size - 1
     total_nt = int(offsets[-1])
     algo_bytes = 4 * total_nt + 8 * (n + 1) + 24 * n
@@ -231,6 +234,8 @@ def fused_section(args, eng, dev, thresholds, n_set, csr_out):
         "algorithmic_bytes_per_launch": algo_bytes,
         "translating": int(out.status.sum()),
     }
+    traffic, traffic_src = measured_traffic(args.cfg, n, "tile", args.seed, kernel="rp::k_tile_score<true>")
+    rep["traffic"], rep["traffic_source"] = traffic, traffic_src
     if not args.no_verify:
         def profiles_of(lo, hi):
             k0, k1 = int(orf_iv[lo]), int(orf_iv[hi])
