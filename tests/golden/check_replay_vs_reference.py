@@ -1,6 +1,8 @@
-"""Container-only check (imports /root/reference): oracle/scipy_replay.c against the
-reference's own phasescore on a fresh batch of tie-rich profiles -- phase score bit for bit,
-valid_codons exact.  usage: python tests/golden/check_replay_vs_reference.py [n] [seed]"""
+"""Container-only check (imports /root/reference): oracle/scipy_replay.c AND the product's host tie
+resolver (rp_tie_replay_host / rp_tie_replay_f64_host of libribophase.so, no GPU involved) against
+the reference's own phasescore on a fresh batch of tie-rich profiles -- sparse ones, ones scaled up
+to counts of 16..1000, and float-valued ones -- phase score bit for bit, valid_codons exact.
+usage: python tests/golden/check_replay_vs_reference.py [n] [seed]"""
 import os
 import sys
 
@@ -29,6 +31,24 @@ for i in range(n):
     if cf.flags[i] & 1:
         ties += 1
         tie_disagree_closed_form += int(v) != cf.valid[i]
+# the product's host resolver on the same profiles, on a scaled-up copy (counts 16..1000 inside the ties) and on floats
+from ribotricer_amd import _lib  # noqa: E402
+
+host_bad = 0
+ph, va = _lib.tie_replay_host(counts, offsets)
+host_bad += int((ph != rep.phase).sum() + (va != rep.valid).sum())
+scale = np.repeat(rng.integers(16, 1001, n), lens)
+big = (counts.astype(np.int64) * np.where(np.repeat(lam, lens) < 0.2, scale, 1)).astype(np.int32)
+ph, va = _lib.tie_replay_host(big, offsets)
+fl = big.astype(np.float64) * np.repeat(rng.choice([0.5, 0.125, 1.75, 3.3], n), lens)
+phf, vaf = _lib.tie_replay_host(fl, offsets)
+for i in range(n):
+    p, v = phasescore(big[offsets[i] : offsets[i + 1]].tolist())
+    host_bad += (float(p) != ph[i]) + (int(v) != va[i])
+    p, v = phasescore(fl[offsets[i] : offsets[i + 1]].tolist())
+    host_bad += (float(p) != phf[i]) + (int(v) != vaf[i])
+print(f"host resolver (rp_tie_replay_host, libm pow): {host_bad} mismatches over {3 * n} profiles (plain, counts x16..1000, float)")
+bad_phase += host_bad
 print(f"{n} profiles, {ties} exact frame ties ({tie_disagree_closed_form} of them decided differently by the closed form's "
       f"earlier-frame rule): replay phase mismatches {bad_phase}, valid_codons mismatches {bad_valid}")
 sys.exit(1 if bad_phase or bad_valid else 0)
