@@ -1016,7 +1016,10 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
 // LDS instead of finding the piece of every position they touch.
 // ---------------------------------------------------------------------------
 constexpr int kFinishBlock = kWave;  // one wave per workgroup: a re-walk holds up nobody else
-constexpr int kStageNt = 2040;       // fused path: profiles up to this long are copied to LDS first (8 KB per wave)
+#ifndef RP_STAGE_NT
+#define RP_STAGE_NT 1016
+#endif
+constexpr int kStageNt = RP_STAGE_NT;       // fused path: profiles up to this long are copied to LDS first (4 KB per wave: with 8 KB the pass itself loses occupancy, profiles/r03_ab_stage_nt.txt)
 
 // copy the profile of ORF `orf` out of the coverage into `stage`, piece by piece, coalesced; the
 // piece descriptors of up to 63 pieces are fetched lane-parallel first (one round trip, not one
