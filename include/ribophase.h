@@ -226,6 +226,21 @@ int rp_tie_replay_f64_host(const double *values, const int64_t *offsets, int64_t
                            double *phase, int32_t *valid);
 
 /*
+ * The per-ORF loop body of detect_orfs.py:274-299 for a whole CSR batch ON THE HOST, in the
+ * reference's own float64 arithmetic (the sequence of rp_tie_replay_host for every profile, not
+ * only the ties) -- SURVEY.md section 8(b) lists a host entry point next to the device one.  Outputs
+ * as rp_phase_score_csr_dev's (host pointers): phase and valid_codons carry the reference's bits on
+ * EVERY ORF, read_count / min_codon_cov are the integer results, flags = 0, status (may be NULL)
+ * the predicate of `filter` (may be NULL: no status).  n_threads <= 0: all hardware threads.
+ * NOT a fallback: nothing in the ribotricer_amd package routes scoring through it (there is no CPU
+ * path in the product); it serves callers that want the reference's bits without a GPU and the
+ * GPU-free cross-checks in tests/.  ~1 microsecond per codon and thread.
+ */
+int rp_phase_score_csr_host(const int32_t *counts, const int64_t *offsets, int64_t n_orfs, double *phase,
+                            int32_t *valid, int64_t *read_count, int32_t *min_codon_cov, uint8_t *flags,
+                            uint8_t *status, const rp_filter_params *filter, int n_threads);
+
+/*
  * Profile gather: builds the CSR counts array on the device from
  * dense P-site coverage and the ORFs' exon intervals.  Replaces orf_coverage() for every
  * ORF at once (detect_orfs.py:134-203): the positions of the intervals in ascending order,

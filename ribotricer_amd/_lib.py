@@ -74,6 +74,7 @@ SYMBOLS = {
     # host side (no GPU): exact-tie replay with this host's libm
     "rp_tie_replay_host": (_int, [_vp, _vp, _i64, _vp, _vp]),
     "rp_tie_replay_f64_host": (_int, [_vp, _vp, _i64, _vp, _vp]),
+    "rp_phase_score_csr_host": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(FilterParams), _int]),
     "rp_gather_profiles_dev": (_int, [_int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "rp_gather_plan_bytes": (_int, [_i64, _i64, _i64, ctypes.POINTER(ctypes.c_size_t)]),
     "rp_gather_plan_create_dev": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp, ctypes.POINTER(_vp)]),
@@ -199,3 +200,24 @@ def usable_cores() -> int:
     except (OSError, ValueError):
         pass
     return max(1, n)
+
+
+def phase_score_csr_host(counts, offsets, thresholds=None, n_threads: int = 0) -> dict:
+    """``rp_phase_score_csr_host``: the per-ORF loop body on the HOST in the reference's own float64
+    arithmetic (SURVEY.md 8(b) lists a host entry point beside the device one).  NOT a fallback --
+    nothing in this package scores through it; for callers without a GPU who want the reference's
+    bits, and for GPU-free cross-checks.  Returns a dict of numpy arrays like ``PhaseScores.cpu_numpy()``."""
+    import numpy as np
+
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = offsets.size - 1
+    out = {"phase": np.empty(n, np.float64), "valid": np.empty(n, np.int32), "read_count": np.empty(n, np.int64),
+           "min_codon_cov": np.empty(n, np.int32), "flags": np.empty(n, np.uint8),
+           "status": np.empty(n, np.uint8) if thresholds is not None else None}
+    check(load().rp_phase_score_csr_host(
+        counts.ctypes.data if counts.size else None, offsets.ctypes.data, n, out["phase"].ctypes.data, out["valid"].ctypes.data,
+        out["read_count"].ctypes.data, out["min_codon_cov"].ctypes.data, out["flags"].ctypes.data,
+        out["status"].ctypes.data if out["status"] is not None else None,
+        ctypes.byref(thresholds) if thresholds is not None else None, int(n_threads)))
+    return out

@@ -11,6 +11,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
+#include <thread>
+#include <vector>
+#include <algorithm>
 
 #include "../../include/ribophase.h"
 #include "rp_device.hpp"
@@ -589,6 +592,68 @@ int rp_tie_replay_f64_host(const double *values, const int64_t *offsets, int64_t
         const int64_t beg = offsets[i], len = offsets[i + 1] - beg;
         if (len < 0 || (len > 0 && !values)) return fail(RP_ERR_OFFSETS, "profile %lld: bad offsets or null values", (long long)i);
         rpreplay::replay_profile(values + beg, len, &phase[i], &valid[i]);
+    }
+    return RP_OK;
+}
+
+int rp_phase_score_csr_host(const int32_t *counts, const int64_t *offsets, int64_t n_orfs, double *phase, int32_t *valid,
+                            int64_t *read_count, int32_t *min_codon_cov, uint8_t *flags, uint8_t *status,
+                            const rp_filter_params *filter, int n_threads)
+{
+    if (n_orfs < 0) return fail(RP_ERR_SIZE, "n_orfs must be >= 0");
+    if (n_orfs == 0) return RP_OK;
+    if (!offsets || !phase || !valid || !read_count || !min_codon_cov || !flags) return fail(RP_ERR_NULL, "offsets and the five output arrays must be non-null");
+    if (offsets[0] != 0) return fail(RP_ERR_OFFSETS, "offsets must start at 0");
+    for (int64_t i = 0; i < n_orfs; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(RP_ERR_OFFSETS, "offsets must be monotone (ORF %lld)", (long long)i);
+    if (offsets[n_orfs] > 0 && !counts) return fail(RP_ERR_NULL, "counts is null but offsets[n] > 0");
+    int threads = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    if (threads < 1) threads = 1;
+    if ((int64_t)threads > n_orfs) threads = (int)n_orfs;
+    auto work = [&](int64_t first, int64_t last) {
+        for (int64_t i = first; i < last; ++i) {
+            const int32_t *v = counts + offsets[i];
+            const int64_t len = offsets[i + 1] - offsets[i];
+            rpreplay::replay_profile(v, len, &phase[i], &valid[i]);
+            int64_t total = 0;
+            int32_t mn = RP_MIN_CODON_COV_EMPTY;
+            for (int64_t k = 0; k < len; k += 3) {  // collapse_coverage_to_codon, common.py:164-180 (the last codon may be partial)
+                int64_t codon = v[k];
+                if (k + 1 < len) codon += v[k + 1];
+                if (k + 2 < len) codon += v[k + 2];
+                total += codon;
+                if (codon < mn) mn = (int32_t)codon;
+            }
+            read_count[i] = total;
+            min_codon_cov[i] = mn;
+            flags[i] = 0;
+            if (status && filter) {
+                const int64_t n_codons = len / 3 > 1 ? len / 3 : 1;  // detect_orfs.py:281
+                const bool ok = phase[i] >= filter->phase_score_cutoff && valid[i] >= filter->min_valid_codons &&
+                                (double)mn >= filter->min_reads_per_codon &&
+                                (double)valid[i] / (double)n_codons >= filter->min_valid_codons_ratio &&
+                                (double)total / (double)n_codons >= filter->min_density_over_orf;
+                status[i] = ok ? 1 : 0;
+            }
+        }
+    };
+    if (threads == 1) {
+        work(0, n_orfs);
+    } else {  // contiguous ORF ranges balanced on nucleotides
+        std::vector<std::thread> pool;
+        const int64_t total_nt = offsets[n_orfs];
+        int64_t first = 0;
+        for (int t = 0; t < threads; ++t) {
+            int64_t last = n_orfs;
+            if (t + 1 < threads) {
+                const int64_t target = total_nt / threads * (t + 1);
+                last = std::lower_bound(offsets + first, offsets + n_orfs, target) - offsets;
+                if (last < first) last = first;
+            }
+            pool.emplace_back(work, first, last);
+            first = last;
+        }
+        for (auto &th : pool) th.join();
     }
     return RP_OK;
 }

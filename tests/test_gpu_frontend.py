@@ -64,6 +64,37 @@ def test_coverage_build_rejects_counts_outside_the_contract():
     assert e.value.status == -7
 
 
+def test_coverage_build_ignores_rows_the_reference_never_looks_up():
+    """a high count on a contig without candidate ORFs (rRNA, chrM), on a position outside
+    every ORF's extent, or on an unknown strand code must not abort the export -- the reference never
+    looks such keys up (detect_orfs.py:176-187); a single row past 2^24 - 1 INSIDE an extent still does."""
+    from ribotricer_amd import alignments as al
+    from ribotricer_amd._lib import RibophaseError
+    from ribotricer_amd.index import NativeIndex
+
+    index = NativeIndex.from_file(INDEX)
+    strand, chrom = index.group_keys[0]
+    s = al.STRANDS.index(strand)
+    lo, hi = int(index.group_lo[0]), int(index.group_hi[0])
+    huge = 3_000_000_000
+    cols = al.MergedColumns(
+        np.array([s, s, s, s, 2], np.uint8), np.array([1, 0, 0, 0, 0], np.int32),
+        np.array([lo + 5, hi + 1000, max(1, lo - 7), lo + 5, lo + 5], np.int64),
+        np.array([huge, huge, huge, 7, huge], np.int64), [chrom, "chrUn_rRNA"],
+    )
+    coverage, base = al.build_coverage_device(cols, index)
+    start, lo0 = base[(strand, chrom)]
+    cov = coverage.cpu().numpy()
+    assert cov[start + 5] == 7 and int(cov.sum()) == 7
+    bad = al.MergedColumns(np.array([s], np.uint8), np.zeros(1, np.int32), np.array([lo + 5], np.int64), np.array([1 << 24], np.int64), [chrom])
+    with pytest.raises(RibophaseError) as e:
+        al.build_coverage_device(bad, index)
+    assert e.value.status == -7
+    neg = al.MergedColumns(np.array([s], np.uint8), np.zeros(1, np.int32), np.array([lo + 5], np.int64), np.array([-1], np.int64), [chrom])
+    with pytest.raises(RibophaseError):
+        al.build_coverage_device(neg, index)
+
+
 def test_metagene_and_offsets_match_the_reference(tmp_path):
     """metagene.py:160-328: profiles (every float), P-site offsets and the offsets report
     identical to the reference's; the two phase scores per read length within 1e-9 (they come

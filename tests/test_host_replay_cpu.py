@@ -60,3 +60,28 @@ def test_bad_arguments():
         _lib.tie_replay_host(np.zeros(3, np.int32), np.array([0, 3, 1], np.int64))  # decreasing offsets
     phase, valid = _lib.tie_replay_host(np.zeros(0, np.int32), np.zeros(1, np.int64))
     assert phase.size == 0 and valid.size == 0
+
+
+@pytest.mark.parametrize("name", ["g2", "g3", "g4", "g8"])
+def test_host_batch_entry_point_equals_the_reference(request, name):
+    """rp_phase_score_csr_host: phase and valid_codons are the reference's on EVERY ORF of
+    the golden sets (bitwise), the integer results equal the C oracle's, status equals the predicate."""
+    from helpers import reference_status
+    from oracle import c_oracle
+    from ribotricer_amd.engine import make_filter
+
+    g = request.getfixturevalue(name)
+    th = make_filter(phase_score_cutoff=0.3, min_valid_codons=3, min_reads_per_codon=0, min_valid_codons_ratio=0.05, min_density_over_orf=0.1)
+    one = _lib.phase_score_csr_host(g["counts"], g["offsets"], thresholds=th, n_threads=1)
+    many = _lib.phase_score_csr_host(g["counts"], g["offsets"], thresholds=th, n_threads=5)
+    for k in one:
+        assert np.array_equal(one[k], many[k]), k
+    assert np.array_equal(one["phase"], g["phase"]) and np.array_equal(one["valid"], g["valid"])
+    o = c_oracle.phase_score_csr(g["counts"], g["offsets"])
+    assert np.array_equal(one["read_count"], o.read_count) and np.array_equal(one["min_codon_cov"], o.min_codon_cov)
+    assert not one["flags"].any()
+    want = reference_status(one["phase"], one["valid"], o.read_count, o.min_codon_cov, np.diff(g["offsets"]), cutoff=0.3, min_valid=3,
+                            min_reads=0, min_ratio=0.05, min_density=0.1)
+    assert np.array_equal(one["status"], want)
+    no_status = _lib.phase_score_csr_host(g["counts"][:0], np.zeros(3, np.int64))
+    assert no_status["status"] is None and np.all(no_status["phase"] == 0) and np.all(no_status["min_codon_cov"] == 2147483647)
