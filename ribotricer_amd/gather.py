@@ -100,25 +100,12 @@ def coverage_entries(merged_alignments, extent: dict, base: dict):
 
 def build_dense_coverage_from_extents(merged_alignments, extent: dict):
     """Same as :func:`build_dense_coverage`, from ``extent[(strand, chrom)] = (lo, hi)`` (what
-    the native index parser reports per group).  Host array; the export path uses
-    :func:`build_dense_coverage_device` instead."""
+    the native index parser reports per group).  Host array (tests and small inputs); the export path
+    builds its coverage on the device from alignment columns (``alignments.build_coverage_device``)."""
     base, total = coverage_layout(extent)
     coverage = np.zeros(total, np.int32)
     idx, cnt = coverage_entries(merged_alignments, extent, base)
     coverage[idx] = cnt  # (strand, chrom, pos) keys are unique, so a plain scatter is enough
-    return coverage, base
-
-
-def build_dense_coverage_device(merged_alignments, extent: dict, device=None):
-    """Dense coverage laid out directly in HBM: only the non-zero entries (12 bytes per
-    distinct P-site position) cross PCIe and are scattered into a zero-filled device
-    array -- for a human-sized index the dense array is tens of GB, mostly zeros."""
-    dev = get_engine(device).device
-    base, total = coverage_layout(extent)
-    idx, cnt = coverage_entries(merged_alignments, extent, base)
-    coverage = torch.zeros(total, dtype=torch.int32, device=dev)
-    if idx.size:
-        coverage[torch.from_numpy(idx).to(dev)] = torch.from_numpy(cnt).to(dev)
     return coverage, base
 
 

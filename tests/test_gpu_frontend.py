@@ -49,6 +49,41 @@ def test_device_coverage_equals_counter_lookup():
     assert np.array_equal(dc2.cpu().numpy(), counts)
 
 
+def test_both_coverage_entry_points_agree():
+    """rp_coverage_build_rows_dev (raw columns, lookup on the device: what the package uses) and
+    rp_coverage_build_dev (rows already grouped on the host) accumulate the same coverage."""
+    import ctypes
+
+    import torch
+
+    from ribotricer_amd import _lib
+    from ribotricer_amd import alignments as al
+    from ribotricer_amd.engine import _ptr
+    from ribotricer_amd.gather import coverage_layout
+    from ribotricer_amd.index import NativeIndex
+
+    offsets = {int(k): v for k, v in g7_params()["psite_offsets"].items()}
+    cols = al.merge_read_lengths(load_g7_alignments(), offsets)
+    index = NativeIndex.from_file(INDEX)
+    cov_rows, base = al.build_coverage_device(cols, index)
+    keys = index.group_keys
+    extent = index.extents
+    _, total = coverage_layout(extent)
+    group = cols.group_codes(keys)
+    live = group >= 0
+    dev = cov_rows.device
+    to_dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)  # noqa: E731
+    d_group, d_pos, d_count = to_dev(group[live], np.int32), to_dev(cols.pos[live], np.int64), to_dev(cols.count[live], np.int32)
+    d_start = to_dev([base[k][0] for k in keys], np.int64)
+    d_lo = to_dev([extent[k][0] for k in keys], np.int64)
+    d_hi = to_dev([extent[k][1] for k in keys], np.int64)
+    cov_old = torch.zeros(total, dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().rp_coverage_build_dev(
+        dev.index, _ptr(d_group), _ptr(d_pos), _ptr(d_count), d_pos.numel(), _ptr(d_start), _ptr(d_lo), _ptr(d_hi), len(keys),
+        _ptr(cov_old), cov_old.numel(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    assert torch.equal(cov_rows, cov_old) and int(cov_rows.sum()) > 0
+
+
 def test_coverage_build_rejects_counts_outside_the_contract():
     from ribotricer_amd import alignments as al
     from ribotricer_amd._lib import RibophaseError
