@@ -67,6 +67,31 @@ for _ in range(5):
     eng.score_coverage(coverage, plan, thresholds=make_filter(), reuse_outputs=True, timings=tm)
 report["device"] = {"fused_score_ms": min(t[3] for t in tm), "kernel_ms": min(t[1] for t in tm), "finish_ms": min(t[2] for t in tm),
                     "total_nt": int(table.offsets[-1]), "coverage_positions": int(coverage.numel()), "exons": int(table.iv_start.size)}
+# what was computed, checked: fused == tile gather + CSR scorer bit for bit over the whole index, and 3 x 10 000
+# ORFs (head / middle / tail: coverage indices past 2^32, pieces of neighbouring ORFs gigabytes apart) against the
+# C oracle on profiles fetched by the per-ORF gather kernel (a code path of its own)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from helpers import assert_matches_oracle  # noqa: E402
+from ribotricer_amd.gather import gather_profiles_device, select_orfs  # noqa: E402
+
+fused = eng.score_coverage(coverage, plan, thresholds=make_filter())
+counts = plan.gather(coverage)
+csr = eng.score(counts, plan.offsets, thresholds=make_filter(), algo="tile")
+torch.cuda.synchronize()
+same = all(bool(torch.equal(getattr(fused, k), getattr(csr, k))) for k in ("phase", "valid", "read_count", "min_codon_cov", "flags", "status"))
+checked, worst = 0, 0.0
+n = index.n_orfs
+for lo in (0, n // 2 - 5000, n - 10000):
+    ids = np.arange(lo, lo + 10000, dtype=np.int64)
+    c_dev, o_dev = gather_profiles_device(coverage, select_orfs(table, ids))
+    c_host, o_host = c_dev.cpu().numpy(), o_dev.cpu().numpy()
+    part = {k: getattr(fused, k)[lo : lo + 10000].cpu().numpy() for k in ("phase", "valid", "read_count", "min_codon_cov", "flags")}
+    o = assert_matches_oracle(part, c_host, o_host)
+    worst = max(worst, float(np.abs(part["phase"] - o.phase).max()))
+    checked += 10000
+report["verify"] = {"fused_equals_gather_then_score_bitwise": same, "orfs_checked_against_oracle": checked, "max_abs_dphase": worst,
+                    "translating": int(fused.status.sum())}
+assert same
 print(json.dumps(report, indent=1))
 if out_json:
     with open(out_json, "w") as fh:
