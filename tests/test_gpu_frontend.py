@@ -158,7 +158,7 @@ def test_metagene_and_offsets_match_the_reference(tmp_path):
     assert open(prefix + "_psite_offsets.txt").read() == open(os.path.join(GOLDEN, "g7_expected_psite_offsets.txt")).read()
 
 
-def test_native_detect_orfs_from_a_bam(tmp_path):
+def test_native_detect_orfs_from_a_bam(tmp_path, capsys):
     """The whole native chain -- BAM -> columns -> metagene -> offsets -> merge -> WIG -> TSV --
     on a BAM holding the G7 reads: every output file equals the reference's (TSV: scores within
     the 1e-6 tolerance, all other columns identical)."""
@@ -192,6 +192,13 @@ def test_native_detect_orfs_from_a_bam(tmp_path):
     prefix = str(tmp_path / "out" / "g7")
     params = g7_params()
     detect_orfs(bam, INDEX, prefix, "forward", None, None, report_all=True, meta_min_reads=params["meta_min_reads"])
+    banners = [ln.split(" ... ", 1)[-1].split(" ..... ", 1)[-1] for ln in capsys.readouterr().out.splitlines() if " ..." in ln]
+    assert banners == [  # the stage lines of the reference (detect_orfs.py:401-525), minus protocol inference and the two plots
+        "started ribotricer detect-orfs", "started parsing ribotricer index file", "started reading bam file",
+        "started calculating metagene profiles. This may take a long time...", "started inferring P-site offsets",
+        "started shifting according to P-site offsets", "started exporting wig file of alignments after shifting",
+        "started calculating phase scores for each ORF", "finished ribotricer detect-orfs",
+    ]
     for name in ("psite_offsets.txt", "pos.wig", "neg.wig"):
         assert open(f"{prefix}_{name}").read() == open(os.path.join(GOLDEN, f"g7_expected_{name}")).read(), name
     assert "total_reads: %d" % (len(reads) + len(lead)) in open(prefix + "_bam_summary.txt").read()
