@@ -121,7 +121,7 @@ int rp_filter_defaults(rp_filter_params *out);
 
 /*
  * Bytes of device workspace rp_phase_score_csr_dev needs for a batch of this
- * shape (tile index + one 52-byte record per ORF and per tile).  16-byte aligned
+ * shape (one 48-byte record per ORF and per tile, the long re-walk queue, and -- without a plan -- the tile index, descriptors and head rows).  16-byte aligned
  * pointer required.
  */
 int rp_workspace_bytes(int64_t n_orfs, int64_t total_nt, int algo, size_t *bytes);

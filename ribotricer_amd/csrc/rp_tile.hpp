@@ -5,31 +5,31 @@
 // number of bytes regardless of how ragged the ORFs are (25 short ORFs or a slice of
 // one 100 k-nt ORF cost the same).  Inside a tile:
 //
-//   1. waves 1-3 stage the tile (+ a 4-dword halo) in LDS with the LDS-DMA form of
-//      global_load (each count leaves HBM once); meanwhile wave 0 reads the tile index
-//      and the offsets of its 64 segment slots and builds the segment table: slot 0 is
-//      the ORF that straddles in from the left ("head"), the others the ORFs that start
-//      inside; each segment gets ceil(T/kRun) lanes, T = codon triplets whose first
-//      position lies in the tile;
+//   1. the last wave stages the tile (+ a halo) in LDS with the LDS-DMA form of global_load
+//      (each count leaves HBM once); meanwhile every wave reads its part of the tile's head row
+//      of the plan (segment descriptors, lane map) and works out, in registers, which triplets
+//      its lanes walk: slot 0 is the ORF that straddles in from the left ("head"), the others
+//      the ORFs that start inside; each segment gets ceil(T/kRun) lanes, T = codon triplets
+//      whose first position lies in the tile;
 //   2. every lane walks a contiguous run of <= kRun triplets of ONE segment out of LDS
 //      (odd dword stride between lanes -> bank-conflict free), one codon of each reading
 //      frame per step, predicate-free fp32 arithmetic (one v_rsq_f32 per codon);
 //   3. integer sums go to per-segment LDS atomics (exact, order independent); the six
 //      float sums are folded by a segmented DPP scan inside each 16-lane row into one
 //      record per (segment, row) -- deterministic, no float atomics;
-//   4. one thread per segment sums its row records in float64 and writes ONE segment
-//      record (six sums, packed N/M, read count, minimum codon coverage) to the
-//      workspace, struct-of-arrays, at index  orf + tile  (unique and increasing);
-//   5. k_orf_finish, one thread per ORF at full occupancy, adds the records of the tiles
-//      the ORF spans (one, for most), scores the frames, runs the state machine and the
-//      filters and stores the outputs; ORFs whose fp32 frame decision is too close to call
-//      are re-walked in float64 from global memory by a whole wave (wave_walk, rp_wave.hpp).
+//   4. wave f < 3 sums reading frame f of every segment's row records in float64 and writes
+//      plane f of ONE 48-byte segment record (P_f, Q_f, N_f | M_f, a third of read count /
+//      minimum codon coverage) to the workspace at index  orf + tile  (unique and increasing);
+//   5. k_orf_finish, one thread per ORF, adds the records of the tiles the ORF spans (one, for
+//      most), scores the frames, runs the state machine and the filters and stores the
+//      outputs; ORFs whose fp32 frame decision is too close to call are re-walked in float64
+//      from global memory by a whole wave (wave_walk, rp_wave.hpp).
 //
-// The scoring kernel used to finish the ORFs itself (frame scores, float64 re-walk out of
-// LDS); that is a ~300-instruction dependent float64 chain run by ONE wave per workgroup
-// while the other three idle and the LDS tile stays allocated.  Splitting it off costs
-// 52 bytes of write + read per segment (~5 % more traffic) and took the scoring kernel
-// from 0.317 to 0.276 ms on BASELINE configs[1].
+// The scoring kernel does NOT finish ORFs itself: round 1 did (frame scores and float64 re-walk
+// out of LDS by one wave per workgroup: 0.317 vs 0.276 ms on BASELINE configs[1]), and round 3
+// tried again with only the cheap part (ORFs inside one tile, a wave per reading frame, pending
+// ORFs left to k_orf_finish): the float64 chain at the end of every workgroup costs the kernel
+// +12 %, three times what the 48 bytes of write + read per segment cost.
 //
 // Ownership rule: a triplet (3 positions from an ORF-relative multiple of 3) belongs
 // to the tile that holds its FIRST position; its frame-1/2 codons may reach 4
