@@ -179,17 +179,31 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
     const long long t0 = b * (long long)TILE;
     long long t_end = t0 + TILE + HALO;
     if (t_end > total_nt) t_end = total_nt;
-    if (t == 0) {  // last j with start_j <= t0 (start_0 == 0 <= t0)
-        long long lo = 0, hi = n_pieces;  // start[hi] (sentinel or later piece) > t0 unless t0 >= total_nt
+    if (wave == 0) {  // last j with start_j <= t0 (start_0 == 0 <= t0)
+        // 64-ary search by the wave: every step probes 64 evenly spaced pieces of [lo, hi) at once (one
+        // memory latency per step, 4-5 steps for 23 M pieces; a binary search by one thread took 25
+        // dependent loads and was most of this kernel's 3.6 ms at 500 000 tiles)
+        long long lo = 0, hi = n_pieces;  // invariant: start[lo] <= t0 < start[hi] (sentinel: total_nt) unless t0 >= total_nt
         while (hi - lo > 1) {
-            const long long mid = lo + (hi - lo) / 2;
-            if ((long long)(plan.start[mid] & ~kPieceNeg) <= t0) lo = mid; else hi = mid;
+            const long long span = hi - lo;
+            const long long step = (span + 63) / 64;
+            const long long probe = lo + step * (long long)lane;  // lane 0 probes lo itself: always <= t0
+            const bool le = probe < hi && (long long)(plan.start[probe] & ~kPieceNeg) <= t0;
+            const unsigned long long m = __ballot(le);
+            const int top = 63 - __builtin_clzll(m | 1ull);  // the highest lane whose probe is <= t0
+            const long long nlo = lo + step * (long long)top;
+            long long nhi = nlo + step;
+            if (nhi > hi) nhi = hi;
+            lo = nlo;
+            hi = nhi;
         }
-        s_j0 = lo;
-        plan.tile_piece0[b] = lo;
-        s_lo = INT64_MAX;
-        s_hi = INT64_MIN;
-        s_total = 0;
+        if (lane == 0) {
+            s_j0 = lo;
+            plan.tile_piece0[b] = lo;
+            s_lo = INT64_MAX;
+            s_hi = INT64_MIN;
+            s_total = 0;
+        }
     }
     __syncthreads();
     // pass 1: extent and chunk count of ALL the tile's pieces (kRowBlock at a time)
