@@ -126,7 +126,18 @@ def cpu_baseline(pool, counts_host, offsets_host, per_core):
     dt_c = (time.perf_counter() - t0) / reps
     extra = {"value": n_c / dt_c, "unit": "ORFs/s", "cores": cores, "kind": "port",
              "sample": f"first {n_c} ORFs, oracle/phase_oracle.c closed form + OpenMP, mean of {reps} passes of {dt_c * 1e3:.1f} ms"}
-    return base, one, extra
+    # the reference's own float64 arithmetic (every scipy / numpy operation restated, libm pow included) in C++ on
+    # all cores: libribophase's rp_phase_score_csr_host -- bit-exact with the reference, and what "the reference
+    # without the Python interpreter" would cost
+    from ribotricer_amd import _lib
+
+    _lib.phase_score_csr_host(c[: int(o[2000])], o[:2001], n_threads=cores)
+    t0 = time.perf_counter()
+    _lib.phase_score_csr_host(c, o, n_threads=cores)
+    dt_x = time.perf_counter() - t0
+    exact = {"value": n_c / dt_x, "unit": "ORFs/s", "cores": cores, "kind": "port",
+             "sample": f"first {n_c} ORFs, rp_phase_score_csr_host (the reference's float64 operation sequence in C++, bit-exact), one pass of {dt_x * 1e3:.0f} ms"}
+    return base, one, extra, exact
 
 
 def measured_traffic(cfg, n_orfs, algo, seed, kernel="rp::k_tile_score<false>"):
@@ -504,11 +515,12 @@ def main():
             n_s = min(max(per_core * pool.n, 200_000), n_orfs)
             o_host = offsets[: n_s + 1].cpu().numpy()
             c_host = counts[: int(o_host[-1])].cpu().numpy()
-            base, one, extra = cpu_baseline(pool, c_host, o_host, per_core)
+            base, one, extra, exact = cpu_baseline(pool, c_host, o_host, per_core)
             pool.close()
             result["cpu_baseline"] = base
             result["cpu_baseline_1core"] = one
             result["cpu_closed_form_c"] = extra
+            result["cpu_reference_arithmetic_cpp"] = exact
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
