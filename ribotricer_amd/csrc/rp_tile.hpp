@@ -1068,8 +1068,11 @@ __device__ __forceinline__ void finish_unsafe(Counts v, long long orf, long long
     if (lane == 0) store_orf(out, fp, orf, phase, valid, count, min_codon, flags | split | RP_FLAG_RECHECK64, len);
 }
 
+#ifndef RP_FINISH_WAVES
+#define RP_FINISH_WAVES 1
+#endif
 template <int TILE, typename Source>
-__global__ __launch_bounds__(kFinishBlock) void k_orf_finish(Source source,
+__global__ __launch_bounds__(kFinishBlock, RP_FINISH_WAVES) void k_orf_finish(Source source,
                                                              const int64_t *__restrict__ offsets,
                                                              long long n_orfs, TilePlan plan,
                                                              TileWorkspace ws, OrfOutputs out,
