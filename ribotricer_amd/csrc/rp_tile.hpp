@@ -361,19 +361,19 @@ __global__ __launch_bounds__(kHeadBlock) void k_tile_head(long long n_tiles, con
 // ---------------------------------------------------------------------------
 // pass 2: the scoring kernel
 // ---------------------------------------------------------------------------
-struct alignas(16) RunRec {  // float sums one 16-lane row contributes to one segment
+// What one 16-lane row contributes to one segment (48 bytes): the six float sums, and -- since
+// round 3 -- the integer results as well, carried through the same segmented DPP scan instead of
+// per-segment LDS atomics (8-16 lanes on one address: a kernel without them ran 6.7 % faster,
+// profiles/r03_ab_no_int_atomics_upper_bound.txt):
+//   S[f]      the census sum of reading frame f, 2^13 (E + 256 Z) + eps (see kDust*): E, Z <= 240 per row
+//   clo, chi  the read count as two floats (low 16 bits, high bits): row sums < 2^24, exact
+//   mn        the minimum codon coverage
+struct alignas(16) RunRec {
     float p[3];
     float q[3];
-    float pad[2];
-};
-
-// integer sums of one segment, accumulated with LDS atomics (order independent, exact)
-struct SegInts {
-    unsigned long long nn;     // n[0] | n[1] << 16 | n[2] << 32  (a tile owns < 2^16 triplets)
-    unsigned long long mm;     // same packing
-    unsigned long long count;  // read count
-    unsigned min_codon;
-    unsigned pad;
+    float S[3];
+    float clo, chi;
+    unsigned mn;
 };
 
 }  // namespace rp
@@ -457,8 +457,8 @@ __device__ __forceinline__ int dpp_row(int src)
 struct LaneSums {
     float p[3];
     float q[3];
-    unsigned long long nn, mm;  // N_f / M_f of the three frames, 16-bit fields: f0 | f1 << 16 | f2 << 32
-    unsigned count;   // <= 3 * kRun * RP_MAX_COUNT < 2^32
+    float S[3];      // census sums (flat / all-zero codons), decoded per row in the record stage
+    float clo, chi;  // read count: (cnt & 0xffff), (cnt >> 16) -- <= 65 535 and <= 11 520 per lane
     unsigned mn;
 };
 
@@ -468,15 +468,15 @@ struct LaneSums {
 // that the six stay together: a DPP read needs 2 wait states after the VALU write of its
 // source, which the leading s_nop gives the first and the five others give each following
 // step (the compiler inserts no wait states around inline asm).
-#define RP_SCAN_STEP(ctrl)                                                                          \
-    asm volatile("s_nop 1\n\t"                                                                      \
-                 "v_fmac_f32_dpp %0, %0, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
-                 "v_fmac_f32_dpp %1, %1, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
-                 "v_fmac_f32_dpp %2, %2, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
-                 "v_fmac_f32_dpp %3, %3, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
-                 "v_fmac_f32_dpp %4, %4, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   \
-                 "v_fmac_f32_dpp %5, %5, %6 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1"         \
-                 : "+v"(v.p[0]), "+v"(v.p[1]), "+v"(v.p[2]), "+v"(v.q[0]), "+v"(v.q[1]), "+v"(v.q[2]) \
+#define RP_SCAN_FMAC(n, ctrl) "v_fmac_f32_dpp %" #n ", %" #n ", %11 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define RP_SCAN_STEP(ctrl)                                                                              \
+    asm volatile("s_nop 1\n\t"                                                                          \
+                 RP_SCAN_FMAC(0, ctrl) RP_SCAN_FMAC(1, ctrl) RP_SCAN_FMAC(2, ctrl) RP_SCAN_FMAC(3, ctrl)  \
+                 RP_SCAN_FMAC(4, ctrl) RP_SCAN_FMAC(5, ctrl) RP_SCAN_FMAC(6, ctrl) RP_SCAN_FMAC(7, ctrl)  \
+                 RP_SCAN_FMAC(8, ctrl) RP_SCAN_FMAC(9, ctrl)                                              \
+                 "v_fmac_f32_dpp %10, %10, %11 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1"          \
+                 : "+v"(v.p[0]), "+v"(v.p[1]), "+v"(v.p[2]), "+v"(v.q[0]), "+v"(v.q[1]), "+v"(v.q[2]),    \
+                   "+v"(v.S[0]), "+v"(v.S[1]), "+v"(v.S[2]), "+v"(v.clo), "+v"(v.chi)                     \
                  : "v"(m))
 
 template <int K>
@@ -484,13 +484,20 @@ __device__ __forceinline__ void seg_scan_step(LaneSums &v, int key)
 {
     static_assert(K == 1 || K == 2 || K == 4 || K == 8, "row_shr distance");
     constexpr int ctrl = K == 1 ? kDppRowShr1 : K == 2 ? kDppRowShr2 : K == 4 ? kDppRowShr4 : kDppRowShr8;
-    const float m = (dpp_row<ctrl>(key) == key) ? 1.0f : 0.0f;  // 1 inside the segment, 0 across its start
-#ifdef RP_SCAN_PLAIN  // the same step in plain C++ (A/B reference: +40 VALU instructions per pass)
+    const bool same = dpp_row<ctrl>(key) == key;  // inside the segment (false across its start and for lanes without a source)
+    const float m = same ? 1.0f : 0.0f;
+    // the minimum: the source lane's value where it belongs to the same segment (lanes without a source keep their own)
+    const unsigned from = (unsigned)__builtin_amdgcn_update_dpp((int)v.mn, (int)v.mn, ctrl, 0xf, 0xf, false);
+    v.mn = same ? min(v.mn, from) : v.mn;
+#ifdef RP_SCAN_PLAIN  // the same step in plain C++ (A/B reference)
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         v.p[f] = __builtin_fmaf(__int_as_float(dpp_row<ctrl>(__float_as_int(v.p[f]))), m, v.p[f]);
         v.q[f] = __builtin_fmaf(__int_as_float(dpp_row<ctrl>(__float_as_int(v.q[f]))), m, v.q[f]);
+        v.S[f] = __builtin_fmaf(__int_as_float(dpp_row<ctrl>(__float_as_int(v.S[f]))), m, v.S[f]);
     }
+    v.clo = __builtin_fmaf(__int_as_float(dpp_row<ctrl>(__float_as_int(v.clo))), m, v.clo);
+    v.chi = __builtin_fmaf(__int_as_float(dpp_row<ctrl>(__float_as_int(v.chi))), m, v.chi);
     return;
 #endif
     if constexpr (K == 1) RP_SCAN_STEP("row_shr:1");
@@ -582,14 +589,16 @@ struct RunAcc {
 };
 
 // q is kept off zero by a "dust" folded into d0^2 that depends on the codon's first count a:
-// 2^-36 for a == 0, 2^-26 for a >= 1 (one v_med3 of the converted count).  Any q >= 1 absorbs
+// 2^-42 for a == 0, 2^-26 for a >= 1 (one v_med3 of the converted count).  Any q >= 1 absorbs
 // either exactly, and a flat codon (a == b == c, so d0 = d1 = 0 and its products with the root
-// vanish) gets a root that names its kind: 2^18 for an all-zero codon, 2^13 for a flat one with
-// reads.  Every other root is <= 1, so ONE running sum per frame S = 2^13 (E + 32 Z) + eps,
-// eps <= kRun, carries both counts of the lane (E, Z <= kRun < 32):  M = codons - Z - E,
-// N = codons - Z -- no per-position indicator arithmetic at all.
-constexpr float kDustZero = 0x1p-36f, kDustFlat = 0x1p-26f, kFlatUnit = 0x1p-13f;
-static_assert(kRun < 32, "the flat-codon census packs E into 5 bits per lane and frame");
+// vanish) gets a root that names its kind: 2^21 for an all-zero codon, 2^13 for a flat one with
+// reads.  Every other root is <= 1, so ONE running sum per frame S = 2^13 (E + 256 Z) + eps
+// carries both counts -- of a lane (E, Z <= kRun) and, summed by the segmented scan, of a 16-lane
+// row (E, Z <= 240 < 256; S < 2^29, eps and its fp32 rounding stay far below half a unit):
+// M = codons - Z - E, N = codons - Z -- no per-position indicator arithmetic and no integer
+// reduction at all; the record stage decodes the row sums.
+constexpr float kDustZero = 0x1p-42f, kDustFlat = 0x1p-26f, kFlatUnit = 0x1p-13f;
+static_assert(16 * kRun < 256, "the flat-codon census packs E into 8 bits per 16-lane row and frame");
 
 // One block of 3 * kRunBlock codon starts at s[0..]; (nf0, nf1) = the two values after the
 // block as floats.  MASKED: only the first `lim` starts count (their roots are multiplied by
@@ -662,19 +671,14 @@ __device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, Lan
         if (lb >= it)  // lanes whose run has fewer blocks sit this one out (EXEC)
             run_block<false>(lo + (kBlocks - 1 - it) * B, B, nf0, nf1, a);
     }
-    unsigned m[3], n[3];
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         o.p[f] = a.P[f];
         o.q[f] = a.Q[f];
-        const int k = (int)__builtin_fmaf(a.S[f], kFlatUnit, 0.5f);  // E + 32 Z
-        const int codons = ((lim + 2 - f) * 21846) >> 16;            // codon starts of frame f among the first lim (lim <= 3 kRun)
-        n[f] = (unsigned)(codons - (k >> 5));
-        m[f] = n[f] - (unsigned)(k & 31);
+        o.S[f] = a.S[f];
     }
-    o.mm = ((unsigned long long)m[2] << 32) | (m[1] << 16) | m[0];
-    o.nn = ((unsigned long long)n[2] << 32) | (n[1] << 16) | n[0];
-    o.count = a.cnt;
+    o.clo = (float)(a.cnt & 0xffffu);  // <= 3 * kRun * RP_MAX_COUNT < 2^30: two exact floats
+    o.chi = (float)(a.cnt >> 16);
     o.mn = a.mn;
 }
 
@@ -701,24 +705,16 @@ __device__ unsigned long long rp_dbg_stamps[kStampSlots][4][8];  // plain stores
 #define RP_STAMP() do {} while (0)
 #define RP_STAMP_FLUSH() do {} while (0)
 #endif
-// One pass of a wave: every lane walks its run, then the per-segment reduction.
+// One pass of a wave: every lane walks its run, then the per-segment reduction -- a segmented
+// inclusive scan inside each 16-lane DPP row over the six float sums, the three census sums, the
+// two halves of the read count (all as v_fmac_f32_dpp) and the minimum: deterministic, no atomics;
+// the last lane of a segment in a row stores one 48-byte row record.
 template <int KRUN>
-__device__ __forceinline__ void tile_pass(const int *__restrict__ s_counts, SegInts *__restrict__ s_ints,
-                                          RunRec *__restrict__ s_rec, int q0, int lim, bool active, int seg, int vl)
+__device__ __forceinline__ void tile_pass(const int *__restrict__ s_counts, RunRec *__restrict__ s_rec, int q0, int lim,
+                                          bool active, int seg, int vl)
 {
     LaneSums sv;
     lane_run<KRUN>(s_counts + q0, lim, sv);
-
-    // integer sums: exact and order independent -> LDS atomics straight per segment
-    if (active) {
-        SegInts &acc = s_ints[seg];
-        atomicAdd(&acc.nn, sv.nn);  // three 16-bit fields per word: no carry between them
-        atomicAdd(&acc.mm, sv.mm);
-        atomicAdd(&acc.count, (unsigned long long)sv.count);
-        atomicMin(&acc.min_codon, sv.mn);
-    }
-
-    // float sums: deterministic segmented scan inside each 16-lane row
     const int key = active ? seg + 1 : kSegChunk + 1;
     seg_scan_rows(sv, key);
     const int key_next = dpp_fetch<0x101 /* row_shl:1 */, 0xf>(0, key);  // 0 at the row's last lane
@@ -729,17 +725,24 @@ __device__ __forceinline__ void tile_pass(const int *__restrict__ s_counts, SegI
         for (int f = 0; f < 3; ++f) {
             rec.p[f] = sv.p[f];
             rec.q[f] = sv.q[f];
+            rec.S[f] = sv.S[f];
         }
+        rec.clo = sv.clo;
+        rec.chi = sv.chi;
+        rec.mn = sv.mn;
     }
 }
 
-// Record stage: row records + integer sums -> ONE record per live segment.  The three words
-// of a record live in three planes (rec[f * n_rec + id]), one per reading frame; wave f < 3
-// writes plane f for all 64 slots (thread = slot), so the three short dependency chains run
-// side by side on three SIMDs and every store instruction covers consecutive 16-byte words.
-__device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, const SegInts *__restrict__ s_ints,
-                                             const RunRec *__restrict__ s_rec, const int *__restrict__ s_vlstart,
-                                             const int *__restrict__ s_tail, const int *__restrict__ s_live,
+// Record stage: the row records of a segment -> ONE 48-byte record.  The three words of a record
+// live in three planes (rec[f * n_rec + id]), one per reading frame; wave f < 3 writes plane f for
+// all 64 slots (thread = slot), so the three short dependency chains run side by side on three
+// SIMDs and every store instruction covers consecutive 16-byte words.  Per row the census sum of
+// the frame is decoded -- k = round(S / 2^13) = E + 256 Z, the row's flat and all-zero codons --
+// and the frame's codon starts come from the segment's geometry (s_geom: how many of its start
+// positions are valid), so N = codons - Z and M = N - E need no counting anywhere.
+__device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, const RunRec *__restrict__ s_rec,
+                                             const int *__restrict__ s_vlstart, const int *__restrict__ s_tail,
+                                             const int *__restrict__ s_live, const int *__restrict__ s_geom,
                                              uint4 *__restrict__ rec, long long n_rec, long long id0, int wave, int seg)
 {
     if (wave >= 3 || !s_live[seg]) return;
@@ -749,20 +752,23 @@ __device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, c
     const int w_last = ve > vs ? (ve - 1) >> 4 : w_first - 1;
     const int tail = s_tail[seg];
     double a0 = 0.0, a1 = 0.0;
+    int flat = 0, zero = 0;
+    unsigned long long count = 0;
+    unsigned min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
     for (int w = w_first; w <= w_last; ++w) {
         const RunRec &r = s_rec[seg + w];
         a0 += (double)(wave == 0 ? r.p[0] : wave == 1 ? r.p[1] : r.p[2]);
         a1 += (double)(wave == 0 ? r.q[0] : wave == 1 ? r.q[1] : r.q[2]);
+        const int k = (int)__builtin_fmaf(wave == 0 ? r.S[0] : wave == 1 ? r.S[1] : r.S[2], kFlatUnit, 0.5f);  // E + 256 Z of this row
+        flat += k & 255;
+        zero += k >> 8;
+        count += ((unsigned long long)(unsigned)r.chi << 16) + (unsigned long long)(unsigned)r.clo;
+        min_codon = min(min_codon, r.mn);
     }
-    unsigned n = 0, m = 0;
-    unsigned long long count = 0;
-    unsigned min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
-    if (ve > vs) {
-        n = (unsigned)(s_ints[seg].nn >> (16 * wave)) & 0xffffu;
-        m = (unsigned)(s_ints[seg].mm >> (16 * wave)) & 0xffffu;
-        count = s_ints[seg].count;
-        min_codon = s_ints[seg].min_codon;
-    }
+    const int lim_seg = s_geom[seg];  // the segment's valid codon starts are its first lim_seg start positions
+    const int codons = ((lim_seg + 2 - wave) * 21846) >> 16;  // those of frame `wave`: floor((lim + 2 - f) / 3), lim < 8 192
+    const unsigned n = (unsigned)(codons - zero);
+    const unsigned m = n - (unsigned)flat;
     if (tail >= 0) {  // an owned partial last codon (L % 3 != 0): common.py:164-180 still sums it
         unsigned codon = (unsigned)s_counts[tail & 0xffff];
         if ((tail >> 16) == 2) codon += (unsigned)s_counts[(tail & 0xffff) + 1];
@@ -773,13 +779,24 @@ __device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, c
     rec[wave * n_rec + id0 + seg] = make_uint4(__float_as_uint((float)a0), __float_as_uint((float)a1), n | (m << 16), extra);
 }
 
+// the segment's number of valid codon-start positions (every frame counted), from its descriptor:
+// its owned triplets offer 3 * ntrip starts, of which those whose codon would reach past the ORF's
+// end (rem = endq - qfirst positions from the first start on) are not valid
+__device__ __forceinline__ int seg_geom(seg_desc_t d)
+{
+    const int rem = (((int)(d >> 13)) & 0x1fff) - ((int)d & 0x1fff);
+    const int starts = 3 * ((int)(d >> 26) & 0xfff);
+    const int lim = rem - 2 < starts ? rem - 2 : starts;
+    return lim > 0 ? lim : 0;
+}
+
 // One round of the short-ORF path: the 64 segments whose descriptors the lanes hold (`dc`), walked
 // with runs of KRUN triplets.  Every wave finds its lanes' segments through 64 private words of
 // LDS (marks at the segments' first lanes, then a max-scan); tables, pass, reduction as in the
 // common path.  Ends after barrier 2 (the caller runs the record stage).
 template <int KRUN>
-__device__ __forceinline__ void short_round(seg_desc_t dc, const int *s_counts, SegInts *s_ints, RunRec *s_rec,
-                                            int *s_vlstart, int *s_tail, int *s_live, int *s_owner, int wave, int lane)
+__device__ __forceinline__ void short_round(seg_desc_t dc, const int *s_counts, RunRec *s_rec, int *s_vlstart, int *s_tail,
+                                            int *s_live, int *s_geom, int *s_owner, int wave, int lane)
 {
     const int ntrip_i = (int)(dc >> 26) & 0xfff;
     const int lanes_i = (dc >> 63) ? (ntrip_i + KRUN - 1) / KRUN : 0;
@@ -822,9 +839,10 @@ __device__ __forceinline__ void short_round(seg_desc_t dc, const int *s_counts, 
         if (lane == kWave - 1) s_vlstart[kSegChunk] = incl;
         s_tail[lane] = part ? (((int)(dc >> 38) & 0x1fff) | (part << 16)) : -1;
         s_live[lane] = (int)(dc >> 63);
+        s_geom[lane] = seg_geom(dc);
     }
-    __syncthreads();  // tables and cleared accumulators are in place
-    if (pass) tile_pass<KRUN>(s_counts, s_ints, s_rec, q0, lim, active, seg, vl);
+    __syncthreads();  // the previous round's record stage is done with the row records
+    if (pass) tile_pass<KRUN>(s_counts, s_rec, q0, lim, active, seg, vl);
     __syncthreads();
 }
 
@@ -841,7 +859,7 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
     __shared__ int s_vlstart[kSegChunk + 1];
     __shared__ int s_owner[kTileBlock];   // short-ORF path: 64 private words per wave for the segment marks
     __shared__ RunRec s_rec[kMaxRecs];
-    __shared__ SegInts s_ints[kSegChunk];
+    __shared__ int s_geom[kSegChunk];     // valid codon-start positions of the slot's segment (record stage)
 
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -884,12 +902,6 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
         __builtin_amdgcn_s_setprio(0);
     } else {
         load_tile_to_lds<TILE>(counts, t0, plan.total_nt, s_counts, tid);
-    }
-    if (wave == 0) {  // the integer accumulators of the 64 slots (before anyone's atomics: barrier 1)
-        s_ints[lane].nn = 0;
-        s_ints[lane].mm = 0;
-        s_ints[lane].count = 0;
-        s_ints[lane].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
     }
     RP_STAMP();  // 1: loads issued
 
@@ -936,16 +948,17 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
             if (lane == kWave - 1) s_vlstart[kSegChunk] = incl;
             s_tail[lane] = part ? (((int)(d >> 38) & 0x1fff) | (part << 16)) : -1;
             s_live[lane] = (int)(d >> 63);
+            s_geom[lane] = seg_geom(d);
         }
         RP_STAMP();  // 3: mapped, arrived at barrier 1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is tracked by vmcnt only
         __syncthreads();
         RP_STAMP();  // 4: tile landed (barrier 1)
-        if (pass) tile_pass<kRun>(s_counts, s_ints, s_rec, q0, lim, active, seg, vl);
+        if (pass) tile_pass<kRun>(s_counts, s_rec, q0, lim, active, seg, vl);
         RP_STAMP();  // 5: this wave's lane runs done
         __syncthreads();
         RP_STAMP();  // 6: all lane runs done (barrier 2)
-        record_stage(s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, ws.rec, ws.n_rec, a0 - 1 + b, wave, lane);
+        record_stage(s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, ws.rec, ws.n_rec, a0 - 1 + b, wave, lane);
         RP_STAMP();  // 7: records stored
         RP_STAMP_FLUSH();
         return;
@@ -969,12 +982,6 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
     for (long long c0 = 0; c0 < n_slots; c0 += kSegChunk) {
         if (c0 > 0) {
             __syncthreads();  // the previous chunk's record stage is done with the tables
-            if (wave == 0) {
-                s_ints[lane].nn = 0;
-                s_ints[lane].mm = 0;
-                s_ints[lane].count = 0;
-                s_ints[lane].min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
-            }
             const long long orf = a0 - 1 + c0 + lane;
             dc = orf < a1 ? ws.desc[orf + b] : 0;
         }
@@ -987,15 +994,15 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
         const int total5 = __builtin_amdgcn_readlane(wave_add_scan(live_i ? (ntrip_i + 4) / 5 : 0), kWave - 1);
         const int total9 = __builtin_amdgcn_readlane(wave_add_scan(live_i ? (ntrip_i + 8) / 9 : 0), kWave - 1);
         if (total5 <= kTileBlock)
-            short_round<5>(dc, s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, s_owner, wave, lane);
+            short_round<5>(dc, s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, s_owner, wave, lane);
         else if (total9 <= kTileBlock)
-            short_round<9>(dc, s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, s_owner, wave, lane);
+            short_round<9>(dc, s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, s_owner, wave, lane);
         else
-            short_round<kRun>(dc, s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, s_owner, wave, lane);
+            short_round<kRun>(dc, s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, s_owner, wave, lane);
 #ifdef RP_STAMPS
         if (n_stamp_ < 7) RP_STAMP();  // short path: 2, 4, 6 = after barrier 2 of rounds 0, 1, 2
 #endif
-        record_stage(s_counts, s_ints, s_rec, s_vlstart, s_tail, s_live, ws.rec, ws.n_rec, a0 - 1 + c0 + b, wave, lane);
+        record_stage(s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, ws.rec, ws.n_rec, a0 - 1 + c0 + b, wave, lane);
 #ifdef RP_STAMPS
         if (n_stamp_ < 7) RP_STAMP();  // short path: 3, 5, 7 = records of rounds 0, 1, 2 stored
 #endif
