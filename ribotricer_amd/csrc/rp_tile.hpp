@@ -90,8 +90,8 @@ struct TilePlan {
 // kernel, a thread per segment) and readers (a thread per ORF) touch consecutive words with
 // consecutive threads.
 //   plane f  p[f]  q[f]  n_f | m_f << 16  extra_f     p, q fp32: the float64 sum of <= 11 fp32 row
-//            records, rounded once; extra_0 = count.lo, extra_1 = count.hi, extra_2 = min_codon
-//            (a tile owns < 2^16 triplets)
+//            records, rounded once; the read count is (extra_2 << 16) + extra_0 (sums of the row
+//            records' high and low halves), extra_1 = min_codon (a tile owns < 2^16 triplets)
 // (Finishing the ORFs that lie inside one tile in the scoring kernel itself -- no record, no
 // round trip -- was built and measured in round 3: the float64 chain at the end of every
 // workgroup costs the scoring kernel +12 %, three times what the round trip costs;
@@ -753,8 +753,7 @@ __device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, c
     const int tail = s_tail[seg];
     double a0 = 0.0, a1 = 0.0;
     int flat = 0, zero = 0;
-    unsigned long long count = 0;
-    unsigned min_codon = (unsigned)RP_MIN_CODON_COV_EMPTY;
+    unsigned extra = wave == 1 ? (unsigned)RP_MIN_CODON_COV_EMPTY : 0u;  // wave 0: sum of clo, wave 1: minimum, wave 2: sum of chi
     for (int w = w_first; w <= w_last; ++w) {
         const RunRec &r = s_rec[seg + w];
         a0 += (double)(wave == 0 ? r.p[0] : wave == 1 ? r.p[1] : r.p[2]);
@@ -762,20 +761,22 @@ __device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, c
         const int k = (int)__builtin_fmaf(wave == 0 ? r.S[0] : wave == 1 ? r.S[1] : r.S[2], kFlatUnit, 0.5f);  // E + 256 Z of this row
         flat += k & 255;
         zero += k >> 8;
-        count += ((unsigned long long)(unsigned)r.chi << 16) + (unsigned long long)(unsigned)r.clo;
-        min_codon = min(min_codon, r.mn);
+        if (wave == 0)
+            extra += (unsigned)r.clo;  // <= 11 rows x 2^20
+        else if (wave == 1)
+            extra = min(extra, r.mn);
+        else
+            extra += (unsigned)r.chi;  // <= 11 rows x 2^18
     }
     const int lim_seg = s_geom[seg];  // the segment's valid codon starts are its first lim_seg start positions
     const int codons = ((lim_seg + 2 - wave) * 21846) >> 16;  // those of frame `wave`: floor((lim + 2 - f) / 3), lim < 8 192
     const unsigned n = (unsigned)(codons - zero);
     const unsigned m = n - (unsigned)flat;
-    if (tail >= 0) {  // an owned partial last codon (L % 3 != 0): common.py:164-180 still sums it
+    if (tail >= 0 && wave < 2) {  // an owned partial last codon (L % 3 != 0): common.py:164-180 still sums it
         unsigned codon = (unsigned)s_counts[tail & 0xffff];
         if ((tail >> 16) == 2) codon += (unsigned)s_counts[(tail & 0xffff) + 1];
-        count += codon;
-        min_codon = min(min_codon, codon);
+        extra = wave == 0 ? extra + codon : min(extra, codon);  // (<= 2 x 2^24 on top of the clo sum: fits)
     }
-    const unsigned extra = wave == 0 ? (unsigned)count : wave == 1 ? (unsigned)(count >> 32) : min_codon;
     rec[wave * n_rec + id0 + seg] = make_uint4(__float_as_uint((float)a0), __float_as_uint((float)a1), n | (m << 16), extra);
 }
 
@@ -1116,8 +1117,8 @@ __global__ __launch_bounds__(kFinishBlock, RP_FINISH_WAVES) void k_orf_finish(So
                 m[1] += (int)(w1.z >> 16);
                 n[2] += (int)(w2.z & 0xffffu);
                 m[2] += (int)(w2.z >> 16);
-                count += (long long)(((unsigned long long)w1.w << 32) | w0.w);
-                min_codon = min(min_codon, (int)w2.w);
+                count += (long long)(((unsigned long long)w2.w << 16) + w0.w);
+                min_codon = min(min_codon, (int)w1.w);
             }
             if (b_last > b_first) split = RP_FLAG_SPLIT;
         }
