@@ -29,7 +29,10 @@ AFTER the timed region (N = 1): `verify` -- head / middle / tail slices of 20 00
 ORFs around 2^31 / 2^32 nt of what the steps computed, against the C oracle on the same bytes
 (integers bit-exact, phase <= 1e-6, exact frame ties bit for bit) -- and `fused` -- the kernel
 the drop-in export path runs by default (gather + score fused, rp::k_tile_score<true>) on an
-exon layout of the same length law, with its own `verify`.
+exon layout of the same length law, with its own `verify` -- and `roofline.stream_read` -- a plain
+streaming read of the same counts buffer in the same process (csrc/stream_probe.hip), the yardstick
+next to which `frac_of_stream_read` puts the kernel (the kernel's time depends on where its buffers
+lie, by up to 15 % from process to process; the plain read does not).
 """
 
 from __future__ import annotations
@@ -444,6 +447,22 @@ def main():
             print(json.dumps({"error": "results differ from the oracle", "verify": verify, "fused": fused}), flush=True)
             sys.exit(2)
 
+    stream_read = None
+    if rank == 0 and world == 1 and total_nt >= (1 << 22):
+        # After the timed region: what does a plain read of the SAME counts buffer reach in this process, on this
+        # box, right now?  (csrc/stream_probe.hip: 32 KiB pieces DMA'd into LDS by one loader wave, four workgroups
+        # per CU -- the scoring kernel's skeleton and nothing else.)  The scoring kernel was seen between 2.6 and
+        # 3.1 ms on the same bytes depending on where its buffers lie (profiles/r03_clock_trace.txt); the plain
+        # read is the yardstick that does not move.
+        try:
+            from ribotricer_amd._probe import stream_read_GBps
+
+            gbps, ms = stream_read_GBps(counts, launches=10, flavour="lds_dma")
+            stream_read = {"GBps": gbps, "ms": ms, "bytes": int(counts.numel()) * 4 // 32768 * 32768,
+                           "what": "csrc/stream_probe.hip k_stream_read_lds over the counts buffer of this run, after the timed region"}
+        except ImportError:
+            stream_read = None
+
     if rank == 0:
         algo_bytes = 4 * total_nt + 8 * (n_orfs + 1) + 24 * n_orfs
         achieved = algo_bytes / (k_main * 1e-3) / 1e9
@@ -494,6 +513,8 @@ def main():
                 "aux_kernels_ms": {"tile_index": k_index, "orf_finish": k_fin},
                 "step_achieved": algo_bytes / (dev_ms_per_step * 1e-3) / 1e9,
                 "step_frac": algo_bytes / (dev_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "stream_read": stream_read,
+                "frac_of_stream_read": (achieved / stream_read["GBps"]) if stream_read else None,
             },
             "per_rank": ranks,
             "quality": {

@@ -180,6 +180,12 @@ bool known_algo(int algo) { return algo == RP_ALGO_AUTO || algo == RP_ALGO_WAVE 
         }                                        \
     } while (0)
 
+// workgroups of the scoring launch (RP_TILES_PER_WG tiles each, rp_tile.hpp)
+inline unsigned score_grid(long long n_tiles)
+{
+    return (unsigned)((n_tiles + RP_TILES_PER_WG - 1) / RP_TILES_PER_WG);
+}
+
 int launch_plan_kernels(const int64_t *d_offsets, int64_t n_orfs, const rp::TilePlan &plan, int tile,
                         const rp::TileWorkspace &ws, int *d_err, hipStream_t stream)
 {
@@ -311,10 +317,10 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[1], stream));
     // 2. scoring pass over flat tiles: one record per (ORF, tile) segment
     if (gather != nullptr)
-        RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score<true, TILE>), dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
+        RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score<true, TILE>), dim3(score_grid(plan.n_tiles)), dim3(rp::kTileBlock), 0, stream,
                                               d_counts, (long long)n_orfs, plan, ws, piece_plan_of(gather)));
     else
-        RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score<false, TILE>), dim3((unsigned)plan.n_tiles), dim3(rp::kTileBlock), 0, stream,
+        RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score<false, TILE>), dim3(score_grid(plan.n_tiles)), dim3(rp::kTileBlock), 0, stream,
                                               d_counts, (long long)n_orfs, plan, ws, rp::PiecePlan{}));
     RP_HIP(hipGetLastError());
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));

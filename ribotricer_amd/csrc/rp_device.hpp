@@ -529,6 +529,25 @@ __device__ __forceinline__ bool near_cutoff(const FilterParams &fp, double phase
     return fp.enabled && fabs(phase - fp.phase_score_cutoff) <= kCutoffMargin;
 }
 
+// Stores of data that this kernel will not touch again.  Measured on gfx950 (scripts/probe_rw.py,
+// profiles/r03_probe_rw.txt): a read stream at 7.15 TB/s that also writes 1 152 bytes per 32 KiB read
+// -- 3.5 % more bytes, the segment records of k_tile_score -- loses 17 % with ordinary stores and 9 %
+// with `nt` stores (sc1: 10 %; sc0, dword instead of dwordx4, scalar stores, atomics, one plane or
+// three, earlier in the workgroup: all 16-19 %).  Writes cost five times their share of the bytes
+// when they ride a read stream, so every byte that need not be written is worth five read.
+#ifndef RP_NT_STORES
+#define RP_NT_STORES 1
+#endif
+template <typename T>
+__device__ __forceinline__ void stream_store(T *p, T v)
+{
+#if RP_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 struct OrfOutputs {
     double *phase;
     int32_t *valid;
@@ -542,13 +561,14 @@ __device__ __forceinline__ void store_orf(const OrfOutputs &out, const FilterPar
                                           double phase, int valid, long long read_count,
                                           int min_codon_cov, unsigned flags, long long length)
 {
-    out.phase[i] = phase;
-    out.valid[i] = valid;
-    out.read_count[i] = read_count;
-    out.min_codon_cov[i] = min_codon_cov;
-    out.flags[i] = (uint8_t)flags;
+    // results are written once and read by nobody on the device: streaming stores (see RP_NT_STORES)
+    stream_store(out.phase + i, phase);
+    stream_store(out.valid + i, (int32_t)valid);
+    stream_store(out.read_count + i, (int64_t)read_count);
+    stream_store(out.min_codon_cov + i, (int32_t)min_codon_cov);
+    stream_store(out.flags + i, (uint8_t)flags);
     if (out.status != nullptr && fp.enabled)
-        out.status[i] = orf_status(fp, phase, valid, read_count, min_codon_cov, length);
+        stream_store(out.status + i, (uint8_t)orf_status(fp, phase, valid, read_count, min_codon_cov, length));
 }
 
 }  // namespace rp

@@ -443,6 +443,7 @@ template <int TILE, int HALO>
 __global__ __launch_bounds__(kGatherTileBlock) void k_tile_gather(const int32_t *__restrict__ cov, PiecePlan pp,
                                                                   long long total_nt, int32_t *__restrict__ counts)
 {
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
     __shared__ __attribute__((aligned(16))) int s_counts[TILE + HALO];  // the rows are clipped for the scorer: halo included
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long b = blockIdx.x;
@@ -458,9 +459,9 @@ __global__ __launch_bounds__(kGatherTileBlock) void k_tile_gather(const int32_t 
     if (left >= TILE) {
 #pragma unroll
         for (int c = tid; c < TILE / 4; c += kGatherTileBlock)
-            reinterpret_cast<int4 *>(counts + t0)[c] = reinterpret_cast<const int4 *>(s_counts)[c];
+            stream_store(reinterpret_cast<i32x4_t *>(counts + t0) + c, reinterpret_cast<const i32x4_t *>(s_counts)[c]);
     } else {
-        for (int c = tid; c < (int)left; c += kGatherTileBlock) counts[t0 + c] = s_counts[c];
+        for (int c = tid; c < (int)left; c += kGatherTileBlock) stream_store(counts + t0 + c, (int32_t)s_counts[c]);
     }
 }
 

@@ -777,7 +777,15 @@ __device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, c
         if ((tail >> 16) == 2) codon += (unsigned)s_counts[(tail & 0xffff) + 1];
         extra = wave == 0 ? extra + codon : min(extra, codon);  // (<= 2 x 2^24 on top of the clo sum: fits)
     }
-    rec[wave * n_rec + id0 + seg] = make_uint4(__float_as_uint((float)a0), __float_as_uint((float)a1), n | (m << 16), extra);
+#ifdef RP_EXPERIMENT_NO_RECORD_STORE  // timing experiment only (results wrong): what the record stream costs the kernel
+    if (a0 == 12345.678) rec[wave * n_rec + id0 + seg] = make_uint4(0, 0, n, extra);
+#else
+    {   // written once, read once by the next kernel: a streaming store (rp_device.hpp, stream_store)
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        stream_store(reinterpret_cast<u32x4_t *>(rec + wave * n_rec + id0 + seg),
+                     u32x4_t{__float_as_uint((float)a0), __float_as_uint((float)a1), n | (m << 16), extra});
+    }
+#endif
 }
 
 // the segment's number of valid codon-start positions (every frame counted), from its descriptor:
@@ -849,26 +857,18 @@ __device__ __forceinline__ void short_round(seg_desc_t dc, const int *s_counts, 
 
 // FUSED: `counts` is the dense coverage and the tile is staged through the piece plan
 // (rp_pieces.hpp) -- the profiles never exist in HBM (plan.mis == 0 there).
+// The work of one workgroup on one tile (k_tile_score below calls it once, or RP_TILES_PER_WG times).
 template <bool FUSED, int TILE>
-__global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const int32_t *__restrict__ counts,
-                                                           long long n_orfs, TilePlan plan,
-                                                           TileWorkspace ws, PiecePlan pp)
+__device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, const TilePlan &plan, const TileWorkspace &ws,
+                                          const PiecePlan &pp, const long long b, int *__restrict__ s_counts, int *__restrict__ s_live,
+                                          int *__restrict__ s_tail, int *__restrict__ s_vlstart, int *__restrict__ s_owner,
+                                          RunRec *__restrict__ s_rec, int *__restrict__ s_geom)
 {
-    __shared__ __attribute__((aligned(16))) int s_counts[lds_counts<TILE>()];
-    __shared__ int s_live[kSegChunk];     // the slot holds a segment of this tile
-    __shared__ int s_tail[kSegChunk];     // LDS index of an owned partial last codon | its length << 16, or -1
-    __shared__ int s_vlstart[kSegChunk + 1];
-    __shared__ int s_owner[kTileBlock];   // short-ORF path: 64 private words per wave for the segment marks
-    __shared__ RunRec s_rec[kMaxRecs];
-    __shared__ int s_geom[kSegChunk];     // valid codon-start positions of the slot's segment (record stage)
-
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
-    const long long b = blockIdx.x;
     const long long t0 = b * (long long)TILE - plan.mis;  // position of LDS index 0 (may be < 0 for b == 0)
-
-    if (blockIdx.x == 0 && tid == 0) *ws.long_count = 0;  // (k_orf_finish, next in the stream, appends)
+    if (b == 0 && tid == 0) *ws.long_count = 0;  // (k_orf_finish, next in the stream, appends)
     RP_STAMP_DECL
     RP_STAMP();  // 0: entry
     // The tile's head row first -- its [a0, a1) ORF range through the scalar unit, its segment
@@ -1009,6 +1009,37 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const i
 #endif
     }
     RP_STAMP_FLUSH();
+}
+
+#ifndef RP_TILES_PER_WG
+#define RP_TILES_PER_WG 1  // > 1: a workgroup takes that many consecutive tiles one after the other (A/B knob)
+#endif
+template <bool FUSED, int TILE>
+__global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score(const int32_t *__restrict__ counts,
+                                                           long long n_orfs, TilePlan plan,
+                                                           TileWorkspace ws, PiecePlan pp)
+{
+    __shared__ __attribute__((aligned(16))) int s_counts[lds_counts<TILE>()];
+    __shared__ int s_live[kSegChunk];     // the slot holds a segment of this tile
+    __shared__ int s_tail[kSegChunk];     // LDS index of an owned partial last codon | its length << 16, or -1
+    __shared__ int s_vlstart[kSegChunk + 1];
+    __shared__ int s_owner[kTileBlock];   // short-ORF path: 64 private words per wave for the segment marks
+    __shared__ RunRec s_rec[kMaxRecs];
+    __shared__ int s_geom[kSegChunk];     // valid codon-start positions of the slot's segment (record stage)
+#if RP_TILES_PER_WG == 1
+    tile_body<FUSED, TILE>(counts, plan, ws, pp, (long long)blockIdx.x, s_counts, s_live, s_tail, s_vlstart, s_owner, s_rec, s_geom);
+#else
+    for (int k = 0; k < RP_TILES_PER_WG; ++k) {
+#ifdef RP_TILES_STRIDED
+        const long long b = (long long)k * gridDim.x + blockIdx.x;
+#else
+        const long long b = (long long)blockIdx.x * RP_TILES_PER_WG + k;
+#endif
+        if (b >= plan.n_tiles) break;  // (workgroup-uniform)
+        if (k) __syncthreads();        // the previous tile's record stage is done with LDS
+        tile_body<FUSED, TILE>(counts, plan, ws, pp, b, s_counts, s_live, s_tail, s_vlstart, s_owner, s_rec, s_geom);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kWaveBlock) void k_gather_profiles(
 #pragma unroll
                 for (int u = 0; u < kGatherUnroll; ++u) {  // every load above is in flight by now
                     const int a = a0 + u * kWave + lane;
-                    if (a < todo) dst[rev_j ? (int)len_j - 1 - a : a] = val[u];
+                    if (a < todo) stream_store(dst + (rev_j ? (int)len_j - 1 - a : a), (int32_t)val[u]);
                 }
             }
             if (nk_j > kWave) {  // more than 64 exons: the rest straight from memory

@@ -40,6 +40,8 @@ def test_bench_line_has_the_contract_fields():
     assert d["value"] > 0 and d["ms_per_step"] > 0
     assert "configs[2]" in d["config"]["workload"] and d["config"]["orfs_total"] == 60000
     assert d["roofline"]["kernel"] == "rp::k_tile_score"
+    sr = d["roofline"]["stream_read"]  # the live yardstick: a plain read of the same buffer
+    assert sr is not None and sr["GBps"] > 0 and 0 < d["roofline"]["frac_of_stream_read"] < 1.5
     # after the timed region: head / middle / tail slices against the oracle, the fused section, the single-sample rate
     v = d["verify"]
     assert v["ok"] is True and v["orfs_checked"] >= 60000 and v["max_abs_dphase"] <= 1e-6 and v["read_count_checksum_ok"] is True
