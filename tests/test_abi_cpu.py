@@ -34,6 +34,20 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(_lib.SYMBOLS) == declared, "Python binding table and header disagree"
 
 
+def test_stream_probe_is_a_separate_library_that_only_measuring_code_loads():
+    """csrc/stream_probe.hip (bench.py's yardstick) is built beside the product library, exports its three
+    entry points, and no product module refers to it."""
+    path = os.path.join(REPO, "ribotricer_amd", "csrc", "libstreamprobe.so")
+    assert os.path.exists(path), "run `make -C ribotricer_amd/csrc` (build() does)"
+    lib = ctypes.CDLL(path)
+    for name in ("sp_stream_read", "sp_stream_read_lds", "sp_stream_rw"):
+        assert hasattr(lib, name), name
+    pkg = os.path.join(REPO, "ribotricer_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py") and f != "_probe.py":
+            assert "_probe" not in open(os.path.join(pkg, f)).read(), f"{f} must not use the measuring stick"
+
+
 def test_version_and_status_strings():
     assert _lib.version() == "0.3.0"
     lib = _lib.load()
