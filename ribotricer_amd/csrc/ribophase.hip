@@ -253,6 +253,8 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
                const rp_plan *plan_h, void *hip_stream, Timing *tm, const rp_gather_plan *gather = nullptr)
 {
     if (n_orfs < 0 || total_nt < 0) return fail(RP_ERR_SIZE, "n_orfs=%lld total_nt=%lld must be >= 0", (long long)n_orfs, (long long)total_nt);
+    if (total_nt >= (1ll << 40))  // (4 TiB of counts: rp::tile_of keeps 32 bits of position >> 8)
+        return fail(RP_ERR_SIZE, "total_nt=%lld exceeds 2^40 positions per call", (long long)total_nt);
     if (!known_algo(algo)) return fail(RP_ERR_ARG, "unknown algo %d", algo);
     if (n_orfs > 0 && (!d_offsets || !d_phase || !d_valid || !d_read_count || !d_min_codon_cov || !d_flags))
         return fail(RP_ERR_NULL, "offsets and the five output arrays must be non-null");

@@ -98,6 +98,18 @@ struct TilePlan {
 // profiles/r03_ab_inkernel_finish.txt.)
 constexpr size_t kRecordBytes = 48;
 
+// position -> tile for x >= 0 without a 64-bit division (TILE = 2^k * m, m odd and small): the
+// shifted value fits 32 bits for every set that fits this GPU's memory (x < 2^(32 + k) >= 2^40
+// positions), and a 32-bit division by a constant is a multiply-high.  k_orf_finish is bound by
+// its vector ALUs (70 % busy), and the two 64-bit divisions were ~50 of its ~350 main-path instructions.
+template <int TILE>
+__device__ __forceinline__ long long tile_of(long long x)
+{
+    constexpr int k = __builtin_ctz((unsigned)TILE);
+    constexpr unsigned m = (unsigned)TILE >> k;
+    return (long long)((unsigned)((unsigned long long)x >> k) / m);
+}
+
 // One descriptor per segment id, derived from the offsets alone (k_tile_desc): where the
 // segment's triplets lie inside its tile's LDS image and how many lanes walk them.
 //   bits  0-12  qfirst   LDS index of the first owned triplet
@@ -1132,8 +1144,8 @@ __global__ __launch_bounds__(kFinishBlock, RP_FINISH_WAVES) void k_orf_finish(So
         double p[3] = {0, 0, 0}, q[3] = {0, 0, 0};
         int n[3] = {0, 0, 0}, m[3] = {0, 0, 0};
         if (len > 0) {
-            const long long b_first = (beg + plan.mis) / TILE;
-            const long long b_last = (beg + len - 1 + plan.mis) / TILE;
+            const long long b_first = tile_of<TILE>(beg + plan.mis);
+            const long long b_last = tile_of<TILE>(beg + len - 1 + plan.mis);
             for (long long b = b_first; b <= b_last; ++b) {  // tile order: deterministic sums
                 const uint4 w0 = ws.rec[orf + b], w1 = ws.rec[ws.n_rec + orf + b], w2 = ws.rec[2 * ws.n_rec + orf + b];
                 p[0] += (double)__uint_as_float(w0.x);
