@@ -17,7 +17,11 @@
 // Plain C++17, no HIP.
 #pragma once
 
+#include <sys/mman.h>
+
 #include <algorithm>
+#include <cstdlib>
+#include <new>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -35,6 +39,19 @@ enum ParseError : int { kOk = 0, kColumns = 1, kCoordinate = 2 };
 // std::vector / byte buffer whose resize() leaves new elements uninitialised: the stitched arrays of
 // an 11 M-line index are 2 GB that would otherwise be zero-filled by one thread before the parser
 // threads overwrite every byte of them.
+// Large blocks (>= 8 MiB) are 2 MiB aligned and marked MADV_HUGEPAGE: the parser's output arrays of an
+// 11 M-line index are ~2 GB touched for the first time by the parser threads, i.e. half a million
+// 4 KiB page faults, or a thousand 2 MiB ones where transparent huge pages are in `madvise` mode
+// (the GPU boxes).  RIBOPHASE_HUGEPAGES=0 switches it off (A/B).
+inline bool use_hugepages()
+{
+    static const bool on = [] {
+        const char *e = std::getenv("RIBOPHASE_HUGEPAGES");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 template <typename T>
 struct DefaultInitAlloc : std::allocator<T> {
     template <typename U>
@@ -42,6 +59,22 @@ struct DefaultInitAlloc : std::allocator<T> {
         using other = DefaultInitAlloc<U>;
     };
     using std::allocator<T>::allocator;
+    static constexpr size_t kHuge = size_t(2) << 20, kHugeMin = size_t(8) << 20;
+    T *allocate(size_t n)
+    {
+        const size_t bytes = n * sizeof(T);
+        if (bytes >= kHugeMin && use_hugepages()) {
+            void *p = nullptr;
+            const size_t rounded = (bytes + kHuge - 1) & ~(kHuge - 1);
+            if (posix_memalign(&p, kHuge, rounded) != 0) throw std::bad_alloc();
+            madvise(p, rounded, MADV_HUGEPAGE);
+            return static_cast<T *>(p);
+        }
+        void *p = std::malloc(bytes ? bytes : 1);
+        if (!p) throw std::bad_alloc();
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, size_t) noexcept { std::free(p); }
     template <typename U>
     void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value)
     {
