@@ -32,7 +32,8 @@ the drop-in export path runs by default (gather + score fused, rp::k_tile_score<
 exon layout of the same length law, with its own `verify` -- and `roofline.stream_read` -- a plain
 streaming read of the same counts buffer in the same process (csrc/stream_probe.hip), the yardstick
 next to which `frac_of_stream_read` puts the kernel (the kernel's time depends on where its buffers
-lie, by up to 15 % from process to process; the plain read does not).
+lie, by up to 15 % from process to process; the plain read does not; `record_write_penalty` there says
+which case this run was: DESIGN.md section 4).
 """
 
 from __future__ import annotations
@@ -460,6 +461,17 @@ def main():
             gbps, ms = stream_read_GBps(counts, launches=10, flavour="lds_dma")
             stream_read = {"GBps": gbps, "ms": ms, "bytes": int(counts.numel()) * 4 // 32768 * 32768,
                            "what": "csrc/stream_probe.hip k_stream_read_lds over the counts buffer of this run, after the timed region"}
+            # ... and where do this run's record workspace and counts lie relative to each other?  (the write stream
+            # costs a read stream ~10 % or ~23 % depending on whether the two share a class of the physical address
+            # space: profiles/r03_probe_rw_regions.txt; the records are dead after the steps, the probe overwrites them)
+            from ribotricer_amd._probe import write_penalty
+
+            ws_t = next(iter(eng._workspace.values()), None)
+            wp = write_penalty(counts, ws_t) if ws_t is not None else None
+            if wp is not None:
+                stream_read["record_write_penalty"] = {"penalty": wp[0], "read_only_ms": wp[1], "read_plus_writes_ms": wp[2],
+                                                       "what": "2 GiB of the counts read, 1 152 B per 32 KiB written into the engine's record workspace "
+                                                               "(csrc/stream_probe.hip k_stream_rw): ~0.10 = different classes of physical memory, ~0.23 = the same"}
         except ImportError:
             stream_read = None
 

@@ -21,6 +21,9 @@ def _load():
             fn = getattr(_lib, name)
             fn.restype = ctypes.c_int
             fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.sp_stream_rw.restype = ctypes.c_int
+        _lib.sp_stream_rw.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_void_p]
     return _lib
 
 
@@ -49,3 +52,45 @@ def stream_read_GBps(buf, launches: int = 20, warmup: int = 3, flavour: str = "r
     torch.cuda.synchronize(buf.device)
     ms = e0.elapsed_time(e1) / launches
     return nbytes / ms / 1e6, ms
+
+
+
+def write_penalty(read_buf, write_buf, read_bytes: int = 2 << 30, launches: int = 8):
+    """How much does a sprinkle of writes into `write_buf` (1 152 bytes per 32 KiB read, streaming stores, three
+    planes: the scoring kernel's record stream) cost a read stream over the middle of `read_buf`?  Returns
+    (penalty, ms without writes, ms with writes); penalty = with / without - 1.  On MI355X the penalty is ~0.10 when
+    the two buffers lie in different classes of the physical address space and ~0.23 when they share one
+    (profiles/r03_probe_rw_regions.txt) -- the spread of the scoring kernel over "placements".  Overwrites the
+    middle of `write_buf` (a uint8 tensor of >= 3 * 384 * read_bytes / 32768 bytes)."""
+    import torch
+
+    lib = _load()
+    total = read_buf.numel() * read_buf.element_size()
+    nbytes = min(read_bytes, total) // 32768 * 32768
+    blocks = nbytes // 32768
+    plane = blocks * 384
+    need = 3 * plane
+    wtotal = write_buf.numel() * write_buf.element_size()
+    if nbytes == 0 or wtotal < need:
+        return None
+    rptr = read_buf.data_ptr() + ((total - nbytes) // 2) // 32768 * 32768
+    wptr = write_buf.data_ptr() + ((wtotal - need) // 2) // 4096 * 4096
+    scratch = torch.zeros(1, dtype=torch.int64, device=read_buf.device)
+    stream = torch.cuda.current_stream(read_buf.device)
+
+    def run(mode):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(launches + 2):
+            if i == 2:
+                e0.record(stream)
+            rc = lib.sp_stream_rw(rptr, nbytes, wptr, plane, 1152, mode, scratch.data_ptr(), stream.cuda_stream)
+            if rc:
+                raise RuntimeError(f"stream probe failed ({rc})")
+        e1.record(stream)
+        torch.cuda.synchronize(read_buf.device)
+        return e0.elapsed_time(e1) / launches
+
+    plain = min(run(0), run(0))
+    mixed = min(run(15), run(15))
+    return mixed / plain - 1.0, plain, mixed
+

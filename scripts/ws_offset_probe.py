@@ -25,9 +25,12 @@ def main():
     stream_key = int(torch.cuda.current_stream().cuda_stream)
     ws0 = eng._workspace[stream_key]
     need = ws0.numel()
-    big = torch.empty(need + (8 << 20), dtype=torch.uint8, device="cuda:0")
+    far = len(sys.argv) > 2 and sys.argv[2] == "far"  # offsets of 64 MiB ... 24 GiB inside one 26 GiB allocation
+    big = torch.empty(need + ((26 << 30) if far else (8 << 20)), dtype=torch.uint8, device="cuda:0")
     rows = []
-    for off in (0, 256, 1024, 4096, 16384, 65536, 262144, 1 << 20, 2 << 20, (2 << 20) + 4096, 4 << 20, 0):
+    near = (0, 256, 1024, 4096, 16384, 65536, 262144, 1 << 20, 2 << 20, (2 << 20) + 4096, 4 << 20, 0)
+    steps = (0, 64 << 20, 256 << 20, 512 << 20, 1 << 30, 3 << 29, 2 << 30, 3 << 30, 4 << 30, 6 << 30, 8 << 30, 12 << 30, 16 << 30, 20 << 30, 24 << 30, 0)
+    for off in (steps if far else near):
         eng._workspace[stream_key] = big[off : off + need]
         t = []
         for _ in range(3):
