@@ -123,6 +123,12 @@ int rp_filter_defaults(rp_filter_params *out);
  * Bytes of device workspace rp_phase_score_csr_dev needs for a batch of this
  * shape (one 48-byte record per ORF and per tile, the long re-walk queue, and -- without a plan -- the tile index, descriptors and head rows).  16-byte aligned
  * pointer required.
+ * Placement matters on MI355X: the scorer writes its records into the workspace while it streams
+ * the counts, and a write stream costs a read stream ~10 % when the two buffers lie in different
+ * classes of the physical address space (runs of 16-32 GiB) and ~23 % when they share one -- 2.6 vs
+ * 3.0 ms per 4 G nt.  HIP has no placement hint; a caller that scores many batches can allocate a
+ * few candidate workspaces some GiB apart, time a call on each and keep the fastest (what
+ * ribotricer_amd's engine.tune_workspace does).
  */
 int rp_workspace_bytes(int64_t n_orfs, int64_t total_nt, int algo, size_t *bytes);
 

@@ -175,6 +175,66 @@ class PhaseScoreEngine:
             self._workspace[stream_key] = ws
         return ws
 
+    def tune_workspace(self, counts, offsets=None, thresholds: Optional[FilterParams] = None, tries: int = 6,
+                       chunk_gib: float = 8.0, launches: int = 5, spread: float = 0.05, gather_plan=None) -> dict:
+        """Opt-in, once per engine and index: look for a placement of the current stream's record workspace
+        whose writes do not share a class of physical memory with the counts they ride beside.
+
+        On MI355X a write stream costs a read stream ~10 % when the two buffers lie in different classes of the
+        physical address space (runs of 16-32 GiB) and ~23 % when they share one; the tile kernel writes its
+        segment records while it streams the counts and takes 2.6 or 3.0 ms per 4 G nt accordingly (DESIGN.md
+        section 4, profiles/r03_probe_rw_regions.txt).  HIP has no placement hint and a fresh allocation
+        usually lands next to the previous one, so this allocates up to ``tries`` candidate workspaces of
+        ``chunk_gib`` one after the other -- the earlier ones stay allocated meanwhile, as spacers, which
+        walks the candidates through physical memory (28 GiB of candidates cross a class boundary in about
+        half of the processes measured) -- times the scoring step of THIS batch on each, and stops early once
+        a candidate beats the slowest seen by ``spread``.  The fastest stays, the rest goes back to the driver
+        (``torch.cuda.empty_cache()``).  Never slower than before (the first workspace is a candidate), 0.1 s
+        and ``tries * chunk_gib`` GiB held for a moment; pays when one index is scored against many samples.
+        With ``gather_plan`` the fused path is tuned instead: ``counts`` is then the dense coverage
+        (:meth:`score_coverage`).  Returns what it measured."""
+        dev = self.device
+        if gather_plan is None:
+            counts = _as_device(counts, torch.int32, dev)
+            offsets = _as_device(offsets, torch.int64, dev)
+            n, total_nt = offsets.numel() - 1, counts.numel()
+
+            def run(t=None):
+                self.score(counts, offsets, thresholds=thresholds, algo="tile", reuse_outputs=True, timings=t)
+        else:  # the fused path: `counts` is the dense coverage, the profiles are read through the gather plan
+            n, total_nt = gather_plan.n_orfs, gather_plan.total_nt
+
+            def run(t=None):
+                self.score_coverage(counts, gather_plan, thresholds=thresholds, reuse_outputs=True, timings=t)
+        stream_key = int(torch.cuda.current_stream(dev).cuda_stream)
+        nbytes = max(_lib.workspace_bytes(n, total_nt, _lib.RP_ALGO_TILE), int(chunk_gib * (1 << 30)))
+
+        def step_ms():
+            t: list = []
+            run()
+            for _ in range(launches):
+                run(t)
+            return sorted(x[1] + x[2] for x in t)[len(t) // 2]
+
+        run()  # plan, outputs, first workspace
+        held = [self._workspace[stream_key]]
+        times = [step_ms()]
+        try:
+            while len(held) <= tries and not (len(times) > 1 and times[-1] <= (1.0 - spread) * max(times)):
+                held.append(torch.empty(nbytes, dtype=torch.uint8, device=dev))
+                self._workspace[stream_key] = held[-1]
+                times.append(step_ms())
+        except torch.cuda.OutOfMemoryError:
+            held = held[: len(times)]
+        best = min(range(len(times)), key=times.__getitem__)
+        self._workspace[stream_key] = held[best]
+        report = {"step_ms": [round(t, 4) for t in times], "chosen": best, "chunk_gib": chunk_gib,
+                  "what": "engine.tune_workspace: candidate record workspaces allocated one after the other, the scoring step timed on each"}
+        del held
+        torch.cuda.synchronize(dev)
+        torch.cuda.empty_cache()
+        return report
+
     def _get_outputs(self, n: int, with_status: bool, stream_key: int) -> PhaseScores:
         o = self._out.get(stream_key)
         if o is None or o.phase.numel() != n or (with_status and o.status is None):

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Does it matter which of several workspace allocations the scoring kernel writes its records to?  One set, one
-engine, K workspaces allocated one after the other (spacer allocations in between), the kernel timed on each in two
-rounds (order bias), then engine.tune_workspace.  usage: tune_workspace_probe.py [K] [spacer GiB]"""
+"""engine.tune_workspace on a cfg3 batch: step time before, what the search saw, step time after.
+usage: tune_workspace_probe.py [cfg:n_orfs] [chunk GiB] [tries] [spread (1 = try them all)]"""
 import json
 import os
 import sys
+import time
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
@@ -13,33 +13,31 @@ sys.path.insert(0, REPO)
 def main():
     import torch
 
-    from ribotricer_amd import _lib
     from ribotricer_amd.engine import PhaseScoreEngine, make_filter
     from ribotricer_amd.synth import synth_csr_device
 
-    k_cand = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-    spacer = float(sys.argv[2]) if len(sys.argv) > 2 else 8.0
-    counts, offsets = synth_csr_device(11_000_000, cfg="cfg3", device="cuda:0")
-    eng = PhaseScoreEngine("cuda:0")
+    cfg, n = (sys.argv[1] if len(sys.argv) > 1 else "cfg3:11000000").split(":")
+    chunk = float(sys.argv[2]) if len(sys.argv) > 2 else 4.0
+    tries = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    counts, offsets = synth_csr_device(int(n), cfg=cfg, device="cuda:0")
     th = make_filter()
-    eng.score(counts, offsets, thresholds=th, algo="tile", reuse_outputs=True)
-    key = int(torch.cuda.current_stream().cuda_stream)
-    nbytes = eng._workspace[key].numel()
-    pool, spacers = [eng._workspace[key]], []
-    for _ in range(1, k_cand):
-        spacers.append(torch.empty(int(spacer * (1 << 30)), dtype=torch.uint8, device="cuda:0"))
-        pool.append(torch.empty(nbytes, dtype=torch.uint8, device="cuda:0"))
+    eng = PhaseScoreEngine("cuda:0")
 
-    def ms(ws):
-        eng._workspace[key] = ws
-        t = []
+    def now():
+        tm = []
         eng.score(counts, offsets, thresholds=th, algo="tile", reuse_outputs=True)
-        for _ in range(5):
-            eng.score(counts, offsets, thresholds=th, algo="tile", reuse_outputs=True, timings=t)
-        return round(sorted(x[1] for x in t)[2], 3)
+        for _ in range(10):
+            eng.score(counts, offsets, thresholds=th, algo="tile", reuse_outputs=True, timings=tm)
+        return [round(sorted(x[k] for x in tm)[5], 3) for k in (1, 2)]
 
-    rounds = [[ms(w) for w in pool] for _ in range(2)] + [[ms(w) for w in reversed(pool)][::-1]]
-    print(json.dumps({"counts": hex(counts.data_ptr()), "workspaces": [hex(w.data_ptr()) for w in pool], "kernel_ms_rounds": rounds}))
+    before = now()
+    if os.environ.get("KEEP_CACHE") == "1":  # (experiment: do the freed candidates have to go back to the driver?)
+        torch.cuda.empty_cache = lambda: None
+    t = time.perf_counter()
+    rep = eng.tune_workspace(counts, offsets, thresholds=th, chunk_gib=chunk, tries=tries, spread=float(sys.argv[4]) if len(sys.argv) > 4 else 0.06)
+    dt = time.perf_counter() - t
+    print(json.dumps({"before_kernel_finish_ms": before, "tune_s": round(dt, 2), "search_step_ms": rep["step_ms"], "chosen": rep["chosen"],
+                      "after_kernel_finish_ms": now()}))
 
 
 if __name__ == "__main__":

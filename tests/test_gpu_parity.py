@@ -433,3 +433,25 @@ def test_full_size_properties(eng, algo):
     o_end = int(offsets[n_chk])
     res = {k: v[:n_chk].cpu().numpy() for k, v in a._asdict().items() if v is not None}
     assert_matches_oracle(res, counts[:o_end].cpu().numpy(), offsets[: n_chk + 1].cpu().numpy())
+
+
+def test_tune_workspace_changes_placement_not_results():
+    """engine.tune_workspace (opt-in placement search for the record workspace) leaves every result bit-identical
+    and never picks a slower candidate than the first workspace."""
+    import torch
+
+    from ribotricer_amd.engine import PhaseScoreEngine, make_filter
+    from ribotricer_amd.synth import synth_csr_device
+
+    counts, offsets = synth_csr_device(400_000, seed=11, cfg="cfg3", device="cuda:0")
+    eng = PhaseScoreEngine("cuda:0")
+    th = make_filter()
+    before = eng.score(counts, offsets, thresholds=th, algo="tile")
+    rep = eng.tune_workspace(counts, offsets, thresholds=th, tries=3, chunk_gib=0.5)
+    after = eng.score(counts, offsets, thresholds=th, algo="tile")
+    torch.cuda.synchronize()
+    assert 1 <= len(rep["step_ms"]) <= 4 and 0 <= rep["chosen"] < len(rep["step_ms"])
+    assert rep["step_ms"][rep["chosen"]] == min(rep["step_ms"])
+    for k in ("phase", "valid", "read_count", "min_codon_cov", "flags", "status"):
+        assert torch.equal(getattr(before, k), getattr(after, k)), k
+
