@@ -176,7 +176,8 @@ class PhaseScoreEngine:
         return ws
 
     def tune_workspace(self, counts, offsets=None, thresholds: Optional[FilterParams] = None, tries: int = 6,
-                       chunk_gib: float = 8.0, launches: int = 5, spread: float = 0.05, gather_plan=None) -> dict:
+                       chunk_gib: float = 8.0, launches: int = 5, spread: float = 0.05, gather_plan=None,
+                       release: bool = False) -> dict:
         """Opt-in, once per engine and index: look for a placement of the current stream's record workspace
         whose writes do not share a class of physical memory with the counts they ride beside.
 
@@ -188,9 +189,11 @@ class PhaseScoreEngine:
         ``chunk_gib`` one after the other -- the earlier ones stay allocated meanwhile, as spacers, which
         walks the candidates through physical memory (28 GiB of candidates cross a class boundary in about
         half of the processes measured) -- times the scoring step of THIS batch on each, and stops early once
-        a candidate beats the slowest seen by ``spread``.  The fastest stays, the rest goes back to the driver
-        (``torch.cuda.empty_cache()``).  Never slower than before (the first workspace is a candidate), 0.1 s
-        and ``tries * chunk_gib`` GiB held for a moment; pays when one index is scored against many samples.
+        a candidate beats the slowest seen by ``spread``.  The fastest stays; the others go back to PyTorch's
+        caching allocator (later tensors reuse them) or, with ``release``, to the driver
+        (``torch.cuda.empty_cache()``; the driver wipes freed memory in the background, which costs the
+        kernels of the next second 1-4 %).  Never slower than before (the first workspace is a candidate),
+        0.1 s, up to ``tries * chunk_gib`` GiB touched; pays when one index is scored against many samples.
         With ``gather_plan`` the fused path is tuned instead: ``counts`` is then the dense coverage
         (:meth:`score_coverage`).  Returns what it measured."""
         dev = self.device
@@ -216,7 +219,8 @@ class PhaseScoreEngine:
                 run(t)
             return sorted(x[1] + x[2] for x in t)[len(t) // 2]
 
-        run()  # plan, outputs, first workspace
+        for _ in range(3):  # plan, outputs, first workspace; clocks up
+            run()
         held = [self._workspace[stream_key]]
         times = [step_ms()]
         try:
@@ -231,8 +235,9 @@ class PhaseScoreEngine:
         report = {"step_ms": [round(t, 4) for t in times], "chosen": best, "chunk_gib": chunk_gib,
                   "what": "engine.tune_workspace: candidate record workspaces allocated one after the other, the scoring step timed on each"}
         del held
-        torch.cuda.synchronize(dev)
-        torch.cuda.empty_cache()
+        if release:  # back to the driver -- which wipes freed memory in the background: the next second of kernels runs 1-4 % slower
+            torch.cuda.synchronize(dev)
+            torch.cuda.empty_cache()
         return report
 
     def _get_outputs(self, n: int, with_status: bool, stream_key: int) -> PhaseScores:
