@@ -61,7 +61,7 @@ def write_penalty(read_buf, write_buf, read_bytes: int = 2 << 30, launches: int 
     (penalty, ms without writes, ms with writes); penalty = with / without - 1.  On MI355X the penalty is ~0.10 when
     the two buffers lie in different classes of the physical address space and ~0.23 when they share one
     (profiles/r03_probe_rw_regions.txt) -- the spread of the scoring kernel over "placements".  Overwrites the
-    middle of `write_buf` (a uint8 tensor of >= 3 * 384 * read_bytes / 32768 bytes)."""
+    head of `write_buf` (a uint8 tensor of >= 3 * 384 * read_bytes / 32768 bytes)."""
     import torch
 
     lib = _load()
@@ -74,7 +74,7 @@ def write_penalty(read_buf, write_buf, read_bytes: int = 2 << 30, launches: int 
     if nbytes == 0 or wtotal < need:
         return None
     rptr = read_buf.data_ptr() + ((total - nbytes) // 2) // 32768 * 32768
-    wptr = write_buf.data_ptr() + ((wtotal - need) // 2) // 4096 * 4096
+    wptr = write_buf.data_ptr()  # the head of the buffer: where the kernels put their records
     scratch = torch.zeros(1, dtype=torch.int64, device=read_buf.device)
     stream = torch.cuda.current_stream(read_buf.device)
 
