@@ -479,11 +479,13 @@ def main():
             from ribotricer_amd._probe import write_penalty
 
             ws_t = next(iter(eng._workspace.values()), None)
-            wp = write_penalty(counts, ws_t) if ws_t is not None else None
-            if wp is not None:
-                stream_read["record_write_penalty"] = {"penalty": wp[0], "read_only_ms": wp[1], "read_plus_writes_ms": wp[2],
-                                                       "what": "2 GiB of the counts read, 1 152 B per 32 KiB written into the engine's record workspace "
-                                                               "(csrc/stream_probe.hip k_stream_rw): ~0.10 = different classes of physical memory, ~0.23 = the same"}
+            wps = [write_penalty(counts, ws_t, where=w) for w in (0.0, 0.5, 1.0)] if ws_t is not None else []
+            if wps and all(w is not None for w in wps):
+                stream_read["record_write_penalty"] = {"penalty": [w[0] for w in wps], "read_only_ms": [w[1] for w in wps],
+                                                       "read_plus_writes_ms": [w[2] for w in wps],
+                                                       "what": "2 GiB of the counts read (head / middle / tail of the array), 1 152 B per 32 KiB written into the head of "
+                                                               "the engine's record workspace (csrc/stream_probe.hip k_stream_rw): ~0.10 = different classes of "
+                                                               "physical memory, ~0.2 = the same; a 16 GB array can span two classes"}
         except ImportError:
             stream_read = None
 

@@ -55,9 +55,9 @@ def stream_read_GBps(buf, launches: int = 20, warmup: int = 3, flavour: str = "r
 
 
 
-def write_penalty(read_buf, write_buf, read_bytes: int = 2 << 30, launches: int = 8):
+def write_penalty(read_buf, write_buf, read_bytes: int = 2 << 30, launches: int = 8, where: float = 0.5):
     """How much does a sprinkle of writes into `write_buf` (1 152 bytes per 32 KiB read, streaming stores, three
-    planes: the scoring kernel's record stream) cost a read stream over the middle of `read_buf`?  Returns
+    planes: the scoring kernel's record stream) cost a read stream over a 2 GiB slice of `read_buf` (`where`)?  Returns
     (penalty, ms without writes, ms with writes); penalty = with / without - 1.  On MI355X the penalty is ~0.10 when
     the two buffers lie in different classes of the physical address space and ~0.23 when they share one
     (profiles/r03_probe_rw_regions.txt) -- the spread of the scoring kernel over "placements".  Overwrites the
@@ -73,7 +73,7 @@ def write_penalty(read_buf, write_buf, read_bytes: int = 2 << 30, launches: int 
     wtotal = write_buf.numel() * write_buf.element_size()
     if nbytes == 0 or wtotal < need:
         return None
-    rptr = read_buf.data_ptr() + ((total - nbytes) // 2) // 32768 * 32768
+    rptr = read_buf.data_ptr() + int((total - nbytes) * min(max(where, 0.0), 1.0)) // 32768 * 32768  # `where`: 0 = head, 1 = tail of read_buf
     wptr = write_buf.data_ptr()  # the head of the buffer: where the kernels put their records
     scratch = torch.zeros(1, dtype=torch.int64, device=read_buf.device)
     stream = torch.cuda.current_stream(read_buf.device)

@@ -18,4 +18,4 @@ for k in range(2 * (int(sys.argv[1]) if len(sys.argv) > 1 else 3)):
     r = d["roofline"]
     wp = d["config"]["workspace_placement"]
     print("tuned " if not extra else "plain ", "value %.3e" % d["value"], "kernel", round(r["kernel_ms"], 3), round(r["frac"], 3), "step_frac", round(r["step_frac"], 3),
-          "penalty", round(r["stream_read"]["record_write_penalty"]["penalty"], 3), wp["step_ms"] if isinstance(wp, dict) else "", flush=True)
+          "penalty", [round(x, 3) for x in r["stream_read"]["record_write_penalty"]["penalty"]], wp["step_ms"] if isinstance(wp, dict) else "", flush=True)
