@@ -21,6 +21,11 @@ the plan rebuilt inside every step (an index used for ONE sample).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
+Once per index and outside the timed region, like the plan build: `engine.tune_workspace` tries a few
+placements of the record workspace and keeps the fastest (on MI355X a write stream costs a read stream
+10 % or 23 % depending on the classes of physical memory the two buffers lie in, DESIGN.md section 4);
+what it saw is reported in `config.workspace_placement`, `--no-tune-workspace` switches it off.
+
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (algorithmic bytes
 B = 4*sum(L) + 8*(n+1) + 24*n per launch over its HIP-event duration, vs the 8 TB/s
 HBM peak); `cpu_baseline` is the literal scipy restatement of the reference's phasescore
