@@ -492,6 +492,13 @@ int rp_format_double_repr(double value, char *buf);
 size_t rp_format_int_list(const int32_t *values, int64_t n, char *out);
 
 /*
+ * The body of one variableStep block of export_wig (detect_orfs.py:346-351): "{pos}\t{count}\n" for n
+ * positions into out (>= 42*n bytes); returns the length.  The "variableStep chrom=..." header lines
+ * stay with the caller.
+ */
+size_t rp_format_wig_rows_host(const int64_t *pos, const int64_t *count, int64_t n, char *out);
+
+/*
  * Same as rp_phase_score_csr_dev (plan == NULL) or rp_phase_score_csr_plan_dev (plan given)
  * but brackets each internal launch with HIP events on `hip_stream`, synchronises, and
  * reports milliseconds: ms[0] tile-index pass (0 with a plan), ms[1] main scoring kernel,

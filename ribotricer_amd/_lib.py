@@ -98,6 +98,7 @@ SYMBOLS = {
     "rp_bam_free": (None, [_vp]),
     "rp_format_double_repr": (_int, [ctypes.c_double, _vp]),
     "rp_format_int_list": (ctypes.c_size_t, [_vp, _i64, _vp]),
+    "rp_format_wig_rows_host": (ctypes.c_size_t, [_vp, _vp, _i64, _vp]),
 }
 
 _lib = None

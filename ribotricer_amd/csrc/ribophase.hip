@@ -1043,6 +1043,11 @@ size_t rp_format_int_list(const int32_t *values, int64_t n, char *out)
     return (out && (values || n <= 0)) ? rpfmt::int_list_str(values, n, out) : 0;
 }
 
+size_t rp_format_wig_rows_host(const int64_t *pos, const int64_t *count, int64_t n, char *out)
+{
+    return (out && n > 0 && pos && count) ? rpfmt::wig_rows_str(pos, count, n, out) : 0;
+}
+
 int rp_validate_csr_dev(int device, const int32_t *d_counts, const int64_t *d_offsets,
                         int64_t n_orfs, int64_t total_nt, void *hip_stream)
 {

@@ -116,6 +116,20 @@ inline int int_str(long long v, char *buf)
     return (int)(o - buf);
 }
 
+// the body lines of a variableStep WIG block, detect_orfs.py:346-351: "{pos}\t{count}\n" per position.
+// Returns bytes written; out must hold 42 * n bytes.
+inline size_t wig_rows_str(const int64_t *pos, const int64_t *count, long long n, char *out)
+{
+    char *o = out;
+    for (long long k = 0; k < n; ++k) {
+        o += int_str(pos[k], o);
+        *o++ = '\t';
+        o += int_str(count[k], o);
+        *o++ = '\n';
+    }
+    return (size_t)(o - out);
+}
+
 // str(list_of_int): "[a, b, c]".  Returns bytes written; out must hold list_bound(n).
 inline size_t list_bound(long long n) { return 2 + (size_t)(n > 0 ? n : 0) * 13; }  // "-2147483648, "
 
