@@ -485,6 +485,14 @@ int rp_bam_split_host(const char *path, int protocol, const int32_t *read_length
 int rp_bam_view_host(const rp_bam *bam, rp_bam_view *view);
 void rp_bam_free(rp_bam *bam);
 
+/*
+ * Measurement aid: while the tag is on (process-wide), scoring launches use a second instantiation of the
+ * scoring kernel (rp::k_tile_score_probe -- same code, another name), so that a profiler's per-kernel
+ * statistics of rp::k_tile_score hold the production launches only.  ribotricer_amd's
+ * engine.tune_workspace brackets its candidate timings with it.  Returns the previous state.
+ */
+int rp_measurement_tag(int on);
+
 /* repr(float) of CPython 3 into buf (>= 32 bytes, not NUL-terminated); returns the length. */
 int rp_format_double_repr(double value, char *buf);
 

@@ -99,6 +99,7 @@ SYMBOLS = {
     "rp_format_double_repr": (_int, [ctypes.c_double, _vp]),
     "rp_format_int_list": (ctypes.c_size_t, [_vp, _i64, _vp]),
     "rp_format_wig_rows_host": (ctypes.c_size_t, [_vp, _vp, _i64, _vp]),
+    "rp_measurement_tag": (ctypes.c_int, [ctypes.c_int]),
 }
 
 _lib = None

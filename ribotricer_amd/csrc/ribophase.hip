@@ -5,6 +5,8 @@
 // CPU compute path: if HIP is unusable every compute entry point fails.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -180,6 +182,8 @@ bool known_algo(int algo) { return algo == RP_ALGO_AUTO || algo == RP_ALGO_WAVE 
         }                                        \
     } while (0)
 
+std::atomic<int> g_measurement_tag{0};
+
 // workgroups of the scoring launch (RP_TILES_PER_WG tiles each, rp_tile.hpp)
 inline unsigned score_grid(long long n_tiles)
 {
@@ -318,12 +322,22 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     }
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[1], stream));
     // 2. scoring pass over flat tiles: one record per (ORF, tile) segment
-    if (gather != nullptr)
-        RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score<true, TILE>), dim3(score_grid(plan.n_tiles)), dim3(rp::kTileBlock), 0, stream,
-                                              d_counts, (long long)n_orfs, plan, ws, piece_plan_of(gather)));
-    else
-        RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score<false, TILE>), dim3(score_grid(plan.n_tiles)), dim3(rp::kTileBlock), 0, stream,
-                                              d_counts, (long long)n_orfs, plan, ws, rp::PiecePlan{}));
+    const bool tagged = g_measurement_tag.load(std::memory_order_relaxed) != 0;  // (rp_measurement_tag: same code, second kernel name)
+    if (gather != nullptr) {
+        if (tagged)
+            RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score_probe<true, TILE>), dim3(score_grid(plan.n_tiles)), dim3(rp::kTileBlock), 0, stream,
+                                                  d_counts, (long long)n_orfs, plan, ws, piece_plan_of(gather)));
+        else
+            RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score<true, TILE>), dim3(score_grid(plan.n_tiles)), dim3(rp::kTileBlock), 0, stream,
+                                                  d_counts, (long long)n_orfs, plan, ws, piece_plan_of(gather)));
+    } else {
+        if (tagged)
+            RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score_probe<false, TILE>), dim3(score_grid(plan.n_tiles)), dim3(rp::kTileBlock), 0, stream,
+                                                  d_counts, (long long)n_orfs, plan, ws, rp::PiecePlan{}));
+        else
+            RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_tile_score<false, TILE>), dim3(score_grid(plan.n_tiles)), dim3(rp::kTileBlock), 0, stream,
+                                                  d_counts, (long long)n_orfs, plan, ws, rp::PiecePlan{}));
+    }
     RP_HIP(hipGetLastError());
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));
     // 3. one thread per ORF: add its records, score, filter, store
@@ -1041,6 +1055,11 @@ int rp_format_double_repr(double value, char *buf) { return buf ? rpfmt::double_
 size_t rp_format_int_list(const int32_t *values, int64_t n, char *out)
 {
     return (out && (values || n <= 0)) ? rpfmt::int_list_str(values, n, out) : 0;
+}
+
+int rp_measurement_tag(int on)
+{
+    return g_measurement_tag.exchange(on ? 1 : 0, std::memory_order_relaxed);
 }
 
 size_t rp_format_wig_rows_host(const int64_t *pos, const int64_t *count, int64_t n, char *out)
