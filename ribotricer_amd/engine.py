@@ -187,9 +187,8 @@ class PhaseScoreEngine:
         section 4, profiles/r03_probe_rw_regions.txt).  HIP has no placement hint and a fresh allocation
         usually lands next to the previous one, so this allocates up to ``tries`` candidate workspaces of
         ``chunk_gib`` one after the other -- the earlier ones stay allocated meanwhile, as spacers, which
-        walks the candidates through physical memory (28 GiB of candidates cross a class boundary in about
-        half of the processes measured) -- times the scoring step of THIS batch on each, and stops early once
-        a candidate beats the slowest seen by ``spread``.  The fastest stays; the others go back to PyTorch's
+        walks the candidates through physical memory -- times the scoring step of THIS batch on each, and stops
+        once a NEW candidate beats the slowest seen by ``spread`` (or after ``tries``).  The fastest stays; the others go back to PyTorch's
         caching allocator (later tensors reuse them) or, with ``release``, to the driver
         (``torch.cuda.empty_cache()``; the driver wipes freed memory in the background, which costs the
         kernels of the next second 1-4 %).  Never slower than before (the first workspace is a candidate),
