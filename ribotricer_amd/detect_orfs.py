@@ -274,7 +274,7 @@ def export_orf_coverages(
     import time
 
     t0 = time.perf_counter()
-    index = NativeIndex.from_file(ribotricer_index)
+    index = _index_of(ribotricer_index)  # parsed once per file: detect-orfs scores one index against many samples
     if timings is not None:
         timings["index_parse"] = time.perf_counter() - t0
     if devices is None:
@@ -298,6 +298,45 @@ def export_orf_coverages(
                 output.write(chunk)
     if timings is not None:
         timings["profiles_d2h_tsv_render_write"] = time.perf_counter() - t0
+
+
+_INDEX_CACHE: dict = {}  # (real path, size, mtime_ns) -> NativeIndex; the interval table and gather plan hang on the index
+_INDEX_CACHE_MAX = 2
+
+
+def _index_of(path: str):
+    """The parsed index of ``path``, kept across calls while the file is unchanged (RIBOTRICER_AMD_INDEX_CACHE=0
+    disables it).  The reference re-reads the index for every sample (detect_orfs.py:263-278); a batch job that runs
+    many samples against one index pays the parse (0.45 s for 11 M lines), the interval table and the gather plan once."""
+    import os
+
+    from .index import NativeIndex
+
+    if os.environ.get("RIBOTRICER_AMD_INDEX_CACHE", "1") == "0":
+        return NativeIndex.from_file(path)
+    st = os.stat(path)
+    key = (os.path.realpath(path), st.st_size, st.st_mtime_ns)
+    hit = _INDEX_CACHE.pop(key, None)
+    if hit is None:
+        hit = NativeIndex.from_file(path)
+        while len(_INDEX_CACHE) >= _INDEX_CACHE_MAX:
+            _INDEX_CACHE.pop(next(iter(_INDEX_CACHE)))
+    _INDEX_CACHE[key] = hit  # most recently used last
+    return hit
+
+
+def _table_and_plan(index, base, coverage_len: int, device):
+    """(interval table, gather plan) of an index for a coverage layout, remembered on the index object: both depend on
+    the index and the layout only (the layout on the index's group extents only), not on the sample."""
+    from .gather import interval_table_from_index, make_gather_plan
+
+    key = (str(device), int(coverage_len), tuple(sorted((k, tuple(int(x) for x in v)) for k, v in base.items())))
+    cache = index.__dict__.setdefault("_layout_cache", {})
+    if key not in cache:
+        table = interval_table_from_index(index, base)
+        cache.clear()  # (one layout per index: another one replaces it)
+        cache[key] = (table, make_gather_plan(table, coverage_len, device))
+    return cache[key]
 
 
 def _profile_slices(counts, offsets, slice_nt: int = 64 << 20):
@@ -372,8 +411,7 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     t = time.perf_counter()
     coverage, base = build_coverage_device(merged_alignments, index, device)
     t = lap("coverage_build", t)
-    table = interval_table_from_index(index, base)
-    plan = make_gather_plan(table, coverage.numel(), device)
+    table, plan = _table_and_plan(index, base, coverage.numel(), device)
     t = lap("interval_table_gather_plan", t)
     sharded = devices is not None and len(devices) > 1
     if plan is None or report_all:

@@ -166,3 +166,38 @@ def test_export_sharded_over_two_slices_equals_single(tmp_path):
     assert d1[0] == d3[0]
     for a, b in zip(d1[1:], d3[1:]):  # the tile path: another slicing moves the fp32 partial sums by <= 2e-7
         assert a[:3] == b[:3] and a[4:] == b[4:] and abs(float(a[3]) - float(b[3])) <= 1e-6
+
+
+def test_index_is_parsed_once_per_file_and_reparsed_when_it_changes(tmp_path):
+    """One index, many samples: the parsed index, its interval table and its gather plan are kept across
+    export_orf_coverages calls while the file is unchanged; a rewritten file is read again; results are the same
+    either way."""
+    import shutil
+
+    from ribotricer_amd import detect_orfs as d
+
+    params = json.load(open(os.path.join(GOLDEN, "g6_params.json")))["param_sets"]["default"]
+    index_path = str(tmp_path / "index.tsv")
+    shutil.copy(os.path.join(GOLDEN, "g6_index.tsv"), index_path)
+    d._INDEX_CACHE.clear()
+    outs = []
+    for k in range(2):
+        prefix = str(tmp_path / f"out{k}")
+        d.export_orf_coverages(index_path, load_alignments(), prefix, **params)
+        outs.append(open(prefix + "_translating_ORFs.tsv", "rb").read())
+    assert outs[0] == outs[1]
+    assert len(d._INDEX_CACHE) == 1
+    first = next(iter(d._INDEX_CACHE.values()))
+    assert len(first.__dict__.get("_layout_cache", {})) == 1  # table + gather plan remembered on the index
+    # the same path with other content (one ORF fewer): parsed again, not served from the cache
+    lines = open(index_path).read().splitlines(keepends=True)
+    with open(index_path, "w") as fh:
+        fh.writelines(lines[:-1])
+    os.utime(index_path, ns=(os.stat(index_path).st_atime_ns, os.stat(index_path).st_mtime_ns + 1_000_000))
+    prefix = str(tmp_path / "out2")
+    d.export_orf_coverages(index_path, load_alignments(), prefix, report_all=True)
+    rows = open(prefix + "_translating_ORFs.tsv").read().splitlines()
+    assert len(rows) - 1 == len(lines) - 2  # header line of the index + the dropped ORF
+    assert next(reversed(d._INDEX_CACHE.values())) is not first
+    d._INDEX_CACHE.clear()
+
