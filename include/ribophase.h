@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define RP_VERSION_STRING "0.3.0"
+#define RP_VERSION_STRING "0.4.0"
 
 /* largest admissible P-site count per nucleotide (exact in fp32; codon sums stay inside
  * int32 and a lane's 45-position partial read count inside uint32) */
@@ -74,7 +74,7 @@ typedef enum rp_status {
                                   the host C library's pow() (statistics.py:83), which the device cannot
                                   restate past its host-filled table; phase / valid_codons stand on x*x
                                   there.  rp_tie_replay_host on the profile gives the reference's bits
-                                  (the Python layer does that for every such ORF: engine.resolve_ties) */
+                                  (the Python layer does that for every such ORF: engine.resolve_big_ties) */
 
 /* two frame scores count as tied when they differ by no more than RP_TIE_RTOL * (the larger
  * one) + RP_TIE_ATOL: relative, because the reference's own rounding noise is relative (~1e-15);

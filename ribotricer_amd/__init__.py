@@ -13,4 +13,17 @@ No CPU fallback: the HIP library must be built (``make -C ribotricer_amd/csrc``)
 and a GPU must be present for any compute call.
 """
 
-__version__ = "0.1.0"
+
+
+def _abi_version() -> str:
+    """ONE version string: the C ABI's (``RP_VERSION_STRING`` in include/ribophase.h, what ``rp_version()``
+    returns); read from the header so that importing the package does not need the built library."""
+    import os
+    import re
+
+    header = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ribophase.h")
+    with open(header) as fh:
+        return re.search(r'#define\s+RP_VERSION_STRING\s+"([^"]+)"', fh.read()).group(1)
+
+
+__version__ = _abi_version()

@@ -629,7 +629,7 @@ int rp_phase_score_csr_host(const int32_t *counts, const int64_t *offsets, int64
     for (int64_t i = 0; i < n_orfs; ++i)
         if (offsets[i + 1] < offsets[i]) return fail(RP_ERR_OFFSETS, "offsets must be monotone (ORF %lld)", (long long)i);
     if (offsets[n_orfs] > 0 && !counts) return fail(RP_ERR_NULL, "counts is null but offsets[n] > 0");
-    int threads = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int threads = n_threads > 0 ? n_threads : rphost::usable_threads();
     if (threads < 1) threads = 1;
     if ((int64_t)threads > n_orfs) threads = (int)n_orfs;
     auto work = [&](int64_t first, int64_t last) {

@@ -18,6 +18,8 @@
 
 #include <zlib.h>
 
+#include "rp_host.hpp"
+
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -56,8 +58,8 @@ class BgzfReader {
 public:
     explicit BgzfReader(FILE *fh) : fh_(fh)
     {
-        threads_ = (int)std::thread::hardware_concurrency();
-        threads_ = threads_ > 8 ? 8 : (threads_ < 1 ? 1 : threads_);
+        threads_ = rphost::usable_threads();
+        threads_ = threads_ > 8 ? 8 : threads_;
     }
     // read exactly n bytes of the uncompressed stream; false at a clean EOF before the first byte
     int read(void *dst, size_t n, bool *eof)

@@ -19,6 +19,8 @@
 
 #include <sys/mman.h>
 
+#include "rp_host.hpp"
+
 #include <algorithm>
 #include <cstdlib>
 #include <new>
@@ -324,8 +326,10 @@ inline int64_t count_lines(const char *text, size_t len)
 inline int parse(const char *text, size_t len, bool skip_header, Index &ix, int threads = 0)
 {
     if (threads <= 0) {
-        threads = (int)std::thread::hardware_concurrency();
-        threads = threads > 32 ? 32 : (threads < 1 ? 1 : threads);
+        // twice the usable cores: half of the parse is page faults on the output arrays, which overlap
+        // (16 usable cores: 16 threads 0.57 s, 24-32 threads 0.46-0.50 s, profiles/r03_index_parse_threads.txt)
+        threads = 2 * rphost::usable_threads();
+        threads = threads > 32 ? 32 : threads;
     }
     const size_t min_run = (size_t)4 << 20;
     if ((size_t)threads > len / min_run) threads = (int)(len / min_run);

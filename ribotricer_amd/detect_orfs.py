@@ -473,11 +473,14 @@ def export_wig(merged_alignments, prefix: str) -> None:
                 and int(count.max()) < (1 << 22):
             # (chromosome rank, position, count) packed into one 64-bit word: a plain value sort (5x faster than
             # lexsort + gathers) orders the rows, and rows of one position end up next to each other
-            packed = (rank[chrom].astype(np.int64) << 54) | (pos.astype(np.int64) << 22) | count.astype(np.int64)
+            # UNSIGNED words: ranks >= 512 reach bit 63, which a signed sort would order first (and shift back negative)
+            packed = (rank[chrom].astype(np.uint64) << np.uint64(54)) | (pos.astype(np.uint64) << np.uint64(22)) | count.astype(np.uint64)
             packed.sort()
             inv = np.empty(names.size, np.int64)
             inv[rank] = np.arange(names.size)
-            chrom, pos, count = inv[packed >> 54], (packed >> 22) & 0xFFFFFFFF, packed & 0x3FFFFF
+            chrom = inv[(packed >> np.uint64(54)).astype(np.int64)]
+            pos = ((packed >> np.uint64(22)) & np.uint64(0xFFFFFFFF)).astype(np.int64)
+            count = (packed & np.uint64(0x3FFFFF)).astype(np.int64)
         else:
             order = np.lexsort((pos, rank[chrom])) if pos.size else np.zeros(0, np.int64)
             chrom, pos, count = chrom[order], pos[order], count[order]

@@ -34,11 +34,29 @@ def _array(ptr, n, dtype):
     return np.frombuffer(buf, dtype=dtype, count=n).copy()
 
 
-def _view(ptr, n, dtype):
-    """numpy view (no copy) of n items of the library's memory at ptr -- valid while the owner lives"""
+class _Parsed:
+    """Owns one ``rp_index`` object of the library.  Every view handed out below refers to it (through the
+    ctypes buffer at the bottom of numpy's ``base`` chain), so the C++ memory lives as long as any array
+    derived from it does -- not only as long as the ``NativeIndex`` (no cycle: this object knows nobody)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                _lib.load().rp_index_free(h)
+            except Exception:  # pragma: no cover - interpreter shutdown
+                pass
+
+
+def _view(ptr, n, dtype, owner):
+    """numpy view (no copy) of n items of the library's memory at ptr; keeps ``owner`` alive"""
     if n == 0:
         return np.zeros(0, dtype)
     buf = (ctypes.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    buf._owner = owner
     a = np.frombuffer(buf, dtype=dtype, count=n)
     a.flags.writeable = False
     return a
@@ -58,12 +76,18 @@ class NativeIndex:
         lib = _lib.load()
         handle = ctypes.c_void_p()
         bad_line = ctypes.c_int64(0)
-        if isinstance(text, (bytes, bytearray)):
-            src, n_text = bytes(text), len(text)
-        else:
-            flat = np.frombuffer(text, dtype=np.uint8)
-            src, n_text = ctypes.c_void_p(flat.ctypes.data if flat.size else 0), int(flat.size)
-        rc = lib.rp_index_parse_host(src, n_text, int(skip_header), ctypes.byref(handle), ctypes.byref(bad_line))
+        flat = None
+        try:
+            if isinstance(text, (bytes, bytearray)):
+                src, n_text = bytes(text), len(text)
+            else:
+                flat = np.frombuffer(text, dtype=np.uint8)
+                src, n_text = ctypes.c_void_p(flat.ctypes.data if flat.size else 0), int(flat.size)
+            rc = lib.rp_index_parse_host(src, n_text, int(skip_header), ctypes.byref(handle), ctypes.byref(bad_line))
+        finally:
+            # the export of the caller's buffer ends HERE: an error raised below must not keep it pinned through the
+            # traceback's frame (a mapped file could then not be closed, and that error would mask this one)
+            del flat, text
         if rc == RP_ERR_INDEX_COLUMNS:  # what ORF.from_string does (orf.py:143-152)
             sys.exit(
                 "{}\n{}".format(
@@ -72,17 +96,17 @@ class NativeIndex:
                 )
             )
         _lib.check(rc)
-        self._handle = handle
+        self._parsed = own = _Parsed(handle)
         v = _View()
         _lib.check(lib.rp_index_view_host(handle, ctypes.byref(v)))
         n, m, g = v.n_orfs, v.n_intervals, v.n_groups
         self.n_orfs = int(n)
-        self.orf_iv = _view(v.orf_iv, n + 1, np.int64)
-        self.length = _view(v.length, n, np.int64)
-        self.group = _view(v.group, n, np.int32)
-        self.reverse = _view(v.reverse, n, np.uint8)
-        self.iv_start = _view(v.iv_start, m, np.int64)
-        self.iv_end = _view(v.iv_end, m, np.int64)
+        self.orf_iv = _view(v.orf_iv, n + 1, np.int64, own)
+        self.length = _view(v.length, n, np.int64, own)
+        self.group = _view(v.group, n, np.int32, own)
+        self.reverse = _view(v.reverse, n, np.uint8, own)
+        self.iv_start = _view(v.iv_start, m, np.int64, own)
+        self.iv_end = _view(v.iv_end, m, np.int64, own)
         group_off = _array(v.group_off, g + 1, np.int64)
         names = _bytes(v.group_names, int(group_off[-1]))
         self.group_keys = [
@@ -90,18 +114,10 @@ class NativeIndex:
         ]  # (strand, chrom)
         self.group_lo = _array(v.group_lo, g, np.int64)
         self.group_hi = _array(v.group_hi, g, np.int64)
-        self.head_off = _view(v.head_off, n + 1, np.int64)
-        self.tail_off = _view(v.tail_off, n + 1, np.int64)
+        self.head_off = _view(v.head_off, n + 1, np.int64, own)
+        self.tail_off = _view(v.tail_off, n + 1, np.int64, own)
         self._head_ptr, self._tail_ptr = v.head, v.tail
         self._head = self._tail = None
-
-    def __del__(self):
-        h, self._handle = getattr(self, "_handle", None), None
-        if h:
-            try:
-                _lib.load().rp_index_free(h)
-            except Exception:  # pragma: no cover - interpreter shutdown
-                pass
 
     @property
     def head(self) -> bytes:
@@ -124,8 +140,14 @@ class NativeIndex:
         with open(path, "rb") as fh:
             if os.fstat(fh.fileno()).st_size == 0:
                 return cls(b"", skip_header=True)
-            with mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+            mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+            try:  # (not `with mm`: closing a mapping that an in-flight exception still exports raises BufferError)
                 return cls(mm, skip_header=True)  # header line skipped: detect_orfs.py:273
+            finally:
+                try:
+                    mm.close()
+                except BufferError:  # pragma: no cover - the parse error on its way out is the one to report
+                    pass
 
     @property
     def tables(self):
@@ -140,7 +162,7 @@ class NativeIndex:
         for ptr, off in ((self._head_ptr, self.head_off), (self._tail_ptr, self.tail_off)):
             n = int(off[-1]) if self.n_orfs else 0
             buf = (ctypes.c_char * max(1, n)).from_address(ptr) if n else ctypes.create_string_buffer(1)
-            buf._owner = self
+            buf._owner = self._parsed
             out += [buf, off]
         return tuple(out)
 

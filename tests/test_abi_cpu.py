@@ -51,7 +51,9 @@ def test_stream_probe_is_a_separate_library_that_only_measuring_code_loads():
 
 
 def test_version_and_status_strings():
-    assert _lib.version() == "0.3.0"
+    import ribotricer_amd
+
+    assert _lib.version() == "0.4.0" == ribotricer_amd.__version__  # one version string: the header's
     lib = _lib.load()
     assert lib.rp_status_string(0) == b"ok"
     assert lib.rp_status_string(-3) == b"bad CSR offsets"

@@ -249,6 +249,46 @@ def test_native_index_line_semantics():
         assert e2.value.status == -10
 
 
+def test_native_index_errors_through_from_file(tmp_path):
+    """The same errors through the mapped-file entry point (round-3 advisor finding: closing the mapping while the
+    error's traceback still exported it raised BufferError, which replaced the reference-style exit)."""
+    from ribotricer_amd._lib import RibophaseError
+    from ribotricer_amd.index import NativeIndex
+
+    good = "id\tannotated\ttx1\tprotein_coding\tg1\tGENE\tprotein_coding\tchr1\t+\tATG\t5-9,10-12\n"
+    p = tmp_path / "few_columns.tsv"
+    p.write_text("header\n" + good + "a\tb\tc\n")
+    with pytest.raises(SystemExit) as e:  # orf.py:143-152
+        NativeIndex.from_file(str(p))
+    assert "unexpected number of columns" in str(e.value) and "prepare-orfs" in str(e.value)
+    p = tmp_path / "bad_interval.tsv"
+    p.write_text("header\n" + good.replace("5-9,10-12", "5-9-12"))
+    with pytest.raises(RibophaseError) as e2:
+        NativeIndex.from_file(str(p))
+    assert e2.value.status == -10
+    p = tmp_path / "empty.tsv"
+    p.write_text("")
+    assert NativeIndex.from_file(str(p)).n_orfs == 0
+
+
+def test_native_index_views_keep_the_parsed_object_alive():
+    """The arrays are zero-copy views of C++ memory: an array (or a view derived from one) that outlives the
+    NativeIndex -- e.g. after the eviction from detect_orfs._INDEX_CACHE -- must keep that memory."""
+    import gc
+
+    from ribotricer_amd.index import NativeIndex
+
+    lines = "".join(f"id\tannotated\ttx{k}\tpc\tg\tG\tpc\tchr1\t+\tATG\t{10 * k + 1}-{10 * k + 9}\n" for k in range(5000))
+    ni = NativeIndex(("header\n" + lines).encode())
+    starts, derived, tables = ni.iv_start, ni.iv_end[10:20], ni.tables_native
+    want = np.arange(5000) * 10 + 1
+    del ni
+    gc.collect()
+    _ = [NativeIndex(("header\n" + lines.replace("chr1", "chr2")).encode()) for _ in range(3)]  # (would reuse freed memory)
+    assert np.array_equal(starts, want) and np.array_equal(derived, want[10:20] + 8)
+    assert bytes(tables[0][:13]) == b"tx0_1_9_9\tann"
+
+
 @pytest.mark.parametrize("threads", [2, 5])
 def test_native_rows_threaded_equal_serial(packed, threads):
     from ribotricer_amd import tsv
