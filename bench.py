@@ -20,6 +20,13 @@ the plan rebuilt inside every step (an index used for ONE sample).
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W      (no launcher: bench.py starts its own N ranks)
+
+Without a launcher (WORLD_SIZE unset) and N > 1 this process never touches the GPU: it starts the N ranks
+as fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), relays
+rank 0's JSON line and exits with the ranks' status (`self_launch`).  When the node shows fewer GPUs than
+ranks (the one-GPU test box), the ranks share GPUs round-robin, the control traffic runs over gloo, and the
+line says so (`config.ranks_share_gpus`): a self-test of the N-rank control flow, not a scaling measurement.
 
 Once per index and outside the timed region, like the plan build: `engine.tune_workspace` tries a few
 placements of the record workspace and keeps the fastest (on MI355X a write stream costs a read stream
@@ -273,13 +280,107 @@ def fused_section(args, eng, dev, thresholds, n_set, csr_out):
     return rep
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as FRESH child processes
+    -- this parent has not imported torch and never touches the GPU (a process that has initialised the GPU must not
+    exec another program on this pool; children started before any HIP call are fine) -- one rank per GPU, rendezvous
+    on 127.0.0.1.  Rank 0's stdout (the one JSON line) is relayed to ours, the other ranks' output goes to stderr;
+    returns rank 0's exit status, or the first non-zero status of another rank.  A rank that dies takes the others
+    down (exact PIDs, after a grace period) instead of leaving them at a barrier for ever."""
+    import socket
+    import subprocess
+    import threading
+
+    n = args.gpus
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    base_env = dict(os.environ)
+    base_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+    base_env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                    RP_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(base_env, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, cwd=os.getcwd()))
+
+    def relay(proc, rank):
+        for line in proc.stdout:
+            if rank == 0:
+                sys.stdout.write(line)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(f"[rank {rank}] {line}")
+
+    threads = [threading.Thread(target=relay, args=(p, r), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    status = [None] * n
+    failed_at = None
+    while any(s is None for s in status):
+        for r, p in enumerate(procs):
+            if status[r] is None:
+                status[r] = p.poll()
+                if status[r] not in (None, 0) and failed_at is None:
+                    failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > 20.0:
+            for r, p in enumerate(procs):  # the others are parked at a barrier the dead rank will never reach
+                if status[r] is None:
+                    p.kill()
+        time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=5.0)
+    if status[0] != 0:
+        return status[0] if status[0] > 0 else 1
+    bad = [s for s in status if s != 0]
+    return (bad[0] if bad[0] > 0 else 1) if bad else 0
+
+
+def launch_only(rank: int, world: int) -> None:
+    """RP_BENCH_LAUNCH_ONLY=1 (tests/test_sharding_cpu.py, no GPU): the rendezvous, the barrier, the max-over-ranks
+    and the per-rank gather of the real run over gloo, with the slices of the real index -- everything of the N-rank
+    control flow except the device work."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from ribotricer_amd.sharding import slice_bounds
+    from ribotricer_amd.synth import offsets_from_lengths, orf_lengths
+
+    args = parse_args()
+    dist.init_process_group(backend="gloo")
+    n_set = args.orfs if args.orfs > 0 else DEFAULT_ORFS[args.cfg]
+    offsets_set = offsets_from_lengths(orf_lengths(n_set, args.seed, args.cfg))
+    bounds = slice_bounds(offsets_set, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ranks = [None] * world
+    dist.all_gather_object(ranks, {"rank": rank, "orfs": hi - lo, "nt": int(offsets_set[hi] - offsets_set[lo]),
+                                   "local_rank": int(os.environ.get("LOCAL_RANK", "-1")), "pid": os.getpid()})
+    if rank == 0:
+        print(json.dumps({"launch_only": True, "n_gpus": world, "max_over_ranks": float(t.item()), "per_rank": ranks,
+                          "orfs_total": n_set, "nt_total": int(offsets_set[-1]),
+                          "self_launched": os.environ.get("RP_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if os.environ.get("RP_BENCH_LAUNCH_ONLY_FAIL_RANK") == str(rank):  # (the launcher's status relay, under test)
+        sys.exit(7)
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus and rank == 0:  # the launcher's world size is what runs
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; running {world} ranks", file=sys.stderr)
+    if os.environ.get("RP_BENCH_LAUNCH_ONLY") == "1":
+        return launch_only(rank, world)
 
     # CPU-baseline workers first: they must exist before this process initialises the GPU
     pool = None
@@ -299,17 +400,28 @@ def main():
     dev = torch.device("cuda", local_dev)
     dist = None
     backend = None
-    if world > 1:
+    side = None  # gloo group for everything that is not the timed region's barrier / max: objects and result hand-over
+    if world > 1 or os.environ.get("RP_BENCH_FORCE_DIST") == "1":
+        import datetime
+
         import torch.distributed as dist
 
-        # RCCL ("nccl") carries only the barrier, the max-over-ranks of the elapsed time and, after
-        # the timed region, the result hand-over for the concat == whole check;
-        # RP_BENCH_BACKEND=gloo lets the same control flow be exercised with ranks sharing a GPU
-        backend = os.environ.get("RP_BENCH_BACKEND", "nccl")
+        # RCCL ("nccl") carries the barriers around the timed region and the max-over-ranks of the elapsed time --
+        # there is no collective on the data path.  Fewer GPUs than ranks (the one-GPU test box): ranks share GPUs
+        # round-robin, and two ranks on one device cannot form an RCCL communicator -> gloo (the line says so:
+        # config.ranks_share_gpus); RP_BENCH_BACKEND overrides.  Per-rank reports and the results handed to rank 0
+        # for the concat == whole check (after the timed region) travel as host tensors over a gloo side group.
+        backend = os.environ.get("RP_BENCH_BACKEND", "nccl" if n_dev >= world else "gloo")
+        if world == 1:  # RP_BENCH_FORCE_DIST: the N-rank control flow with one rank (RCCL init / barrier / all_reduce on one GPU)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(minutes=10))
+            side = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=30))
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=datetime.timedelta(minutes=30))
 
     from ribotricer_amd import _lib
     from ribotricer_amd.engine import PhaseScoreEngine, make_filter
@@ -405,19 +517,21 @@ def main():
         single_ms = e0.elapsed_time(e1) / n_single
         out = step()  # (the outputs checked below come from the planned path the headline times)
         torch.cuda.synchronize(dev)
-    per_rank = {"rank": rank, "orfs": n_orfs, "nt": total_nt, "kernel_ms": k_main, "finish_ms": k_fin,
-                "step_device_ms": dev_ms_per_step}
+    rank_bytes = 4 * total_nt + 8 * (n_orfs + 1) + 24 * n_orfs  # SURVEY 8(d), this rank's slice
+    per_rank = {"rank": rank, "device": local_dev, "orfs": n_orfs, "nt": total_nt, "kernel_ms": k_main, "finish_ms": k_fin,
+                "step_device_ms": dev_ms_per_step, "algorithmic_bytes_per_launch": rank_bytes,
+                "achieved": rank_bytes / (k_main * 1e-3) / 1e9 if k_main > 0 else 0.0,
+                "frac": rank_bytes / (k_main * 1e-3) / 1e9 / HBM_PEAK_GBS if k_main > 0 else 0.0}
     ranks = [per_rank]
     if dist is not None:
         ranks = [None] * world
-        dist.all_gather_object(ranks, per_rank)
+        dist.all_gather_object(ranks, per_rank, group=side)
 
     # ---- N > 1: the concatenation of the ranks' results must equal the one-GPU result ----------
     verify = None
     if dist is not None and strong and not args.no_verify:
         keys = ("phase", "valid", "read_count", "min_codon_cov", "flags", "status")
         mine = {k: getattr(out, k) for k in keys}
-        to_wire = (lambda x: x) if backend == "nccl" else (lambda x: x.cpu())
         if rank == 0:
             counts_all, offsets_all = synth_csr_device(n_set, seed=args.seed, cfg=args.cfg, device=dev)
             whole = eng.score(counts_all, offsets_all, thresholds=thresholds, algo=algo, plan=None)
@@ -431,8 +545,8 @@ def main():
                     if r == 0:
                         got = mine[k]
                     else:
-                        got = torch.empty(b - a, dtype=ref.dtype, device=dev if backend == "nccl" else "cpu")
-                        dist.recv(got, src=r)
+                        got = torch.empty(b - a, dtype=ref.dtype, device="cpu")
+                        dist.recv(got, src=r, group=side)
                         got = got.to(dev)
                     if k == "phase":
                         d = float((got - ref).abs().max()) if b > a else 0.0
@@ -446,7 +560,7 @@ def main():
             del counts_all, offsets_all, whole
         else:
             for k in keys:
-                dist.send(to_wire(mine[k].contiguous()), dst=0)
+                dist.send(mine[k].contiguous().cpu(), dst=0, group=side)
         barrier()
         if rank == 0 and not verify["ok"]:
             print(json.dumps({"error": "sharded results differ from the one-GPU result", "verify": verify}), flush=True)
@@ -455,7 +569,10 @@ def main():
     fused = None
     if rank == 0 and world == 1:
         if not args.no_verify and n_orfs > 0:
+            concat_check = verify  # (RP_BENCH_FORCE_DIST: the N-rank check ran with one rank)
             verify = verify_slices(out, counts, offsets, n_orfs)
+            if concat_check is not None:
+                verify["concat_equals_whole"] = concat_check
             verify["read_count_checksum_ok"] = bool(int(out.read_count.sum()) == int(counts.sum(dtype=torch.int64)))
             verify["ok"] = verify["ok"] and verify["read_count_checksum_ok"]
         if not args.no_fused and resolved == "tile" and n_orfs > 0:
@@ -495,8 +612,13 @@ def main():
             stream_read = None
 
     if rank == 0:
-        algo_bytes = 4 * total_nt + 8 * (n_orfs + 1) + 24 * n_orfs
+        # N > 1: the roofline block is the SLOWEST rank's kernel (the one the max-over-ranks time follows), per launch
+        # and per GPU like at N = 1; `node_achieved` = all ranks' bytes over that slowest kernel's time
+        slow = max(ranks, key=lambda r: r["kernel_ms"])
+        algo_bytes = slow["algorithmic_bytes_per_launch"]
+        k_main, k_fin, dev_ms_per_step = slow["kernel_ms"], slow["finish_ms"], slow["step_device_ms"]
         achieved = algo_bytes / (k_main * 1e-3) / 1e9
+        node_bytes = sum(r["algorithmic_bytes_per_launch"] for r in ranks)
         traffic, traffic_src = (measured_traffic(args.cfg, n_orfs, resolved, args.seed) if world == 1 else (None, None))
         flags = out.flags
         nt_set = int(offsets_set[-1]) if strong else total_nt * world
@@ -529,6 +651,11 @@ def main():
                 "workspace_placement": placement if placement is not None else "first allocation (engine.tune_workspace not run)",
                 "sharding": "nt-balanced contiguous ORF-index slices of one set, host-side concat, no collective on the data path"
                 if strong else "independent per-GPU sets (weak scaling)",
+                "physical_gpus": n_dev,
+                "ranks_share_gpus": world > n_dev,
+                "launcher": "bench.py self_launch" if os.environ.get("RP_BENCH_SELF_LAUNCHED") == "1" else
+                            ("external (torch.distributed.run)" if world > 1 else "none"),
+                "control_backend": backend,
             },
             "roofline": {
                 "bound": "hbm",
@@ -539,6 +666,9 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "kernel": "rp::k_tile_score" if resolved == "tile" else "rp::k_wave_score",
+                "rank": slow["rank"],
+                "node_achieved": node_bytes / (k_main * 1e-3) / 1e9,
+                "node_peak": HBM_PEAK_GBS * min(world, n_dev),
                 "kernel_ms": k_main,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "step_device_ms": dev_ms_per_step,

@@ -174,18 +174,19 @@ def _devices_from_env():
 
 
 def score_profiles(counts, offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
-                   min_valid_codons_ratio, min_density_over_orf, device=None, devices=None) -> dict:
+                   min_valid_codons_ratio, min_density_over_orf, device=None, devices=None, shards=None) -> dict:
     """One launch for the whole batch; host numpy arrays back (24 B + 2 B per ORF).  With
     ``devices`` (several GPUs of this node): nt-balanced ORF-index slices, one per GPU, host
     concat (``engine.score_sharded``).  Exact frame ties carry the reference's bits throughout
-    (``engine.resolve_big_ties`` finishes the few the device cannot)."""
+    (``engine.resolve_big_ties`` finishes the few the device cannot).  ``shards``: the caller's
+    ``engine.CsrShards`` of this index and these devices (per-device plans kept across samples)."""
     thresholds = make_filter(
         phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio, min_density_over_orf
     )
     if devices is not None and len(devices) > 1:
         from .engine import score_sharded
 
-        return score_sharded(counts, offsets, devices, thresholds=thresholds)
+        return score_sharded(counts, offsets, devices, thresholds=thresholds, shards=shards)
     eng = get_engine(device if devices is None or not len(devices) else devices[0])
     return eng.score_host(counts, offsets, thresholds=thresholds)
 
@@ -326,17 +327,30 @@ def _index_of(path: str):
 
 
 def _table_and_plan(index, base, coverage_len: int, device):
-    """(interval table, gather plan) of an index for a coverage layout, remembered on the index object: both depend on
-    the index and the layout only (the layout on the index's group extents only), not on the sample."""
+    """(interval table, gather plan, per-layout extras) of an index for a coverage layout, remembered on the index
+    object: all depend on the index and the layout only (the layout on the index's group extents only), not on the
+    sample.  ``extras`` is a dict that lives and dies with the layout: the multi-GPU shards (``engine.CsrShards`` /
+    ``engine.CoverageShards``: per-device windows, gather plans, tile plans) are kept there."""
     from .gather import interval_table_from_index, make_gather_plan
 
-    key = (str(device), int(coverage_len), tuple(sorted((k, tuple(int(x) for x in v)) for k, v in base.items())))
+    key = (str(get_engine(device).device), int(coverage_len), tuple(sorted((k, tuple(int(x) for x in v)) for k, v in base.items())))
     cache = index.__dict__.setdefault("_layout_cache", {})
     if key not in cache:
         table = interval_table_from_index(index, base)
+        for old in cache.values():
+            for shards in old[2].values():
+                shards.release()
         cache.clear()  # (one layout per index: another one replaces it)
-        cache[key] = (table, make_gather_plan(table, coverage_len, device))
+        cache[key] = (table, make_gather_plan(table, coverage_len, device), {})
     return cache[key]
+
+
+def _shards(extras: dict, kind: str, devices, build):
+    """The layout's shards of ``kind`` for ``devices`` (made once per index, layout and device list)."""
+    key = (kind, tuple(int(d) if isinstance(d, int) else str(d) for d in devices))
+    if key not in extras:
+        extras[key] = build()
+    return extras[key]
 
 
 def _profile_slices(counts, offsets, slice_nt: int = 64 << 20):
@@ -411,14 +425,19 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     t = time.perf_counter()
     coverage, base = build_coverage_device(merged_alignments, index, device)
     t = lap("coverage_build", t)
-    table, plan = _table_and_plan(index, base, coverage.numel(), device)
+    table, plan, extras = _table_and_plan(index, base, coverage.numel(), device)
     t = lap("interval_table_gather_plan", t)
     sharded = devices is not None and len(devices) > 1
     if plan is None or report_all:
         d_counts, d_offsets = gather_profiles_device(coverage, table, device, plan=plan)
+        shards = None
+        if sharded:  # per-device offsets, tile plans, workspaces: once per index, not per sample
+            from .engine import CsrShards
+
+            shards = _shards(extras, "csr", devices, lambda: CsrShards(table.offsets, devices))
         res = score_profiles(
             d_counts, d_offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
-            min_valid_codons_ratio, min_density_over_orf, device=device, devices=devices,
+            min_valid_codons_ratio, min_density_over_orf, device=device, devices=devices, shards=shards,
         )
         t = lap("gather_score_results_d2h", t)
         if profiles_on_device:  # (the caller streams them back slice by slice: _profile_slices)
@@ -430,10 +449,10 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
         phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio, min_density_over_orf
     )
     if sharded:
-        from .engine import score_coverage_sharded
+        from .engine import CoverageShards
 
-        del plan
-        res = score_coverage_sharded(coverage, table, devices, thresholds=thresholds)
+        del plan  # per-device windows, gather plans and tile plans: once per index, not per sample
+        res = _shards(extras, "coverage", devices, lambda: CoverageShards(table, devices, coverage.numel())).score(coverage, thresholds)
     else:
         eng = get_engine(device)
         res = eng.score_coverage(coverage, plan, thresholds=thresholds)

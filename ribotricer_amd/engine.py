@@ -352,6 +352,7 @@ class PhaseScoreEngine:
         thresholds: Optional[FilterParams] = None,
         reuse_outputs: bool = False,
         timings: Optional[list] = None,
+        tile_plan: Optional[TilePlan] = None,
     ) -> PhaseScores:
         """Fused gather + score (``rp_phase_score_coverage_dev``): every ORF of the index behind
         ``gather_plan`` (:class:`ribotricer_amd.gather.GatherPlan`) scored straight from the dense
@@ -363,7 +364,9 @@ class PhaseScoreEngine:
         coverage = _as_device(coverage, torch.int32, dev)
         offsets = gather_plan.offsets
         n, total_nt = gather_plan.n_orfs, gather_plan.total_nt
-        plan = self.plan_for(offsets, total_nt, 0) if n > 0 else None
+        plan = (tile_plan if tile_plan is not None else self.plan_for(offsets, total_nt, 0)) if n > 0 else None
+        if plan is not None and not plan.matches(offsets, total_nt, 0):
+            raise ValueError("tile plan belongs to another index")
         stream_obj = torch.cuda.current_stream(dev)
         stream_key = int(stream_obj.cuda_stream)
         ws = self._get_workspace(_lib.workspace_bytes(n, total_nt, _lib.RP_ALGO_TILE), stream_key)
@@ -533,7 +536,101 @@ def get_engine(device=None) -> PhaseScoreEngine:
         return _engines[dev]
 
 
-def score_sharded(counts, offsets, devices: Sequence, thresholds: Optional[FilterParams] = None, algo: str = "auto") -> dict:
+def _devices(devices) -> list:
+    devs = [torch.device(d) if not isinstance(d, int) else torch.device("cuda", d) for d in devices]
+    if not devs:
+        raise ValueError("sharded scoring needs at least one device")
+    return devs
+
+
+def _run_slices(work, n: int) -> list:
+    if n == 1:
+        return [work(0)]
+    with ThreadPoolExecutor(max_workers=n) as pool:
+        return list(pool.map(work, range(n)))
+
+
+class CsrShards:
+    """One candidate-ORF index (CSR ``offsets``) cut over several GPUs of this node, kept for every sample scored
+    against it: the nt-balanced slice bounds (``sharding.slice_bounds``), and per slice a stream and the re-based
+    offsets on the slice's device -- the tile plan hangs on that tensor in the device engine's plan cache
+    (:meth:`PhaseScoreEngine.plan_for`), the record workspace and the reusable outputs on the stream.  The second
+    sample therefore skips the offsets upload, the index pass and every allocation, as the one-GPU path does
+    (detect_orfs._table_and_plan).  A device may appear more than once (two slices on one GPU, on two streams)."""
+
+    def __init__(self, offsets, devices: Sequence):
+        from .sharding import slice_bounds
+
+        self.devices = _devices(devices)
+        off = offsets.cpu().numpy() if isinstance(offsets, torch.Tensor) else np.ascontiguousarray(offsets, dtype=np.int64)
+        if off.size < 1 or int(off[0]) != 0:
+            raise RibophaseError(-3, "offsets must start at 0")
+        self.offsets = off
+        self.total_nt = int(off[-1])
+        self.bounds = slice_bounds(off, len(self.devices))
+        self._slices: list = [None] * len(self.devices)  # (stream, device offsets, tile plans), made by the slice's own thread
+        self.plans_built = 0  # (diagnostics / tests: tile plans built so far, all slices)
+
+    def matches(self, offsets, devices) -> bool:
+        off = offsets.cpu().numpy() if isinstance(offsets, torch.Tensor) else np.asarray(offsets)
+        return _devices(devices) == self.devices and off.shape == self.offsets.shape and np.array_equal(off, self.offsets)
+
+    def _slice(self, k: int):
+        if self._slices[k] is None:
+            dev = self.devices[k]
+            lo, hi = int(self.bounds[k]), int(self.bounds[k + 1])
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                o = torch.from_numpy(self.offsets[lo : hi + 1] - self.offsets[lo]).to(dev, non_blocking=True)
+            self._slices[k] = (stream, o, {})  # {counts phase: TilePlan}
+        return self._slices[k]
+
+    def score(self, counts, thresholds: Optional[FilterParams] = None, algo: str = "auto") -> dict:
+        """Host numpy arrays, in ORF order, for one sample's ``counts`` (host array or a tensor on any device)."""
+        from .sharding import concat_results
+
+        n_counts = counts.numel() if isinstance(counts, torch.Tensor) else int(np.asarray(counts).size)
+        if n_counts != self.total_nt:
+            raise RibophaseError(-3, "offsets must run from 0 to len(counts)")
+        off_host = self.offsets
+
+        def work(k: int) -> dict:
+            dev = self.devices[k]
+            lo, hi = int(self.bounds[k]), int(self.bounds[k + 1])
+            a, b = int(off_host[lo]), int(off_host[hi])
+            eng = get_engine(dev)
+            with torch.cuda.device(dev):
+                stream, o, plans = self._slice(k)
+                _wait_for_producers(stream, counts)
+                with torch.cuda.stream(stream):
+                    c = counts[a:b]
+                    c = torch.from_numpy(np.ascontiguousarray(c, dtype=np.int32)) if not isinstance(c, torch.Tensor) else c
+                    c = c.to(dev, non_blocking=True)
+                    plan = "auto"
+                    if algo == "tile" or (algo == "auto" and c.numel() >= AUTO_WAVE_NT):  # the tile path: this slice's plan, kept HERE
+                        phase = (c.data_ptr() // 4) % 4 if c.numel() else 0  # (an engine's own cache holds 4 plans)
+                        if phase not in plans and hi > lo:
+                            plans[phase] = TilePlan(dev, o, c.numel(), phase, ctypes.c_void_p(stream.cuda_stream))
+                            self.plans_built += 1
+                        plan = plans.get(phase)
+                    res = eng.score(c, o, thresholds=thresholds, algo=algo, reuse_outputs=True, plan=plan)
+                    host = {k_: (None if v is None else v.cpu()) for k_, v in res._asdict().items()}
+                stream.synchronize()
+            out = {k_: (None if v is None else v.numpy()) for k_, v in host.items()}
+            resolve_big_ties(out, csr_profiles_of(c, o), thresholds)
+            return out
+
+        return concat_results(_run_slices(work, len(self.devices)))
+
+    def release(self) -> None:
+        for k, sl in enumerate(self._slices):
+            if sl is not None:
+                get_engine(self.devices[k]).release_stream(sl[0])
+        self._slices = [None] * len(self.devices)
+
+
+def score_sharded(counts, offsets, devices: Sequence, thresholds: Optional[FilterParams] = None, algo: str = "auto",
+                  shards: Optional[CsrShards] = None) -> dict:
     """Score one CSR batch on several GPUs of this node: host numpy arrays back, in ORF order.
 
     The batch is cut into ``len(devices)`` contiguous ORF-index slices balanced on
@@ -543,95 +640,110 @@ def score_sharded(counts, offsets, devices: Sequence, thresholds: Optional[Filte
     (ctypes releases the GIL for the duration of the library call), and the per-ORF results
     are concatenated on the host.  No collective, no peer traffic besides the slice copies.
     A device may appear more than once (two slices on one GPU, on two streams).
+
+    ``shards``: a :class:`CsrShards` of the same offsets and devices, kept by a caller that scores many samples
+    against one index (per-device offsets, tile plans, workspaces and outputs are then reused); without it the
+    per-device state lives for this call only.
     """
-    from .sharding import concat_results, slice_bounds
-
-    devs = [torch.device(d) if not isinstance(d, int) else torch.device("cuda", d) for d in devices]
-    if not devs:
-        raise ValueError("score_sharded needs at least one device")
-    off_host = offsets.cpu().numpy() if isinstance(offsets, torch.Tensor) else np.ascontiguousarray(offsets, dtype=np.int64)
-    n_total = int(off_host[-1]) if off_host.size else 0
-    n_counts = counts.numel() if isinstance(counts, torch.Tensor) else int(np.asarray(counts).size)
-    if off_host.size < 1 or int(off_host[0]) != 0 or n_total != n_counts:
-        raise RibophaseError(-3, "offsets must run from 0 to len(counts)")
-    bounds = slice_bounds(off_host, len(devs))
-
-    def work(k: int) -> dict:
-        dev = devs[k]
-        lo, hi = int(bounds[k]), int(bounds[k + 1])
-        a, b = int(off_host[lo]), int(off_host[hi])
-        eng = get_engine(dev)
-        with torch.cuda.device(dev):
-            stream = torch.cuda.Stream(device=dev)
-            _wait_for_producers(stream, counts, offsets)
-            with torch.cuda.stream(stream):
-                c = counts[a:b]
-                c = torch.from_numpy(np.ascontiguousarray(c, dtype=np.int32)) if not isinstance(c, torch.Tensor) else c
-                c = c.to(dev, non_blocking=True)
-                o = torch.from_numpy(off_host[lo : hi + 1] - off_host[lo]).to(dev, non_blocking=True)
-                res = eng.score(c, o, thresholds=thresholds, algo=algo, plan=None)
-                host = {k_: (None if v is None else v.cpu()) for k_, v in res._asdict().items()}
-            stream.synchronize()
-            eng.release_stream(stream)
-        out = {k_: (None if v is None else v.numpy()) for k_, v in host.items()}
-        resolve_big_ties(out, csr_profiles_of(c, o), thresholds)
-        return out
-
-    if len(devs) == 1:
-        parts = [work(0)]
-    else:
-        with ThreadPoolExecutor(max_workers=len(devs)) as pool:
-            parts = list(pool.map(work, range(len(devs))))
-    return concat_results(parts)
+    if shards is not None:
+        return shards.score(counts, thresholds=thresholds, algo=algo)
+    once = CsrShards(offsets, devices)
+    try:
+        return once.score(counts, thresholds=thresholds, algo=algo)
+    finally:
+        once.release()
 
 
-def score_coverage_sharded(coverage, table, devices: Sequence, thresholds: Optional[FilterParams] = None) -> dict:
+class CoverageShards:
+    """One interval table (``gather.IntervalTable``: candidate-ORF index + coverage layout) cut over several GPUs
+    for the fused gather + score, kept for every sample: per slice the nt-balanced ORF range, the WINDOWS of the
+    dense coverage its exons touch (``sharding.coverage_windows``: on a human-sized index an eighth of the 25 GB
+    array per GPU of eight, not a full copy each), the slice's table re-based onto them and -- built by the first
+    sample, on the slice's own thread and stream -- its gather plan and tile plan on the device.  A later sample
+    uploads its windows and launches; nothing is planned again (the one-GPU path: detect_orfs._table_and_plan)."""
+
+    def __init__(self, table, devices: Sequence, coverage_len: int):
+        from .gather import IntervalTable, select_orfs
+        from .sharding import coverage_windows, remap_to_windows, slice_bounds
+
+        self.devices = _devices(devices)
+        self.coverage_len = int(coverage_len)
+        self.n_orfs = int(len(table.offsets) - 1)
+        self.bounds = slice_bounds(np.asarray(table.offsets, np.int64), len(self.devices))
+        self.parts: list = []
+        for k in range(len(self.devices)):
+            lo, hi = int(self.bounds[k]), int(self.bounds[k + 1])
+            sub = select_orfs(table, np.arange(lo, hi, dtype=np.int64))
+            windows = None
+            if len(self.devices) > 1:  # only what this slice reads crosses to the device
+                w_start, w_len, w_base, w_total = coverage_windows(sub.iv_start, sub.iv_len)
+                windows = (w_start, w_len, w_base, max(w_total, 16))
+                sub = IntervalTable(remap_to_windows(sub.iv_start, w_start, w_base), sub.iv_len, sub.orf_iv, sub.reverse, sub.offsets)
+            self.parts.append({"table": sub, "windows": windows, "plan": None, "tile_plan": None, "stream": None})
+        self.plans_built = 0
+
+    def score(self, coverage, thresholds: Optional[FilterParams] = None) -> dict:
+        from .gather import GatherPlan, coverage_profiles_of
+        from .sharding import compact_coverage, concat_results
+
+        n_cov = coverage.numel() if isinstance(coverage, torch.Tensor) else int(np.asarray(coverage).size)
+        if n_cov != self.coverage_len:
+            raise ValueError(f"coverage has {n_cov} positions, the shards were laid out for {self.coverage_len}")
+
+        def work(k: int) -> dict:
+            dev = self.devices[k]
+            part = self.parts[k]
+            eng = get_engine(dev)
+            with torch.cuda.device(dev):
+                if part["stream"] is None:
+                    part["stream"] = torch.cuda.Stream(device=dev)
+                stream = part["stream"]
+                _wait_for_producers(stream, coverage)
+                with torch.cuda.stream(stream):
+                    if part["windows"] is not None:
+                        cov = compact_coverage(coverage, *part["windows"], dev)
+                    else:
+                        cov = _as_device(coverage, torch.int32, dev)
+                    if part["plan"] is None:
+                        part["plan"] = gp = GatherPlan(part["table"], cov.numel(), dev)
+                        part["tile_plan"] = TilePlan(dev, gp.offsets, gp.total_nt, 0, ctypes.c_void_p(stream.cuda_stream)) if gp.n_orfs else None
+                        self.plans_built += 1
+                    res = eng.score_coverage(cov, part["plan"], thresholds=thresholds, reuse_outputs=True, tile_plan=part["tile_plan"])
+                    host = {k_: (None if v is None else v.cpu()) for k_, v in res._asdict().items()}
+                stream.synchronize()
+                out = {k_: (None if v is None else v.numpy()) for k_, v in host.items()}
+                with torch.cuda.stream(stream):
+                    resolve_big_ties(out, coverage_profiles_of(cov, part["table"], dev), thresholds)
+                stream.synchronize()
+            return out
+
+        return concat_results(_run_slices(work, len(self.devices)))
+
+    def release(self) -> None:
+        for k, part in enumerate(self.parts):
+            if part["stream"] is not None:
+                get_engine(self.devices[k]).release_stream(part["stream"])
+            part["plan"] = part["tile_plan"] = part["stream"] = None
+
+
+def score_coverage_sharded(coverage, table, devices: Sequence, thresholds: Optional[FilterParams] = None,
+                           shards: Optional[CoverageShards] = None) -> dict:
     """The fused gather + score (:meth:`PhaseScoreEngine.score_coverage`) on several GPUs of this
     node: ``table`` (``gather.IntervalTable``) is cut into nt-balanced contiguous ORF-index slices,
     every device gets the WINDOWS of the dense coverage that its slice's exons touch
-    (``sharding.coverage_windows``: on a human-sized index an eighth of the 25 GB array per GPU of
-    eight, not a full copy each) and the gather plan of its slice re-based onto them; the uploads of
+    (``sharding.coverage_windows``) and the gather plan of its slice re-based onto them; the uploads of
     the devices run side by side (one thread and one stream per device), results are concatenated on
     the host.  No collective; the profiles exist on no device.  Raises ``RibophaseError`` (status
-    ``ERR_INTERVALS``) for a table that cannot be planned."""
-    from .gather import GatherPlan, IntervalTable, coverage_profiles_of, select_orfs
-    from .sharding import compact_coverage, concat_results, coverage_windows, remap_to_windows, slice_bounds
-
-    devs = [torch.device(d) if not isinstance(d, int) else torch.device("cuda", d) for d in devices]
-    if not devs:
-        raise ValueError("score_coverage_sharded needs at least one device")
-    bounds = slice_bounds(np.asarray(table.offsets, np.int64), len(devs))
-
-    def work(k: int) -> dict:
-        dev = devs[k]
-        lo, hi = int(bounds[k]), int(bounds[k + 1])
-        eng = get_engine(dev)
-        with torch.cuda.device(dev):
-            stream = torch.cuda.Stream(device=dev)
-            _wait_for_producers(stream, coverage)
-            with torch.cuda.stream(stream):
-                sub = select_orfs(table, np.arange(lo, hi, dtype=np.int64))
-                if len(devs) > 1:  # only what this slice reads crosses to the device
-                    w_start, w_len, w_base, w_total = coverage_windows(sub.iv_start, sub.iv_len)
-                    cov = compact_coverage(coverage, w_start, w_len, w_base, max(w_total, 16), dev)
-                    sub = IntervalTable(remap_to_windows(sub.iv_start, w_start, w_base), sub.iv_len, sub.orf_iv, sub.reverse, sub.offsets)
-                else:
-                    cov = _as_device(coverage, torch.int32, dev)
-                plan = GatherPlan(sub, cov.numel(), dev)
-                res = eng.score_coverage(cov, plan, thresholds=thresholds)
-                host = {k_: (None if v is None else v.cpu()) for k_, v in res._asdict().items()}
-            stream.synchronize()
-            out = {k_: (None if v is None else v.numpy()) for k_, v in host.items()}
-            resolve_big_ties(out, coverage_profiles_of(cov, sub, dev), thresholds)
-            eng.release_stream(stream)
-        return out
-
-    if len(devs) == 1:
-        parts = [work(0)]
-    else:
-        with ThreadPoolExecutor(max_workers=len(devs)) as pool:
-            parts = list(pool.map(work, range(len(devs))))
-    return concat_results(parts)
+    ``ERR_INTERVALS``) for a table that cannot be planned.  ``shards``: a :class:`CoverageShards` kept by the
+    caller across samples (windows, gather plans and tile plans are then built once per index)."""
+    if shards is not None:
+        return shards.score(coverage, thresholds=thresholds)
+    n_cov = coverage.numel() if isinstance(coverage, torch.Tensor) else int(np.asarray(coverage).size)
+    once = CoverageShards(table, devices, n_cov)
+    try:
+        return once.score(coverage, thresholds=thresholds)
+    finally:
+        once.release()
 
 
 def phase_score_csr(counts, offsets, thresholds: Optional[FilterParams] = None, algo: str = "auto", device=None) -> PhaseScores:

@@ -72,3 +72,57 @@ def test_two_ranks_shard_one_set_and_concat_equals_whole():
     nts = [r["nt"] for r in d["per_rank"]]
     assert abs(nts[0] - nts[1]) <= 0.02 * sum(nts)  # nt-balanced
     assert "configs[3]" in d["config"]["workload"] and "cpu_baseline" not in d
+
+
+def _bare_bench(n, orfs, extra=(), env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    out = subprocess.run(
+        [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n), "--orfs", str(orfs), "--steps", "3", "--warmup", "1", *extra],
+        capture_output=True, text=True, timeout=1500, cwd=REPO, env=env,
+    )
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_bare_command_runs_n_ranks(n):
+    """`python bench.py --gpus N` with NO launcher (the shape of the driver's N = 1 command): bench.py starts its
+    own N ranks before touching the GPU; on this one-GPU box they share the device (gloo control traffic, the line
+    says so).  Checks what the 8-GPU run will be judged on: n_gpus, nt balance, concat == whole, a roofline block."""
+    import torch
+
+    d = _bare_bench(n, 400000)
+    assert d["n_gpus"] == n and d["scaling"] == "strong" and d["config"]["launcher"] == "bench.py self_launch"
+    phys = torch.cuda.device_count()
+    assert d["config"]["physical_gpus"] == phys and d["config"]["ranks_share_gpus"] == (n > phys)
+    assert d["config"]["control_backend"] == ("nccl" if phys >= n else "gloo")
+    ranks = d["per_rank"]
+    assert [r["rank"] for r in ranks] == list(range(n)) and sum(r["orfs"] for r in ranks) == 400000
+    nts = [r["nt"] for r in ranks]
+    assert sum(nts) == d["config"]["nt_total"] and max(nts) - min(nts) <= 0.02 * sum(nts) / n + 100000
+    v = d["verify"]
+    assert v["ok"] is True and v["orfs_checked"] == 400000 and v["max_abs_dphase"] <= 1e-6
+    r = d["roofline"]  # the slowest rank's kernel, per launch and per GPU
+    slow = max(ranks, key=lambda x: x["kernel_ms"])
+    assert r["rank"] == slow["rank"] and r["kernel_ms"] == slow["kernel_ms"] and r["bound"] == "hbm"
+    assert r["algorithmic_bytes_per_launch"] == 4 * slow["nt"] + 8 * (slow["orfs"] + 1) + 24 * slow["orfs"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0 and r["node_achieved"] >= r["achieved"]
+    assert d["value"] == pytest.approx(400000 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3), rel=1e-9)
+    assert "cpu_baseline" not in d
+
+
+def test_one_rank_has_the_same_value_definition_with_and_without_a_process_group():
+    """N = 1 plain, and N = 1 with the N-rank control flow forced on (RP_BENCH_FORCE_DIST=1: RCCL init, barrier and
+    max-over-ranks on the one GPU -- the branch the 8-GPU run takes): `value` = ORFs of the whole job * steps /
+    max-over-ranks wall time of the K steps in both."""
+    plain = _bare_bench(1, 300000, extra=("--cpu-sample", "0", "--no-fused"))
+    forced = _bare_bench(1, 300000, extra=("--cpu-sample", "0", "--no-fused"), env_extra={"RP_BENCH_FORCE_DIST": "1"})
+    for d in (plain, forced):
+        assert d["n_gpus"] == 1 and d["config"]["orfs_total"] == 300000 and d["verify"]["ok"] is True
+        assert d["value"] == pytest.approx(300000 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3), rel=1e-9)
+        assert d["roofline"]["rank"] == 0 and d["roofline"]["kernel_ms"] == d["per_rank"][0]["kernel_ms"]
+    assert plain["config"]["control_backend"] is None and forced["config"]["control_backend"] == "nccl"
+    assert forced["verify"]["concat_equals_whole"]["ok"] is True and "concat_equals_whole" not in plain["verify"]

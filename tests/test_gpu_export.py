@@ -166,6 +166,16 @@ def test_export_sharded_over_two_slices_equals_single(tmp_path):
     assert d1[0] == d3[0]
     for a, b in zip(d1[1:], d3[1:]):  # the tile path: another slicing moves the fp32 partial sums by <= 2e-7
         assert a[:3] == b[:3] and a[4:] == b[4:] and abs(float(a[3]) - float(b[3])) <= 1e-6
+    # a second sample over the same devices: the shards (windows, gather plans, tile plans per slice) hang on the cached index
+    from ribotricer_amd import detect_orfs as d
+
+    export_orf_coverages(index, load_alignments(), str(tmp_path / "d3b"), devices=[0, 0, 0])
+    assert open(str(tmp_path / "d3b_translating_ORFs.tsv")).read() == open(str(tmp_path / "d3_translating_ORFs.tsv")).read()
+    cached = next(reversed(d._INDEX_CACHE.values()))
+    (table, plan, extras), = cached.__dict__["_layout_cache"].values()
+    cov_shards = extras[("coverage", (0, 0, 0))]
+    assert cov_shards.plans_built == 3  # two samples, one build per slice
+    assert extras[("csr", (0, 0))].plans_built <= 2 and ("csr", (0, 0, 0)) in extras
 
 
 def test_index_is_parsed_once_per_file_and_reparsed_when_it_changes(tmp_path):

@@ -162,6 +162,30 @@ def test_fused_sharded_equals_single():
         assert np.abs(parts["phase"] - whole["phase"]).max() <= 1e-6  # another tiling moves fp32 sums by <= 2e-7
 
 
+def test_coverage_shards_keep_their_plans_across_samples():
+    """engine.CoverageShards: windows, gather plans and tile plans of the slices are built by the FIRST sample only;
+    later samples (other coverage, same layout) upload their windows and launch -- and equal the one-GPU result."""
+    from ribotricer_amd.engine import CoverageShards, get_engine, make_filter
+    from ribotricer_amd.gather import GatherPlan
+
+    rng = np.random.default_rng(19)
+    n_cov = 300000
+    t = random_table(rng, 4000, n_cov)
+    whole_plan = GatherPlan(t, n_cov)
+    shards = CoverageShards(t, [0, 0, 0], n_cov)
+    for sample in range(3):
+        cov = rng.poisson(0.2 + 0.3 * sample, size=n_cov).astype(np.int32)
+        whole = get_engine("cuda:0").score_coverage(cov, whole_plan, thresholds=make_filter()).cpu_numpy()
+        parts = shards.score(cov, thresholds=make_filter())
+        for k in ("valid", "read_count", "min_codon_cov", "status"):
+            assert np.array_equal(parts[k], whole[k]), (k, sample)
+        assert np.abs(parts["phase"] - whole["phase"]).max() <= 1e-6
+        assert shards.plans_built == 3, (sample, shards.plans_built)
+    with pytest.raises(ValueError):
+        shards.score(np.zeros(n_cov + 16, np.int32))
+    shards.release()
+
+
 def test_gather_plan_abi_errors():
     """Argument checks of the gather-plan entry points: statuses, not crashes."""
     import ctypes

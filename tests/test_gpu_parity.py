@@ -385,6 +385,24 @@ def test_score_sharded_two_slices_one_gpu(eng):
     assert_matches_oracle(res_dev, counts, offsets)
 
 
+def test_csr_shards_keep_their_plans_across_samples(eng):
+    """One index, many samples, several devices (round-3 verdict 1d): engine.CsrShards builds a slice's offsets upload
+    and tile plan ONCE; the second and third sample of the same index reuse them and still equal the oracle."""
+    from ribotricer_amd.engine import CsrShards, make_filter, score_sharded
+    from ribotricer_amd.synth import synth_csr_host
+
+    counts, offsets = synth_csr_host(30000, seed=33, cfg="cfg3")
+    shards = CsrShards(offsets, [0, 0, 0, 0, 0])  # (five slices on one device: more than an engine's own plan cache holds)
+    rng = np.random.default_rng(8)
+    for sample in range(3):
+        c = counts if sample == 0 else rng.poisson(0.3 * sample, size=counts.size).astype(np.int32)
+        res = score_sharded(c, offsets, [0, 0, 0, 0, 0], thresholds=make_filter(), algo="tile", shards=shards)
+        assert_matches_oracle(res, c, offsets)
+        assert shards.plans_built == 5, (sample, shards.plans_built)
+    assert shards.matches(offsets, [0, 0, 0, 0, 0]) and not shards.matches(offsets, [0, 0])
+    shards.release()
+
+
 def test_validate_rejects_bad_input(eng):
     from ribotricer_amd._lib import RibophaseError
 
