@@ -206,6 +206,24 @@ class GatherPlan:
         _lib.check(_lib.load().rp_gather_profiles_plan_dev(self.handle, _ptr(cov), cov.numel(), _ptr(counts), stream))
         return counts
 
+    def stats(self) -> dict:
+        """Diagnostics (scripts): how the tiles of this plan are staged -- chunk rows per tile (<= 64
+        positions of one exon each; 352 fit a row, more take the scalar slow path), read back from the plan memory
+        (layout: csrc/rp_pieces.hpp ``carve_piece_plan`` behind the 128-byte header)."""
+        tile = _lib.tile_positions(self.n_orfs, self.total_nt)
+        n_tiles = max(1, -(-self.total_nt // tile))
+        up = lambda b: (b + 127) & ~127  # noqa: E731
+        at = 128 + 2 * up((self.n_intervals + 1) * 8) + up((self.n_orfs + 1) * 8) + up(n_tiles * 8)
+        torch.cuda.synchronize(self.device)
+        words = self._mem[at : at + 16 * n_tiles].cpu().numpy().view(np.int64).reshape(n_tiles, 2)
+        lo, chunks = words[:, 0], words[:, 1]
+        slow = lo == np.iinfo(np.int64).min
+        q = np.percentile(chunks, [50, 90, 99]) if n_tiles else [0, 0, 0]
+        return {"tile_positions": tile, "tiles": int(n_tiles), "slow_tiles": int(slow.sum()), "chunks_per_tile_mean": float(chunks.mean()),
+                "chunks_per_tile_p50_p90_p99": [float(x) for x in q], "chunks_per_tile_max": int(chunks.max()),
+                "tiles_over_256_chunks": int((chunks > 256).sum()), "positions_per_chunk_mean": float(self.total_nt / max(1, chunks[~slow].sum())),
+                "pieces_per_tile_mean": float(self.n_intervals / n_tiles)}
+
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
         if h:
