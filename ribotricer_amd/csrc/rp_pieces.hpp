@@ -29,10 +29,14 @@ constexpr int kMaxChunks = 352;                    // chunks in a tile's fixed-s
 constexpr long long kTileSlow = INT64_MIN;         // tile_lo of a tile whose chunks do not fit its row
 
 // A chunk (8 bytes): <= 64 consecutive positions of one piece, inside one tile.
-//   bits  0-31  byte offset of the chunk's lowest-ADDRESS element from cov + tile_lo
+//   bits  0-31  byte offset of the chunk's lowest-ADDRESS element from cov + tile_lo, low half
 //   bits 32-44  LDS index of its first position
 //   bits 45-50  64 - positions
 //   bit  51     the source index falls as the position rises ('-' strand piece)
+//   bits 52-58  the byte offset's high half (units of 4 GiB; round 4): the pieces of one tile may lie anywhere
+//               in a coverage of up to 512 GiB -- an index whose consecutive transcripts sit on different
+//               chromosomes (gigabytes apart in the dense coverage) sent 93 % of its tiles down the scalar slow
+//               path while the offset had 32 bits (profiles/r04_fused_nested_before.json)
 // Unused slots of a row repeat the row's chunk 0 (staging a chunk twice is harmless), so the
 // issuing code never has to ask how many there are.
 
@@ -153,14 +157,19 @@ __device__ __forceinline__ Clipped clip_piece(unsigned long long start_word, uns
     return c;
 }
 
-__device__ __forceinline__ chunk_desc_t make_chunk(const Clipped &c, long long tile_lo, int k)
+constexpr long long kMaxTileSpan = (1ll << 37) - 256;  // positions between a tile's lowest and highest source (7 + 32 bits of byte offset)
+constexpr unsigned kMaxChunkLow = 0xfffffe00u;         // a lane adds up to 252 to the low half in 32-bit arithmetic
+
+__device__ __forceinline__ chunk_desc_t make_chunk(const Clipped &c, long long tile_lo, int k, bool *low_half_full)
 {
-    const unsigned rel = (unsigned)(c.src - tile_lo);  // < 2^30 (checked by the caller)
+    const unsigned long long rel = (unsigned long long)(c.src - tile_lo);  // >= 64, < 2^37 (checked by the caller)
     const int left = c.n - 64 * k;
     const unsigned cnt = left < 64 ? (unsigned)left : 64u;
-    const unsigned soff = (c.neg ? rel - 64u * k - 63u : rel + 64u * k) * 4u;
-    return (chunk_desc_t)soff | ((chunk_desc_t)(unsigned)(c.off + 64 * k) << 32) | ((chunk_desc_t)(64u - cnt) << 45) |
-           ((chunk_desc_t)(c.neg ? 1u : 0u) << 51);
+    const unsigned long long soff = (c.neg ? rel - 64ull * k - 63ull : rel + 64ull * k) * 4ull;
+    const unsigned lo = (unsigned)soff;
+    if (lo > kMaxChunkLow) *low_half_full = true;  // (6e-8 of the chunks: the tile takes the slow path)
+    return (chunk_desc_t)lo | ((chunk_desc_t)(unsigned)(c.off + 64 * k) << 32) | ((chunk_desc_t)(64u - cnt) << 45) |
+           ((chunk_desc_t)(c.neg ? 1u : 0u) << 51) | ((chunk_desc_t)(soff >> 32) << 52);
 }
 
 // One workgroup per tile: find the piece that holds the tile's first position, clip the
@@ -172,7 +181,7 @@ template <int TILE, int HALO>
 __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, long long n_pieces, long long total_nt)
 {
     __shared__ long long s_j0, s_lo, s_hi;
-    __shared__ int s_total, s_base;
+    __shared__ int s_total, s_base, s_full;
     __shared__ int s_wave[kRowBlock / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const long long b = blockIdx.x;
@@ -220,12 +229,13 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
         if (!(last < n_pieces && (long long)(plan.start[last] & ~kPieceNeg) < t_end)) break;
     }
     __syncthreads();
-    const bool fast = s_total > 0 && s_total <= kMaxChunks && s_hi - s_lo < (1ll << 30) - 256;
+    const bool fast = s_total > 0 && s_total <= kMaxChunks && s_hi - s_lo < kMaxTileSpan;
     const long long tile_lo = fast ? s_lo - 64 : kTileSlow;
     if (t == 0) {
         plan.tile_lo[2 * b] = tile_lo;
         plan.tile_lo[2 * b + 1] = s_total;
         s_base = 0;
+        s_full = 0;
     }
     if (!fast) return;  // (the row stays unwritten: never read)
     // pass 2: the chunks, numbered by a prefix sum over the pieces
@@ -247,13 +257,19 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
         __syncthreads();
         int c0 = s_base + incl - nch;
         for (int w = 0; w < wave; ++w) c0 += s_wave[w];
-        for (int k = 0; k < nch; ++k) row[c0 + k] = make_chunk(c, tile_lo, k);
+        bool full = false;
+        for (int k = 0; k < nch; ++k) row[c0 + k] = make_chunk(c, tile_lo, k, &full);
+        if (full) s_full = 1;
         __syncthreads();
         if (t == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         const long long last = j0 + kRowBlock;
         if (!(last < n_pieces && (long long)(plan.start[last] & ~kPieceNeg) < t_end)) break;
     }
     __syncthreads();
+    if (s_full) {  // a chunk's low offset half leaves no room for the lanes' own 252 bytes
+        if (t == 0) plan.tile_lo[2 * b] = kTileSlow;
+        return;
+    }
     // pad: the slots past the last chunk repeat chunk 0 (written by the thread that owns position t0)
     __threadfence_block();
     const chunk_desc_t first = row[0];
@@ -274,16 +290,21 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
 #ifndef RP_CHUNK_POLICY
 #define RP_CHUNK_POLICY " nt"  // the coverage is read once per launch: tile gather -5 % on gapped / 60-nt layouts, else unchanged
 #endif
+// w1 = LDS address | (64 - positions) << 16 | dir << 24 | (byte offset >> 32) << 25; the scalar base of a step is
+// s[20:21] = {base low, base high + the chunk's high offset half} (named registers: an asm operand cannot be
+// addressed by halves; both are on the clobber list)
 #define RP_DMA_STEP(I)                                          \
     "v_readlane_b32 %[so], %[w0], " #I "\n\t"                   \
     "v_readlane_b32 %[s1], %[w1], " #I "\n\t"                   \
     "s_and_b32 m0, %[s1], 0xffff\n\t"                           \
     "s_lshr_b32 %[st], %[s1], 16\n\t"                           \
     "s_lshr_b64 exec, -1, %[st]\n\t"                            \
-    "s_lshr_b32 %[sd], %[st], 8\n\t"                            \
+    "s_bfe_u32 %[sd], %[s1], 0x10018\n\t"                       \
+    "s_lshr_b32 %[st], %[s1], 25\n\t"                           \
+    "s_add_u32 s21, %[bhi], %[st]\n\t"                          \
     "v_mad_i32_i24 %[vt], %[sd], %[vdelta], %[vup]\n\t"         \
     "v_add_u32 %[vt], %[so], %[vt]\n\t"                         \
-    "global_load_lds_dword %[vt], %[base]" RP_CHUNK_POLICY "\n\t"
+    "global_load_lds_dword %[vt], s[20:21]" RP_CHUNK_POLICY "\n\t"
 #define RP_DMA_STEP8(A, B, C, D, E, F, G, H, LIM)               \
     RP_DMA_STEP(A) RP_DMA_STEP(B) RP_DMA_STEP(C) RP_DMA_STEP(D) \
     RP_DMA_STEP(E) RP_DMA_STEP(F) RP_DMA_STEP(G) RP_DMA_STEP(H) \
@@ -302,7 +323,11 @@ __device__ __forceinline__ void issue_chunks(const int32_t *base, unsigned w0, u
     const int vup = lane * 4, vdelta = (63 - 2 * lane) * 4;  // vup + vdelta = (63 - lane) * 4
     unsigned so, s1, st, sd;
     int vt;
+    const unsigned long long u = (unsigned long long)base;
+    const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
     asm volatile(
+        "s_mov_b32 s20, %[blo]\n\t"
         RP_DMA_STEP8(0, 1, 2, 3, 4, 5, 6, 7, 8)
         RP_DMA_STEP8(8, 9, 10, 11, 12, 13, 14, 15, 16)
         RP_DMA_STEP8(16, 17, 18, 19, 20, 21, 22, 23, 24)
@@ -314,8 +339,8 @@ __device__ __forceinline__ void issue_chunks(const int32_t *base, unsigned w0, u
         "1:\n\t"
         "s_mov_b64 exec, -1"
         : [so] "=&s"(so), [s1] "=&s"(s1), [st] "=&s"(st), [sd] "=&s"(sd), [vt] "=&v"(vt)
-        : [w0] "v"(w0), [w1] "v"(w1), [vdelta] "v"(vdelta), [vup] "v"(vup), [base] "s"(base), [steps] "s"(steps)
-        : "memory", "scc", "m0", "exec");  // every step rewrites M0 and EXEC (EXEC is left all-ones, as it came in)
+        : [w0] "v"(w0), [w1] "v"(w1), [vdelta] "v"(vdelta), [vup] "v"(vup), [blo] "s"(blo), [bhi] "s"(bhi), [steps] "s"(steps)
+        : "memory", "scc", "m0", "exec", "s20", "s21");  // every step rewrites M0 and EXEC (EXEC is left all-ones, as it came in)
 }
 #pragma clang diagnostic pop
 #undef RP_DMA_STEP8
@@ -349,7 +374,7 @@ __device__ __forceinline__ void stage_tile_chunks(const int32_t *__restrict__ co
     const int32_t *base = scalar_ptr(cov + tile_lo);
     for (int r0 = 0;; r0 += 256) {  // workgroup-uniform; one round unless the tile has > 256 chunks
         const unsigned hi = (unsigned)(e >> 32);
-        const unsigned w1 = (lds0 + (hi & 0x1fffu) * 4u) | (((hi >> 13) & 0x3fu) << 16) | (((hi >> 19) & 1u) << 24);
+        const unsigned w1 = (lds0 + (hi & 0x1fffu) * 4u) | (((hi >> 13) & 0x3fu) << 16) | (((hi >> 19) & 1u) << 24) | (((hi >> 20) & 0x7fu) << 25);
         int steps = (total - r0 - wave + 3) >> 2;  // chunks r0 + wave, r0 + wave + 4, ... < total
         steps = __builtin_amdgcn_readfirstlane(steps > 64 ? 64 : steps);
         if (steps > 0) issue_chunks(base, (unsigned)e, w1, steps, lane);

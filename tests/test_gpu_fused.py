@@ -106,6 +106,51 @@ def test_fused_score_equals_gather_then_score(case, lam):
         assert (fused["flags"] & 0x08).any()  # ties were replayed through the piece view
 
 
+def test_pieces_of_one_tile_gigabytes_apart():
+    """Consecutive ORFs of an index on different chromosomes: the pieces of ONE tile lie gigabytes apart in the
+    dense coverage (12.9 GB here, three islands).  Until round 4 a chunk's byte offset had 32 bits and such tiles
+    took the scalar slow path (93 % of the tiles of the 11 M-ORF nested index: profiles/r04_fused_nested_before.json);
+    now the offset carries 7 more bits.  Tile gather == per-ORF gather (a code path of its own), fused == gather +
+    score bit for bit, and the oracle agrees."""
+    import torch
+
+    from helpers import assert_matches_oracle
+    from ribotricer_amd.engine import get_engine, make_filter
+    from ribotricer_amd.gather import GatherPlan, IntervalTable, gather_profiles_device
+
+    rng = np.random.default_rng(41)
+    cov_len = 3 * (1 << 30) + 12345
+    island = 300000
+    bases = [0, (1 << 30) + 77, (1 << 31) + 5, cov_len - island]  # byte offsets 0, 4 GiB + .., 8 GiB + .., 12 GiB + ..
+    cov = torch.zeros(cov_len, dtype=torch.int32, device="cuda")
+    for b in bases:
+        cov[b : b + island] = torch.from_numpy(rng.poisson(0.6, size=island).astype(np.int32)).cuda()
+    t = random_table(rng, 6000, island, max_exons=4, exon_len=(20, 300))
+    # every interval moves to the island of its ORF; ORF i lives on island i % 4, so every tile mixes all four
+    orf_of_iv = np.repeat(np.arange(6000), np.diff(t.orf_iv))
+    shift = np.asarray(bases, np.int64)[orf_of_iv % 4]
+    t = IntervalTable(t.iv_start + shift, t.iv_len, t.orf_iv, t.reverse, t.offsets)
+    plan = GatherPlan(t, cov_len)
+    st = plan.stats()
+    # the point: the tiles do not fall back to the scalar loop any more.  A few still do, on purpose: the islands sit
+    # right behind multiples of 4 GiB, so some chunks' low offset halves end within 512 bytes of 2^32, where the lanes'
+    # own 252 bytes would wrap -- such a tile is planned slow (6e-8 of the chunks on an ordinary layout, ~4 % of the
+    # tiles here): both staging paths are compared with the per-ORF gather below
+    assert 0 < st["slow_tiles"] < 0.1 * st["tiles"] and st["tiles"] >= 100, st
+    eng = get_engine("cuda:0")
+    th = make_filter()
+    counts = plan.gather(cov)
+    legacy, _ = gather_profiles_device(cov, t)
+    assert torch.equal(counts, legacy)
+    fused = eng.score_coverage(cov, plan, thresholds=th).cpu_numpy()
+    plain = eng.score(counts, plan.offsets, thresholds=th, algo="tile").cpu_numpy()
+    for k in ("phase", "valid", "read_count", "min_codon_cov", "flags", "status"):
+        assert np.array_equal(fused[k], plain[k]), k
+    assert_matches_oracle(fused, counts.cpu().numpy(), t.offsets)
+    del cov
+    torch.cuda.empty_cache()
+
+
 def test_fused_long_rewalk_reads_through_the_plan():
     """A cutoff placed on a long ORF's own phase score sends it to k_rewalk_long (float64,
     a workgroup per ORF), which in fused mode reads the coverage through the piece view."""
