@@ -240,6 +240,8 @@ def fused_section(args, eng, dev, thresholds, n_set, csr_out):
     placement = None
     if not args.no_tune_workspace and int(offsets[-1]) >= (64 << 20):  # (as for the CSR path: once per index, not timed)
         placement = eng.tune_workspace(cov, thresholds=thresholds, gather_plan=gplan)
+        if placement.get("spacers"):
+            time.sleep(1.0)
     for _ in range(5):
         out = eng.score_coverage(cov, gplan, thresholds=thresholds, reuse_outputs=True)
     tm: list = []
@@ -456,15 +458,32 @@ def main():
         plan = eng.plan_for(offsets, total_nt, (counts.data_ptr() // 4) % 4)  # validates the offsets, syncs
         plan_ms = 1e3 * (time.perf_counter() - t0)
 
+    def step():
+        return eng.score(counts, offsets, thresholds=thresholds, algo=algo, reuse_outputs=True, plan=plan)
+
     placement = None
+    first_alloc_ms = None
     if plan is not None and not args.no_tune_workspace and total_nt >= (64 << 20):
         # once per index, like the plan and outside the timed region: where the record workspace lies relative to the
         # counts decides between 2.6 and 3.0 ms per launch on this part; the engine tries a few
-        # allocations and keeps the fastest.  Reported in config.workspace_placement; --no-tune-workspace switches it off.
+        # placements, keeps the fastest and frees the rest -- exactly what the drop-in export does once per cached index
+        # (detect_orfs.score_index).  Reported in config.workspace_placement; --no-tune-workspace switches it off.
+        # Before it: the same step on the workspace as FIRST allocated (what a process gets without the search),
+        # reported as value_first_allocation.
+        n_first = max(3, min(args.steps, 20))
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n_first):
+            step()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        first_alloc_ms = e0.elapsed_time(e1) / n_first
         placement = eng.tune_workspace(counts, offsets, thresholds=thresholds)
-
-    def step():
-        return eng.score(counts, offsets, thresholds=thresholds, algo=algo, reuse_outputs=True, plan=plan)
+        if placement.get("spacers"):
+            time.sleep(1.0)  # the driver wipes the memory handed back in the background (1-4 % off the next second's kernels)
 
     def barrier():
         if dist is not None:
@@ -685,6 +704,10 @@ def main():
                 "translating": int(out.status.sum()),
             },
         }
+        if first_alloc_ms is not None:
+            result["value_first_allocation"] = (n_job / (first_alloc_ms * 1e-3)) if world == 1 else None
+            result["first_allocation"] = {"ms_per_step": first_alloc_ms, "steps": max(3, min(args.steps, 20)),
+                                          "what": "the same step before engine.tune_workspace: the record workspace where the first allocation put it (rank 0's slice)"}
         if single_ms is not None:
             result["value_single_sample"] = n_job / (single_ms * 1e-3) if world == 1 else None
             result["single_sample"] = {"ms_per_step": single_ms, "what": "tile index + segment descriptors + head rows rebuilt inside every step "

@@ -345,6 +345,15 @@ def _table_and_plan(index, base, coverage_len: int, device):
     return cache[key]
 
 
+PLACE_WORKSPACE_MIN_NT = 64 << 20  # below this a step is launch-bound: nothing to gain
+
+
+def _place_workspace_for(table) -> bool:
+    import os
+
+    return os.environ.get("RIBOTRICER_AMD_PLACE_WORKSPACE", "1") != "0" and int(table.offsets[-1]) >= PLACE_WORKSPACE_MIN_NT
+
+
 def _shards(extras: dict, kind: str, devices, build):
     """The layout's shards of ``kind`` for ``devices`` (made once per index, layout and device list)."""
     key = (kind, tuple(int(d) if isinstance(d, int) else str(d) for d in devices))
@@ -428,6 +437,16 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     table, plan, extras = _table_and_plan(index, base, coverage.numel(), device)
     t = lap("interval_table_gather_plan", t)
     sharded = devices is not None and len(devices) > 1
+    if plan is not None and not sharded and "workspace_placement" not in extras and _place_workspace_for(table):
+        # once per cached index (like the plans): put the record workspace where its writes cost the coverage reads
+        # least (engine.tune_workspace: +8-15 % on the scoring kernel in most processes; 0.1 s; nothing but ONE
+        # workspace stays allocated).  Pays from the second sample on; RIBOTRICER_AMD_PLACE_WORKSPACE=0 switches it off.
+        extras["workspace_placement"] = get_engine(device).tune_workspace(
+            coverage, thresholds=make_filter(phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio,
+                                             min_density_over_orf), gather_plan=plan, tries=3, spread=0.03)  # (a coverage far larger than a memory class: little to find, profiles/r04_placement_check.txt)
+        if timings is not None:
+            timings["workspace_placement_report"] = extras["workspace_placement"]
+        t = lap("workspace_placement", t)
     if plan is None or report_all:
         d_counts, d_offsets = gather_profiles_device(coverage, table, device, plan=plan)
         shards = None

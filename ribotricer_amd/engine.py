@@ -176,23 +176,24 @@ class PhaseScoreEngine:
         return ws
 
     def tune_workspace(self, counts, offsets=None, thresholds: Optional[FilterParams] = None, tries: int = 6,
-                       chunk_gib: float = 8.0, launches: int = 5, spread: float = 0.05, gather_plan=None,
-                       release: bool = False) -> dict:
-        """Opt-in, once per engine and index: look for a placement of the current stream's record workspace
-        whose writes do not share a class of physical memory with the counts they ride beside.
+                       spacer_gib: float = 8.0, launches: int = 4, spread: float = 0.05, gather_plan=None,
+                       release: bool = True) -> dict:
+        """Once per engine and index: place the current stream's record workspace where its writes do not share a
+        class of physical memory with the counts they ride beside -- and hold nothing else afterwards.
 
         On MI355X a write stream costs a read stream ~10 % when the two buffers lie in different classes of the
         physical address space (runs of 16-32 GiB) and ~23 % when they share one; the tile kernel writes its
         segment records while it streams the counts and takes 2.6 or 3.0 ms per 4 G nt accordingly (DESIGN.md
-        section 4, profiles/r03_probe_rw_regions.txt).  HIP has no placement hint and a fresh allocation
-        usually lands next to the previous one, so this allocates up to ``tries`` candidate workspaces of
-        ``chunk_gib`` one after the other -- the earlier ones stay allocated meanwhile, as spacers, which
-        walks the candidates through physical memory -- times the scoring step of THIS batch on each, and stops
-        once a NEW candidate beats the slowest seen by ``spread`` (or after ``tries``).  The fastest stays; the others go back to PyTorch's
-        caching allocator (later tensors reuse them) or, with ``release``, to the driver
-        (``torch.cuda.empty_cache()``; the driver wipes freed memory in the background, which costs the
-        kernels of the next second 1-4 %).  Never slower than before (the first workspace is a candidate),
-        0.1 s, up to ``tries * chunk_gib`` GiB touched; pays when one index is scored against many samples.
+        section 4, profiles/r03_probe_rw_regions.txt).  HIP has no placement hint and a fresh allocation usually
+        lands next to the previous one, so candidates are made one after the other -- each exactly the size the
+        batch needs, each behind a SPACER of ``spacer_gib`` that walks the next one through physical memory -- the
+        scoring step of THIS batch is timed on each, and the search stops once a new candidate beats the slowest
+        seen by ``spread`` (or after ``tries``).  The fastest stays; every spacer and every other candidate is
+        freed and, with ``release`` (default), handed back to the driver (``torch.cuda.empty_cache()``): what
+        remains reserved is the workload plus ONE workspace.  (The driver wipes freed memory in the background,
+        which costs the kernels of the next second 1-4 %.)  Never slower than before (the workspace as first
+        allocated is a candidate); ~0.1 s.  The drop-in export runs it once per cached index
+        (``detect_orfs.score_index``), ``bench.py`` once before its timed steps.
         With ``gather_plan`` the fused path is tuned instead: ``counts`` is then the dense coverage
         (:meth:`score_coverage`).  Returns what it measured."""
         dev = self.device
@@ -209,7 +210,11 @@ class PhaseScoreEngine:
             def run(t=None):
                 self.score_coverage(counts, gather_plan, thresholds=thresholds, reuse_outputs=True, timings=t)
         stream_key = int(torch.cuda.current_stream(dev).cuda_stream)
-        nbytes = max(_lib.workspace_bytes(n, total_nt, _lib.RP_ALGO_TILE), int(chunk_gib * (1 << 30)))
+        need = _lib.workspace_bytes(n, total_nt, _lib.RP_ALGO_TILE)
+        what = ("engine.tune_workspace: candidate record workspaces of the batch's own size, each behind a spacer allocation, "
+                "the scoring step timed on each; spacers and rejected candidates freed")
+        if n <= 0 or need == 0:
+            return {"step_ms": [], "chosen": None, "spacer_gib": spacer_gib, "what": what, "skipped": "empty batch"}
 
         def step_ms():
             t: list = []
@@ -220,29 +225,46 @@ class PhaseScoreEngine:
 
         lib = _lib.load()
         was = lib.rp_measurement_tag(1)  # the search's launches run under a second kernel name (profilers)
+        first = None
+        candidates: list = []
+        spacers: list = []
+        times: list = []
+        oom = False
         try:
-            for _ in range(3):  # plan, outputs, first workspace; clocks up
+            for _ in range(2):  # plan, outputs, first workspace; clocks up
                 run()
-            held = [self._workspace[stream_key]]
-            times = [step_ms()]
-            while len(held) <= tries and not (len(times) > 1 and times[-1] <= (1.0 - spread) * max(times)):
-                held.append(torch.empty(nbytes, dtype=torch.uint8, device=dev))
-                self._workspace[stream_key] = held[-1]
+            first = self._workspace.get(stream_key)
+            if first is None:
+                first = self._get_workspace(need, stream_key)
+            candidates.append(first)
+            times.append(step_ms())
+            if release:  # no cached block may serve a candidate: each must be a fresh allocation behind its spacer
+                torch.cuda.synchronize(dev)
+                torch.cuda.empty_cache()
+            while len(candidates) <= tries and not (len(times) > 1 and times[-1] <= (1.0 - spread) * max(times)):
+                try:
+                    spacers.append(torch.empty(int(spacer_gib * (1 << 30)), dtype=torch.uint8, device=dev))
+                    cand = torch.empty(need, dtype=torch.uint8, device=dev)
+                except torch.cuda.OutOfMemoryError:
+                    oom = True
+                    break
+                self._workspace[stream_key] = cand
+                candidates.append(cand)
                 times.append(step_ms())
-        except torch.cuda.OutOfMemoryError:
-            held = held[: len(times)]
         finally:
             torch.cuda.synchronize(dev)
             lib.rp_measurement_tag(was)
-        best = min(range(len(times)), key=times.__getitem__)
-        self._workspace[stream_key] = held[best]
-        report = {"step_ms": [round(t, 4) for t in times], "chosen": best, "chunk_gib": chunk_gib,
-                  "what": "engine.tune_workspace: candidate record workspaces allocated one after the other, the scoring step timed on each"}
-        del held
-        if release:  # back to the driver -- which wipes freed memory in the background: the next second of kernels runs 1-4 % slower
-            torch.cuda.synchronize(dev)
-            torch.cuda.empty_cache()
-        return report
+            candidates = candidates[: len(times)] if times else candidates[:1]
+            best = min(range(len(times)), key=times.__getitem__) if times else 0
+            if candidates:  # (an exception before the first timing leaves the workspace as it was)
+                self._workspace[stream_key] = candidates[best]
+            n_spacers = len(spacers)
+            del spacers, candidates, first
+            if release:
+                torch.cuda.empty_cache()
+        return {"step_ms": [round(t, 4) for t in times], "chosen": best, "spacer_gib": spacer_gib, "spacers": n_spacers,
+                "workspace_bytes": need, "out_of_memory": oom, "released_to_driver": bool(release),
+                "reserved_bytes_after": int(torch.cuda.memory_reserved(dev)), "what": what}
 
     def _get_outputs(self, n: int, with_status: bool, stream_key: int) -> PhaseScores:
         o = self._out.get(stream_key)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """engine.tune_workspace on a cfg3 batch: step time before, what the search saw, step time after.
-usage: tune_workspace_probe.py [cfg:n_orfs] [chunk GiB] [tries] [spread (1 = try them all)]"""
+usage: tune_workspace_probe.py [cfg:n_orfs] [spacer GiB] [tries] [spread (1 = try them all)]"""
 import json
 import os
 import sys
@@ -34,7 +34,7 @@ def main():
     if os.environ.get("KEEP_CACHE") == "1":  # (experiment: do the freed candidates have to go back to the driver?)
         torch.cuda.empty_cache = lambda: None
     t = time.perf_counter()
-    rep = eng.tune_workspace(counts, offsets, thresholds=th, chunk_gib=chunk, tries=tries, spread=float(sys.argv[4]) if len(sys.argv) > 4 else 0.06)
+    rep = eng.tune_workspace(counts, offsets, thresholds=th, spacer_gib=chunk, tries=tries, spread=float(sys.argv[4]) if len(sys.argv) > 4 else 0.06)
     dt = time.perf_counter() - t
     print(json.dumps({"before_kernel_finish_ms": before, "tune_s": round(dt, 2), "search_step_ms": rep["step_ms"], "chosen": rep["chosen"],
                       "after_kernel_finish_ms": now()}))

@@ -454,8 +454,9 @@ def test_full_size_properties(eng, algo):
 
 
 def test_tune_workspace_changes_placement_not_results():
-    """engine.tune_workspace (opt-in placement search for the record workspace) leaves every result bit-identical
-    and never picks a slower candidate than the first workspace."""
+    """engine.tune_workspace (placement search for the record workspace) leaves every result bit-identical, never
+    picks a slower candidate than the first workspace, and holds ONE workspace afterwards: spacers and rejected
+    candidates go back to the driver."""
     import torch
 
     from ribotricer_amd.engine import PhaseScoreEngine, make_filter
@@ -465,11 +466,19 @@ def test_tune_workspace_changes_placement_not_results():
     eng = PhaseScoreEngine("cuda:0")
     th = make_filter()
     before = eng.score(counts, offsets, thresholds=th, algo="tile")
-    rep = eng.tune_workspace(counts, offsets, thresholds=th, tries=3, chunk_gib=0.5)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    reserved_before = torch.cuda.memory_reserved("cuda:0")
+    rep = eng.tune_workspace(counts, offsets, thresholds=th, tries=3, spacer_gib=0.5)
+    assert rep["reserved_bytes_after"] <= reserved_before + 2 * rep["workspace_bytes"] + (64 << 20), (rep, reserved_before)
     after = eng.score(counts, offsets, thresholds=th, algo="tile")
     torch.cuda.synchronize()
     assert 1 <= len(rep["step_ms"]) <= 4 and 0 <= rep["chosen"] < len(rep["step_ms"])
-    assert rep["step_ms"][rep["chosen"]] == min(rep["step_ms"])
+    assert rep["step_ms"][rep["chosen"]] == min(rep["step_ms"]) and rep["spacers"] == len(rep["step_ms"]) - 1
+    ws = next(iter(eng._workspace.values()))
+    assert ws.numel() == rep["workspace_bytes"]  # a candidate of the batch's own size, not a spacer-sized chunk
+    empty = PhaseScoreEngine("cuda:0").tune_workspace(counts[:0], offsets[:1], thresholds=th)  # (round-3 advisor: KeyError / UnboundLocalError)
+    assert empty["chosen"] is None and empty["skipped"]
     for k in ("phase", "valid", "read_count", "min_codon_cov", "flags", "status"):
         assert torch.equal(getattr(before, k), getattr(after, k)), k
 
