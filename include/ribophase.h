@@ -53,7 +53,7 @@ typedef enum rp_status {
     RP_ERR_HIP = -4,       /* HIP runtime error (see rp_last_error) */
     RP_ERR_WORKSPACE = -5, /* workspace missing, misaligned or too small */
     RP_ERR_DEVICE = -6,    /* no such device / no HIP device available */
-    RP_ERR_COUNTS = -7,    /* a count is negative or exceeds RP_MAX_COUNT */
+    RP_ERR_COUNTS = -7,    /* a count is negative, passes 2^31 - 1, or (strict callers) exceeds RP_MAX_COUNT */
     RP_ERR_ARG = -8,       /* invalid enum / option value */
     RP_ERR_INDEX_COLUMNS = -9, /* index line without exactly 11 tab-separated fields (orf.py:143-152) */
     RP_ERR_INDEX_COORD = -10,  /* malformed "start-end,..." coordinate field */
@@ -70,6 +70,8 @@ typedef enum rp_status {
 #define RP_FLAG_SPLIT 0x04u    /* profile spanned more than one tile (several segment records) */
 #define RP_FLAG_REPLAY 0x08u   /* phase / valid_codons of this tie-flagged ORF come from the on-device
                                   replay of the reference's own float64 (numpy / scipy) arithmetic */
+#define RP_FLAG_BIGCOUNT 0x20u /* set by the Python layer (never by a kernel): the ORF holds a count beyond RP_MAX_COUNT and
+                                  its results were recomputed in float64 / int64 (engine.rescore_big_count_orfs) */
 #define RP_FLAG_BIGTIE 0x10u   /* the replay met a codon with a count >= 16: the reference squares through
                                   the host C library's pow() (statistics.py:83), which the device cannot
                                   restate past its host-filled table; phase / valid_codons stand on x*x
@@ -323,26 +325,45 @@ int rp_phase_score_coverage_dev(int device, const int32_t *d_coverage, int64_t c
  *                       (+offset on '+', -offset on '-': detect_orfs.py:76-80)
  *   d_count   int32[n]  reads; entries hitting one position add up (any order: integer atomics)
  *   d_group_* int64[n_groups]  first coverage index and [lo, hi] extent of each group
- * d_coverage must be zero-filled (or hold a partial sum) on entry.  Synchronous; RP_ERR_COUNTS
- * if an accumulated count leaves [0, RP_MAX_COUNT].
+ * d_coverage must be zero-filled (or hold a partial sum) on entry.  Synchronous.
+ * Counts beyond RP_MAX_COUNT (round 4; the reference has no limit: detect_orfs.py:176-187, 278-280):
+ *   big_counts != NULL   *big_counts = 1 when an accumulated count passed RP_MAX_COUNT, else 0; RP_OK either
+ *                        way.  The scoring kernels' fp32 codon arithmetic is exact only up to RP_MAX_COUNT, so the
+ *                        caller must finish the ORFs that hold such a position in float64
+ *                        (rp_coverage_big_positions_dev lists the positions; rp_phase_score_f64_csr_dev scores
+ *                        their profiles; integer sums from the int32 profile -- ribotricer_amd.engine.
+ *                        rescore_big_count_orfs does all three).
+ *   big_counts == NULL   the strict contract: RP_ERR_COUNTS when a count passes RP_MAX_COUNT.
+ * RP_ERR_COUNTS in both cases for a negative count or a sum past 2^31 - 1 (the coverage is int32).
  */
 int rp_coverage_build_dev(int device, const int32_t *d_group, const int64_t *d_pos, const int32_t *d_count,
                           int64_t n_entries, const int64_t *d_group_start, const int64_t *d_group_lo,
                           const int64_t *d_group_hi, int32_t n_groups, int32_t *d_coverage,
-                          int64_t coverage_len, void *hip_stream);
+                          int64_t coverage_len, void *hip_stream, int32_t *big_counts);
 
 /*
  * The same from the columns merge_read_lengths hands over (detect_orfs.py:54-83 as columns: strand
  * uint8 0 '+' / 1 '-', chromosome code int32, shifted position int64, count int64), with the
  * (strand, chromosome) -> group lookup on the device: d_lut[strand * n_chroms + chrom] = group of the
  * candidate-ORF index, or -1 where no ORF lives.  Rows outside every group's extent are dropped
- * whatever their count (the reference never looks them up); RP_ERR_COUNTS if a row that does land,
- * or an accumulated sum, leaves [0, RP_MAX_COUNT].  Synchronous.
+ * whatever their count (the reference never looks them up).  big_counts / RP_ERR_COUNTS as for
+ * rp_coverage_build_dev, for rows that do land and their sums.  Synchronous.
  */
 int rp_coverage_build_rows_dev(int device, const uint8_t *d_strand, const int32_t *d_chrom, const int64_t *d_pos,
                                const int64_t *d_count, int64_t n_rows, const int32_t *d_lut, int32_t n_chroms,
                                const int64_t *d_group_start, const int64_t *d_group_lo, const int64_t *d_group_hi,
-                               int32_t n_groups, int32_t *d_coverage, int64_t coverage_len, void *hip_stream);
+                               int32_t n_groups, int32_t *d_coverage, int64_t coverage_len, void *hip_stream,
+                               int32_t *big_counts);
+
+/*
+ * The positions of a dense coverage whose count passes RP_MAX_COUNT (after a coverage build reported
+ * big_counts): up to `capacity` indices into d_coverage are written to d_positions (any order),
+ * *n_found receives how many there are in all (call with capacity 0 to size the buffer).  One pass over
+ * the array; synchronous.  Replaces nothing in the reference -- it is what lets the fp32 kernels serve an
+ * input range the reference's Python ints cover (detect_orfs.py:176-187).
+ */
+int rp_coverage_big_positions_dev(int device, const int32_t *d_coverage, int64_t coverage_len, int64_t *d_positions,
+                                  int64_t capacity, int64_t *n_found, void *hip_stream);
 
 /*
  * Metagene profiles of one read length: replaces the per-ORF pandas

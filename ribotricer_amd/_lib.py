@@ -24,6 +24,7 @@ FLAG_RECHECK64 = 0x02
 FLAG_SPLIT = 0x04
 FLAG_REPLAY = 0x08
 FLAG_BIGTIE = 0x10
+FLAG_BIGCOUNT = 0x20
 MIN_CODON_COV_EMPTY = 2147483647
 MAX_COUNT = 16777215
 ERR_INTERVALS = -12
@@ -84,8 +85,10 @@ SYMBOLS = {
                                            _vp, ctypes.c_size_t, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_float * 4)]),
     "rp_validate_csr_dev": (_int, [_int, _vp, _vp, _i64, _i64, _vp]),
     "rp_metagene_dev": (_int, [_int, _vp, _vp, _i64, ctypes.c_int32, _vp, _vp, _vp, _vp]),
-    "rp_coverage_build_dev": (_int, [_int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp]),
-    "rp_coverage_build_rows_dev": (_int, [_int, _vp, _vp, _vp, _vp, _i64, _vp, ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp]),
+    "rp_coverage_build_dev": (_int, [_int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp, ctypes.POINTER(ctypes.c_int32)]),
+    "rp_coverage_build_rows_dev": (_int, [_int, _vp, _vp, _vp, _vp, _i64, _vp, ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp,
+                                          ctypes.POINTER(ctypes.c_int32)]),
+    "rp_coverage_big_positions_dev": (_int, [_int, _vp, _i64, _vp, _i64, ctypes.POINTER(_i64), _vp]),
     # host side (no GPU): TSV row rendering
     "rp_format_rows_host": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp,
                                    ctypes.c_size_t, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_size_t)]),

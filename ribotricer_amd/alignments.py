@@ -194,12 +194,39 @@ def merge_read_lengths(alignments, psite_offsets) -> MergedColumns:
     return MergedColumns(strand, cols.chrom[keep], pos, cols.count[keep], list(cols.chroms))
 
 
-def build_coverage_device(merged, index, device=None):
+def big_positions_device(values, device=None) -> np.ndarray:
+    """Sorted indices of the entries of an int32 device array (a dense coverage, or CSR counts) that pass
+    ``RP_MAX_COUNT`` (``rp_coverage_big_positions_dev``: one pass; the first call sizes the buffer)."""
+    import torch
+
+    from .engine import _ptr
+
+    dev = values.device
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    lib = _lib.load()
+    found = ctypes.c_int64(0)
+    _lib.check(lib.rp_coverage_big_positions_dev(dev.index, _ptr(values), values.numel(), None, 0, ctypes.byref(found), stream))
+    if found.value == 0:
+        return np.zeros(0, np.int64)
+    out = torch.empty(found.value, dtype=torch.int64, device=dev)
+    _lib.check(lib.rp_coverage_big_positions_dev(dev.index, _ptr(values), values.numel(), _ptr(out), out.numel(), ctypes.byref(found), stream))
+    return np.sort(out.cpu().numpy())
+
+
+def build_coverage_device(merged, index, device=None, big=None):
     """Dense P-site coverage of every (strand, chrom) group of ``index`` (a ``NativeIndex``) in
     HBM: ``(coverage int32 device tensor, base)`` with ``base[(strand, chrom)] = (index of position
     lo, lo)`` -- what ``gather.interval_table_from_index`` takes.  ``merged``: :class:`MergedColumns`
     or the reference's ``strand -> Counter``.  Only the histogram rows cross PCIe (16 bytes per
-    row); the adding-up and the range check (RP_ERR_COUNTS) happen on the device."""
+    row); the adding-up and the range check (RP_ERR_COUNTS) happen on the device.
+
+    Counts beyond ``RP_MAX_COUNT`` = 2^24 - 1 (the reference has none: detect_orfs.py:176-187 work on Python
+    ints; the scoring kernels' fp32 codon arithmetic is exact up to there): with ``big`` = a dict the build
+    goes through and ``big["positions"]`` receives the sorted coverage indices of such positions (empty on
+    ordinary samples) -- the caller finishes the ORFs that hold one with
+    ``engine.rescore_big_count_orfs``; without it (callers that hand the coverage to the fp32 scorers
+    themselves) such a count raises ``RibophaseError`` (status -7).  A negative count or a sum past 2^31 - 1
+    raises either way."""
     import torch
 
     from .engine import _ptr, get_engine
@@ -212,6 +239,8 @@ def build_coverage_device(merged, index, device=None):
     base, total = coverage_layout(extent)
     keys = index.group_keys
     coverage = torch.zeros(total, dtype=torch.int32, device=dev)
+    if big is not None:
+        big["positions"] = np.zeros(0, np.int64)
     if cols.pos.size == 0 or total == 0:
         return coverage, base
     g_start = np.array([base[k][0] for k in keys], np.int64)
@@ -236,12 +265,16 @@ def build_coverage_device(merged, index, device=None):
     d_pos, d_count = to_dev(cols.pos, np.int64), to_dev(cols.count, np.int64)
     d_lut, d_start, d_lo, d_hi = to_dev(lut.ravel(), np.int32), to_dev(g_start, np.int64), to_dev(g_lo, np.int64), to_dev(g_hi, np.int64)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    flag = ctypes.c_int32(0)
     _lib.check(
         _lib.load().rp_coverage_build_rows_dev(
             dev.index, _ptr(d_strand), _ptr(d_chrom), _ptr(d_pos), _ptr(d_count), d_pos.numel(), _ptr(d_lut), n_chroms,
             _ptr(d_start), _ptr(d_lo), _ptr(d_hi), len(keys), _ptr(coverage), coverage.numel(), stream,
+            ctypes.byref(flag) if big is not None else None,
         )
     )
+    if big is not None and flag.value:
+        big["positions"] = big_positions_device(coverage)
     return coverage, base
 
 

@@ -638,16 +638,18 @@ int rp_phase_score_csr_host(const int32_t *counts, const int64_t *offsets, int64
             const int64_t len = offsets[i + 1] - offsets[i];
             rpreplay::replay_profile(v, len, &phase[i], &valid[i]);
             int64_t total = 0;
-            int32_t mn = RP_MIN_CODON_COV_EMPTY;
+            int64_t mn = RP_MIN_CODON_COV_EMPTY;
             for (int64_t k = 0; k < len; k += 3) {  // collapse_coverage_to_codon, common.py:164-180 (the last codon may be partial)
                 int64_t codon = v[k];
                 if (k + 1 < len) codon += v[k + 1];
                 if (k + 2 < len) codon += v[k + 2];
                 total += codon;
-                if (codon < mn) mn = (int32_t)codon;
+                if (codon < mn) mn = codon;
             }
             read_count[i] = total;
-            min_codon_cov[i] = mn;
+            // (counts beyond 2^29: a codon sum can pass int32 -- the output saturates below the "empty" sentinel, the
+            // predicate below sees the exact sum)
+            min_codon_cov[i] = (int32_t)(len > 0 && mn > (int64_t)RP_MIN_CODON_COV_EMPTY - 1 ? (int64_t)RP_MIN_CODON_COV_EMPTY - 1 : mn);
             flags[i] = 0;
             if (status && filter) {
                 const int64_t n_codons = len / 3 > 1 ? len / 3 : 1;  // detect_orfs.py:281
@@ -797,11 +799,28 @@ int rp_phase_score_coverage_dev(int device, const int32_t *d_coverage, int64_t c
                       d_flags, d_status, filter, d_workspace, workspace_bytes, RP_ALGO_TILE, plan, hip_stream, nullptr, gather);
 }
 
+namespace {
+// err bit 0: a sum passed RP_MAX_COUNT (fine when the caller asked to be told: it finishes those ORFs in float64);
+// bit 1: negative, or past INT32_MAX -- not representable in the int32 coverage
+int coverage_build_verdict(int h_err, int32_t *big_counts)
+{
+    if (h_err & 2) return fail(RP_ERR_COUNTS, "a P-site count is negative, or an accumulated count passed 2^31 - 1 (the coverage is int32)");
+    if (h_err & 1) {
+        if (!big_counts)
+            return fail(RP_ERR_COUNTS, "an accumulated P-site count passed %d (pass big_counts to be told instead: "
+                                       "rp_coverage_big_positions_dev then lists the positions)", RP_MAX_COUNT);
+        *big_counts = 1;
+    }
+    return RP_OK;
+}
+}  // namespace
+
 int rp_coverage_build_dev(int device, const int32_t *d_group, const int64_t *d_pos, const int32_t *d_count,
                           int64_t n_entries, const int64_t *d_group_start, const int64_t *d_group_lo,
                           const int64_t *d_group_hi, int32_t n_groups, int32_t *d_coverage,
-                          int64_t coverage_len, void *hip_stream)
+                          int64_t coverage_len, void *hip_stream, int32_t *big_counts)
 {
+    if (big_counts) *big_counts = 0;
     if (n_entries < 0 || coverage_len < 0 || n_groups < 0) return fail(RP_ERR_SIZE, "negative size");
     if (n_entries > 0 && (!d_group || !d_pos || !d_count || !d_group_start || !d_group_lo || !d_group_hi))
         return fail(RP_ERR_NULL, "entry columns and group tables must be non-null");
@@ -825,15 +844,16 @@ int rp_coverage_build_dev(int device, const int32_t *d_group, const int64_t *d_p
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     (void)hipFree(d_err);
     if (e != hipSuccess) return fail(RP_ERR_HIP, "coverage build: %s", hipGetErrorString(e));
-    if (h_err) return fail(RP_ERR_COUNTS, "an accumulated P-site count left [0, %d]", RP_MAX_COUNT);
-    return RP_OK;
+    return coverage_build_verdict(h_err, big_counts);
 }
 
 int rp_coverage_build_rows_dev(int device, const uint8_t *d_strand, const int32_t *d_chrom, const int64_t *d_pos,
                                const int64_t *d_count, int64_t n_rows, const int32_t *d_lut, int32_t n_chroms,
                                const int64_t *d_group_start, const int64_t *d_group_lo, const int64_t *d_group_hi,
-                               int32_t n_groups, int32_t *d_coverage, int64_t coverage_len, void *hip_stream)
+                               int32_t n_groups, int32_t *d_coverage, int64_t coverage_len, void *hip_stream,
+                               int32_t *big_counts)
 {
+    if (big_counts) *big_counts = 0;
     if (n_rows < 0 || coverage_len < 0 || n_groups < 0 || n_chroms < 0) return fail(RP_ERR_SIZE, "negative size");
     if (n_rows > 0 && (!d_strand || !d_chrom || !d_pos || !d_count || !d_lut || !d_group_start || !d_group_lo || !d_group_hi))
         return fail(RP_ERR_NULL, "row columns, lookup table and group tables must be non-null");
@@ -857,7 +877,36 @@ int rp_coverage_build_rows_dev(int device, const uint8_t *d_strand, const int32_
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     (void)hipFree(d_err);
     if (e != hipSuccess) return fail(RP_ERR_HIP, "coverage build: %s", hipGetErrorString(e));
-    if (h_err) return fail(RP_ERR_COUNTS, "a P-site count (or an accumulated sum) left [0, %d]", RP_MAX_COUNT);
+    return coverage_build_verdict(h_err, big_counts);
+}
+
+int rp_coverage_big_positions_dev(int device, const int32_t *d_coverage, int64_t coverage_len, int64_t *d_positions,
+                                  int64_t capacity, int64_t *n_found, void *hip_stream)
+{
+    if (!n_found) return fail(RP_ERR_NULL, "n_found is null");
+    *n_found = 0;
+    if (coverage_len < 0 || capacity < 0) return fail(RP_ERR_SIZE, "negative size");
+    if (coverage_len > 0 && !d_coverage) return fail(RP_ERR_NULL, "d_coverage is null");
+    if (capacity > 0 && !d_positions) return fail(RP_ERR_NULL, "d_positions is null but capacity > 0");
+    RP_ON_DEVICE(device);
+    if (coverage_len == 0) return RP_OK;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    unsigned long long *d_found = nullptr;
+    RP_HIP(hipMalloc(&d_found, sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_found, 0, sizeof(unsigned long long), stream);
+    unsigned long long h_found = 0;
+    if (e == hipSuccess) {
+        long long blocks = (coverage_len + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(rp::k_big_positions, dim3((unsigned)blocks), dim3(256), 0, stream, d_coverage, (long long)coverage_len,
+                           reinterpret_cast<long long *>(d_positions), (long long)capacity, d_found);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_found, d_found, sizeof(h_found), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d_found);
+    if (e != hipSuccess) return fail(RP_ERR_HIP, "big positions: %s", hipGetErrorString(e));
+    *n_found = (int64_t)h_found;
     return RP_OK;
 }
 

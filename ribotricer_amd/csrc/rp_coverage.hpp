@@ -17,7 +17,9 @@
 
 namespace rp {
 
-// err[0] |= 1 when an accumulated count leaves [0, RP_MAX_COUNT] (the scorers' input contract)
+// err[0] |= 1 when an accumulated count passes RP_MAX_COUNT (what the fp32 codon arithmetic of the scorers takes
+// exactly: the caller finishes the ORFs that hold such a position in float64, rp_coverage_big_positions_dev),
+// err[0] |= 2 when a count is negative or a sum passes INT32_MAX (not representable in the coverage array)
 __global__ void k_coverage_build(const int32_t *__restrict__ group, const int64_t *__restrict__ pos,
                                  const int32_t *__restrict__ count, long long n,
                                  const int64_t *__restrict__ group_start, const int64_t *__restrict__ group_lo,
@@ -33,17 +35,22 @@ __global__ void k_coverage_build(const int32_t *__restrict__ group, const int64_
         const long long idx = group_start[g] + (p - group_lo[g]);
         if (idx < 0 || idx >= coverage_len) continue;
         const int c = count[k];
+        if (c < 0) {
+            atomicOr(err, 2);
+            continue;
+        }
         const int before = atomicAdd(&coverage[idx], c);
         const long long after = (long long)before + c;
-        if (c < 0 || after > RP_MAX_COUNT) atomicOr(err, 1);
+        if (before < 0 || after > 2147483647ll) atomicOr(err, 2);  // (wrapped)
+        else if (after > RP_MAX_COUNT) atomicOr(err, 1);
     }
 }
 
 // The same straight from the columns merge_read_lengths hands over -- strand uint8, chromosome code
 // int32, position int64, count int64 -- with the (strand, chromosome) -> group lookup done here
 // (lut[strand * n_chroms + chrom], -1: no ORF lives there): no per-row work is left on the host.
-// err |= 1: an accumulated count left [0, RP_MAX_COUNT]; only rows that land inside a group's
-// extent take part -- the reference never looks the others up (detect_orfs.py:176-187).
+// err bits as above; only rows that land inside a group's extent take part -- the reference never looks the
+// others up (detect_orfs.py:176-187).
 __global__ void k_coverage_build_rows(const uint8_t *__restrict__ strand, const int32_t *__restrict__ chrom,
                                       const int64_t *__restrict__ pos, const int64_t *__restrict__ count, long long n,
                                       const int32_t *__restrict__ lut, int n_chroms, const int64_t *__restrict__ group_start,
@@ -61,12 +68,29 @@ __global__ void k_coverage_build_rows(const uint8_t *__restrict__ strand, const 
         const long long idx = group_start[g] + (p - group_lo[g]);
         if (idx < 0 || idx >= coverage_len) continue;
         const long long cnt = count[k];
-        if (cnt < 0 || cnt > RP_MAX_COUNT) {
-            atomicOr(err, 1);
+        if (cnt < 0 || cnt > 2147483647ll) {
+            atomicOr(err, 2);
             continue;
         }
         const int before = atomicAdd(&coverage[idx], (int)cnt);
-        if ((long long)before + cnt > RP_MAX_COUNT) atomicOr(err, 1);
+        const long long after = (long long)before + cnt;
+        if (before < 0 || after > 2147483647ll) atomicOr(err, 2);  // (wrapped)
+        else if (after > RP_MAX_COUNT) atomicOr(err, 1);
+    }
+}
+
+// The positions of a dense coverage whose count passes RP_MAX_COUNT, appended (any order) to `positions`
+// while they fit; *found counts them all.  Runs only when a coverage build reported such a count: a pass
+// over the whole array (a saturated position is a handful-per-sample event: rRNA / tRNA pile-ups).
+__global__ void k_big_positions(const int32_t *__restrict__ coverage, long long coverage_len, long long *__restrict__ positions,
+                                long long capacity, unsigned long long *__restrict__ found)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < coverage_len; k += stride) {
+        if (coverage[k] > RP_MAX_COUNT) {
+            const unsigned long long at = atomicAdd(found, 1ull);
+            if ((long long)at < capacity) positions[at] = k;
+        }
     }
 }
 

@@ -419,8 +419,8 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     import torch
 
     from .alignments import build_coverage_device
-    from .engine import resolve_big_ties
-    from .gather import coverage_profiles_of, gather_profiles_device, interval_table_from_index, make_gather_plan, select_orfs
+    from .engine import rescore_big_count_orfs, resolve_big_ties
+    from .gather import coverage_profiles_of, gather_profiles_device, interval_table_from_index, make_gather_plan, orfs_touching, select_orfs
 
     import time
 
@@ -432,7 +432,8 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
 
     device = None if not devices else f"cuda:{int(devices[0])}"
     t = time.perf_counter()
-    coverage, base = build_coverage_device(merged_alignments, index, device)
+    big: dict = {}  # positions whose count passes 2^24 - 1 (none on ordinary samples): their ORFs are finished in float64 below
+    coverage, base = build_coverage_device(merged_alignments, index, device, big=big)
     t = lap("coverage_build", t)
     table, plan, extras = _table_and_plan(index, base, coverage.numel(), device)
     t = lap("interval_table_gather_plan", t)
@@ -458,6 +459,7 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
             d_counts, d_offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
             min_valid_codons_ratio, min_density_over_orf, device=device, devices=devices, shards=shards,
         )
+        # (counts beyond 2^24 - 1: score_profiles scans the gathered CSR counts itself -- engine.fix_big_counts_csr)
         t = lap("gather_score_results_d2h", t)
         if profiles_on_device:  # (the caller streams them back slice by slice: _profile_slices)
             return d_counts, d_offsets.cpu().numpy(), res
@@ -478,6 +480,8 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
         torch.cuda.synchronize(eng.device)
         res = res.cpu_numpy()
         resolve_big_ties(res, coverage_profiles_of(coverage, table, device), thresholds)
+    if big["positions"].size:
+        rescore_big_count_orfs(res, orfs_touching(table, big["positions"]), coverage_profiles_of(coverage, table, device), thresholds, device)
     t = lap("fused_score_results_d2h", t)
     keep = res["status"] != 0
     chosen = np.flatnonzero(keep)

@@ -464,11 +464,15 @@ class PhaseScoreEngine:
     def score_host(self, counts, offsets, thresholds: Optional[FilterParams] = None, algo: str = "auto", plan="auto") -> dict:
         """:meth:`score`, waited for and brought to the host as a dict of numpy arrays, with the
         exact frame ties the device could not finish resolved (:func:`resolve_big_ties`): every
-        ``phase`` / ``valid`` then carries the reference's bits wherever a tie is flagged."""
-        res = self.score(counts, offsets, thresholds=thresholds, algo=algo, plan=plan)
+        ``phase`` / ``valid`` then carries the reference's bits wherever a tie is flagged.  ORFs that hold a
+        count beyond ``RP_MAX_COUNT`` are finished in float64 / int64 (:func:`fix_big_counts_csr`;
+        ``RP_FLAG_BIGCOUNT``): no count the int32 array can hold is refused."""
+        d_counts = _as_device(counts, torch.int32, self.device)
+        res = self.score(d_counts, offsets, thresholds=thresholds, algo=algo, plan=plan)
         torch.cuda.synchronize(self.device)
         host = res.cpu_numpy()
         resolve_big_ties(host, csr_profiles_of(counts, offsets), thresholds)
+        fix_big_counts_csr(host, d_counts, offsets, thresholds)  # counts beyond 2^24 - 1: those ORFs again, in float64 / int64
         return host
 
     def release_stream(self, stream) -> None:
@@ -512,6 +516,66 @@ def resolve_big_ties(res: dict, profiles_of, thresholds: Optional[FilterParams] 
     if thresholds is not None and res.get("status") is not None:
         res["status"][idx] = status_host(thresholds, phase, valid, res["read_count"][idx], res["min_codon_cov"][idx], np.diff(offsets))
     return int(idx.size)
+
+
+def rescore_big_count_orfs(res: dict, orf_ids, profiles_of, thresholds: Optional[FilterParams] = None, device=None) -> int:
+    """Finish the ORFs that hold a count beyond ``RP_MAX_COUNT`` = 2^24 - 1 (a saturated position: rRNA / tRNA
+    pile-ups).  The reference has no limit -- ``sum(cov)`` and ``phasescore(cov)`` work on Python ints
+    (detect_orfs.py:278-280) -- but the scoring kernels' fp32 codon arithmetic and 32-bit codon sums are exact
+    only up to there, so what they wrote for such an ORF is discarded: its profile (``profiles_of(orf_ids) ->
+    (counts int32, offsets)``, host CSR) is scored again by the float64 kernel (``rp_phase_score_f64_csr_dev``:
+    exact below 2^53; exact frame ties replayed with the reference's own arithmetic as everywhere), ``read_count``
+    and the codon minimum are summed in int64 on the host, the status predicate is taken on those exact values,
+    and ``res`` (host arrays) is patched in place; ``flags`` gets ``RP_FLAG_BIGCOUNT``.  ``min_codon_cov``
+    (int32) saturates at 2^31 - 2 when a codon sum passes int32.  Returns how many ORFs that was."""
+    orf_ids = np.asarray(orf_ids, np.int64)
+    if orf_ids.size == 0:
+        return 0
+    counts, offsets = profiles_of(orf_ids)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    eng = get_engine(device)
+    d_phase, d_valid, d_flags = eng.score_float_profiles(counts.astype(np.float64), offsets)
+    torch.cuda.synchronize(eng.device)
+    phase, valid, flags = d_phase.cpu().numpy(), d_valid.cpu().numpy(), d_flags.cpu().numpy()
+    lengths = np.diff(offsets)
+    tied = np.flatnonzero(flags & _lib.FLAG_TIE)
+    if tied.size:  # the reference's strict `>` between equal frames: its own float64 arithmetic, replayed (DESIGN.md section 2)
+        sub_off = np.zeros(tied.size + 1, np.int64)
+        np.cumsum(lengths[tied], out=sub_off[1:])
+        sub = np.concatenate([counts[offsets[i] : offsets[i + 1]] for i in tied]) if sub_off[-1] else np.zeros(0, np.int32)
+        phase[tied], valid[tied] = _lib.tie_replay_host(sub, sub_off)
+        flags[tied] |= _lib.FLAG_REPLAY
+    read_count = np.zeros(orf_ids.size, np.int64)
+    min_codon = np.full(orf_ids.size, _lib.MIN_CODON_COV_EMPTY, np.int64)
+    for k in range(orf_ids.size):  # (a handful of ORFs; common.py:164-180: codon sums, the last one may be partial)
+        prof = counts[offsets[k] : offsets[k + 1]].astype(np.int64)
+        if prof.size:
+            read_count[k] = prof.sum()
+            min_codon[k] = np.pad(prof, (0, -prof.size % 3)).reshape(-1, 3).sum(axis=1).min()
+    res["phase"][orf_ids] = phase
+    res["valid"][orf_ids] = valid
+    res["read_count"][orf_ids] = read_count
+    res["min_codon_cov"][orf_ids] = np.where(lengths > 0, np.minimum(min_codon, _lib.MIN_CODON_COV_EMPTY - 1), _lib.MIN_CODON_COV_EMPTY).astype(np.int32)
+    res["flags"][orf_ids] = (flags & (_lib.FLAG_TIE | _lib.FLAG_REPLAY)) | _lib.FLAG_BIGCOUNT
+    if thresholds is not None and res.get("status") is not None:
+        res["status"][orf_ids] = status_host(thresholds, phase, valid, read_count, min_codon, lengths)
+    return int(orf_ids.size)
+
+
+def fix_big_counts_csr(res: dict, counts, offsets, thresholds: Optional[FilterParams] = None) -> int:
+    """:func:`rescore_big_count_orfs` for a CSR batch whose ``counts`` live on a device: one scan for entries
+    beyond ``RP_MAX_COUNT`` (none on ordinary data), then the ORFs that hold one."""
+    from .alignments import big_positions_device
+
+    if not isinstance(counts, torch.Tensor) or not counts.is_cuda or counts.numel() == 0:
+        return 0
+    positions = big_positions_device(counts)
+    if positions.size == 0:
+        return 0
+    off = offsets.cpu().numpy() if isinstance(offsets, torch.Tensor) else np.asarray(offsets, np.int64)
+    ids = np.unique(np.searchsorted(off, positions, side="right") - 1)
+    return rescore_big_count_orfs(res, ids, csr_profiles_of(counts, off), thresholds, counts.device)
 
 
 def csr_profiles_of(counts, offsets):
@@ -640,6 +704,8 @@ class CsrShards:
                 stream.synchronize()
             out = {k_: (None if v is None else v.numpy()) for k_, v in host.items()}
             resolve_big_ties(out, csr_profiles_of(c, o), thresholds)
+            with torch.cuda.device(dev), torch.cuda.stream(stream):
+                fix_big_counts_csr(out, c, o, thresholds)
             return out
 
         return concat_results(_run_slices(work, len(self.devices)))

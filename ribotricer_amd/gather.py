@@ -258,6 +258,20 @@ def select_orfs(table: IntervalTable, orf_ids: np.ndarray) -> IntervalTable:
     return IntervalTable(table.iv_start[pick], table.iv_len[pick], orf_iv, table.reverse[orf_ids], offsets)
 
 
+def orfs_touching(table: IntervalTable, positions: np.ndarray) -> np.ndarray:
+    """Sorted ids of the ORFs with an exon interval that contains one of ``positions`` (coverage indices):
+    who holds the saturated positions ``alignments.build_coverage_device`` reported.  Two binary searches per
+    interval -- a rare path (no such position on ordinary samples)."""
+    positions = np.sort(np.asarray(positions, np.int64))
+    if positions.size == 0 or len(table.iv_start) == 0:
+        return np.zeros(0, np.int64)
+    start = np.asarray(table.iv_start, np.int64)
+    end = start + np.asarray(table.iv_len, np.int64)
+    hit = np.searchsorted(positions, end, side="left") > np.searchsorted(positions, start, side="left")
+    iv = np.flatnonzero(hit)
+    return np.unique(np.searchsorted(np.asarray(table.orf_iv, np.int64), iv, side="right") - 1)
+
+
 def gather_profiles_device(coverage, table: IntervalTable, device=None, plan=None):
     """Run the gather on the GPU: ``(counts int32 device tensor, offsets int64 device tensor)``.
     With a :class:`GatherPlan` of the same table: the tile kernel; otherwise one wave per ORF."""

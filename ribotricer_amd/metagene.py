@@ -154,7 +154,8 @@ def metagene_coverage(cds, alignments, read_lengths, prefix, max_positions=600, 
     lib = _lib.load()
     metagenes = {}
     for length in read_lengths:
-        coverage, _ = build_coverage_device(cols.of_length(int(length)), layout, dev)
+        # (big={}: counts beyond 2^24 - 1 are fine here -- the metagene kernels add in int64 / float64)
+        coverage, _ = build_coverage_device(cols.of_length(int(length)), layout, dev, big={})
         counts, offsets = gather_profiles_device(coverage, table, dev)
         n = offsets.numel() - 1
         mean = torch.empty(max(n, 1), dtype=torch.float64, device=dev)

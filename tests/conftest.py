@@ -71,6 +71,11 @@ def g8():
 
 
 @pytest.fixture(scope="session")
+def g10():
+    return load_npz("g10_bigcounts.npz")
+
+
+@pytest.fixture(scope="session")
 def g8f():
     return load_json("g8_float_ties.json")["vectors"]
 

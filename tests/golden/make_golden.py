@@ -23,6 +23,8 @@ Fixture sets:
                          metagene profiles, P-site offsets, merged alignments, WIG, TSV
   g8_bigties.npz         3200 sparse profiles with counts 16..1000 (some to 3e6) built to tie
   g8_float_ties.json     400 float-valued profiles built to tie
+  g10_bigcounts.npz      240 profiles holding counts 2^24 .. 2^30 (beyond the fp32-exact range of the kernels)
+  g10_*                  end-to-end: the g6 index + its alignments with such counts piled on 16 ORFs + the reference's TSVs
 """
 
 from __future__ import annotations
@@ -476,7 +478,85 @@ def g8():
     print(f"g8_float_ties.json: {len(rows)} vectors")
 
 
+# --------------------------------------------------------------------------- G10
+def g10():
+    """Counts beyond 2^24 - 1 (RP_MAX_COUNT: what converts to fp32 exactly).  The reference has no limit
+    (detect_orfs.py:176-187, 278-280 work on Python ints); round 3 aborted the export on such a count."""
+    rng = np.random.default_rng(1010)
+    huge = lambda size=None: (1 << rng.integers(24, 31, size=size)) + rng.integers(-3, 1000, size=size)  # noqa: E731
+    vecs = []
+    for k in range(240):
+        length = int(rng.integers(6, 601)) if k % 5 == 0 else 3 * int(rng.integers(20, 201))
+        kind = k % 6
+        if kind == 0:  # ordinary Poisson profile with one saturated position
+            v = rng.poisson(0.5 * np.array([2.0, 0.5, 0.5])[np.arange(length) % 3]).astype(np.int64)
+            v[int(rng.integers(0, length))] = int(huge())
+        elif kind == 1:  # sparse, a few huge piles on one residue class (ties between frames)
+            v = np.zeros(length, np.int64)
+            r = int(rng.integers(0, 3))
+            at = r + 3 * rng.integers(0, max(1, (length - r + 2) // 3), size=int(rng.integers(1, 5)))
+            at = at[at < length]
+            v[at] = huge(at.size)
+        elif kind == 2:  # every codon huge: differences of huge numbers decide the direction
+            base = huge(length) if k % 12 == 2 else (1 << 30) - rng.integers(0, 5000, size=length)  # (every codon sum past 2^31)
+            v = (base + rng.integers(0, 50, size=length) * np.array([40, 1, 1])[np.arange(length) % 3]).astype(np.int64)
+        elif kind == 3:  # equal huge piles on residues 0, 1, 2: the unit vectors cancel
+            v = np.zeros(length, np.int64)
+            c = int(huge())
+            for r, j in enumerate(rng.choice(max(1, length // 3), size=3, replace=length // 3 < 3)):
+                if 3 * int(j) + r < length:
+                    v[3 * int(j) + r] = c
+        elif kind == 4:  # a codon whose sum passes 2^31 (three positions of ~2^30)
+            v = rng.poisson(1.0, size=length).astype(np.int64)
+            j = 3 * int(rng.integers(0, max(1, length // 3)))
+            v[j : j + 3] = (1 << 30) - np.array([1, 2, 3])[: v[j : j + 3].size]
+        else:  # flat huge codons (a = b = c) among ordinary ones
+            v = rng.poisson(0.3, size=length).astype(np.int64)
+            j = 3 * int(rng.integers(0, max(1, length // 3)))
+            v[j : j + 3] = int(huge())
+        vecs.append(v.tolist())
+    save_csr_set("g10_bigcounts.npz", vecs)
+    # end to end: the g6 index and alignments, with huge counts piled on positions of 16 ORFs
+    align = defaultdict(Counter)
+    with open(os.path.join(HERE, "g6_alignments.tsv")) as fh:
+        fh.readline()
+        for line in fh:
+            strand, chrom, pos, count = line.rstrip("\n").split("\t")
+            align[strand][(chrom, int(pos))] = int(count)
+    index_path = os.path.join(HERE, "g6_index.tsv")
+    rows = [ln.rstrip("\n").split("\t") for ln in open(index_path)][1:]
+    extra = []
+    for k in list(range(1, 220, 14)):
+        f = rows[k]
+        exons = sorted(tuple(int(x) for x in g.split("-")) for g in f[10].split(","))
+        tpos = [p for a, b in exons for p in range(a, b + 1)]
+        if len(tpos) < 6:
+            continue
+        n_piles = 1 + k % 3
+        for p in rng.choice(tpos, size=n_piles, replace=False):
+            c = int(huge())
+            if k % 4 == 1:
+                c = (1 << 30) - 1
+            align[f[8]][(f[7], int(p))] += c
+            extra.append((f[8], f[7], int(p), c))
+    with open(os.path.join(HERE, "g10_alignments.tsv"), "w") as fh:
+        fh.write("strand\tchrom\tpos\tcount\n")
+        for strand in sorted(align):
+            for (chrom, p), c in sorted(align[strand].items()):
+                fh.write(f"{strand}\t{chrom}\t{p}\t{c}\n")
+    for name, kw in (("default", dict()), ("report_all", dict(report_all=True)),
+                     ("strict", dict(report_all=True, phase_score_cutoff=0.3, min_valid_codons=8, min_reads_per_codon=1,
+                                     min_valid_codons_ratio=0.75, min_density_over_orf=1.0))):
+        with tempfile.TemporaryDirectory() as tmp:
+            prefix = os.path.join(tmp, "out")
+            export_orf_coverages(index_path, align, prefix, **kw)
+            text = open(prefix + "_translating_ORFs.tsv").read()
+        with open(os.path.join(HERE, f"g10_expected_{name}.tsv"), "w") as dst:
+            dst.write(text)
+        print(f"g10_expected_{name}.tsv: {text.count(chr(10)) - 1} rows, {len(extra)} piles added")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g10"]
     for name in which:
         globals()[name]()

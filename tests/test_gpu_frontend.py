@@ -80,8 +80,14 @@ def test_both_coverage_entry_points_agree():
     cov_old = torch.zeros(total, dtype=torch.int32, device=dev)
     _lib.check(_lib.load().rp_coverage_build_dev(
         dev.index, _ptr(d_group), _ptr(d_pos), _ptr(d_count), d_pos.numel(), _ptr(d_start), _ptr(d_lo), _ptr(d_hi), len(keys),
-        _ptr(cov_old), cov_old.numel(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        _ptr(cov_old), cov_old.numel(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), None))
     assert torch.equal(cov_rows, cov_old) and int(cov_rows.sum()) > 0
+    flag = ctypes.c_int32(7)  # the non-strict form: told, not failed
+    cov_old.zero_()
+    _lib.check(_lib.load().rp_coverage_build_dev(
+        dev.index, _ptr(d_group), _ptr(d_pos), _ptr(d_count), d_pos.numel(), _ptr(d_start), _ptr(d_lo), _ptr(d_hi), len(keys),
+        _ptr(cov_old), cov_old.numel(), ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream), ctypes.byref(flag)))
+    assert flag.value == 0 and torch.equal(cov_rows, cov_old)
 
 
 def test_coverage_build_rejects_counts_outside_the_contract():
@@ -97,6 +103,36 @@ def test_coverage_build_rejects_counts_outside_the_contract():
     with pytest.raises(RibophaseError) as e:
         al.build_coverage_device(cols, index)
     assert e.value.status == -7
+
+
+def test_coverage_build_reports_counts_beyond_fp32_instead_of_failing():
+    """Round-3 verdict, item 6: one saturated position must not kill the sample.  With ``big`` the build goes
+    through and names the positions; only what an int32 coverage cannot hold is an error."""
+    from ribotricer_amd import alignments as al
+    from ribotricer_amd._lib import RibophaseError
+    from ribotricer_amd.index import NativeIndex
+
+    index = NativeIndex.from_file(INDEX)
+    strand, chrom = index.group_keys[0]
+    s = al.STRANDS.index(strand)
+    lo = int(index.group_lo[0])
+    cols = al.MergedColumns(np.full(5, s, np.uint8), np.zeros(5, np.int32), np.array([lo + 5, lo + 5, lo + 5, lo + 9, lo + 11], np.int64),
+                            np.array([9_000_000, 9_000_000, 9_000_000, 1 << 30, 16777215], np.int64), [chrom])
+    big: dict = {}
+    coverage, base = al.build_coverage_device(cols, index, big=big)
+    start, _ = base[(strand, chrom)]
+    assert big["positions"].tolist() == [start + 5, start + 9]  # 27e6 and 2^30; 2^24 - 1 is still inside the contract
+    cov = coverage.cpu().numpy()
+    assert cov[start + 5] == 27_000_000 and cov[start + 9] == 1 << 30 and cov[start + 11] == 16777215
+    ordinary: dict = {}
+    al.build_coverage_device(al.MergedColumns(cols.strand[:1], cols.chrom[:1], cols.pos[:1], np.array([7], np.int64), [chrom]), index, big=ordinary)
+    assert ordinary["positions"].size == 0
+    for counts in ([1 << 31], [(1 << 31) - 1, 1], [-1]):  # not representable in the int32 coverage
+        n = len(counts)
+        bad = al.MergedColumns(np.full(n, s, np.uint8), np.zeros(n, np.int32), np.full(n, lo + 5, np.int64), np.array(counts, np.int64), [chrom])
+        with pytest.raises(RibophaseError) as e:
+            al.build_coverage_device(bad, index, big={})
+        assert e.value.status == -7
 
 
 def test_coverage_build_ignores_rows_the_reference_never_looks_up():

@@ -403,6 +403,42 @@ def test_csr_shards_keep_their_plans_across_samples(eng):
     shards.release()
 
 
+@pytest.mark.parametrize("algo", ["wave", "tile"])
+def test_counts_beyond_fp32_are_finished_in_float64(eng, g2, g10, algo):
+    """G10 (outputs of the reference on profiles holding counts 2^24 .. 2^30) mixed into ordinary ORFs: the ORFs that
+    hold such a count -- and only they -- are finished through the float64 kernel + int64 sums
+    (engine.fix_big_counts_csr, RP_FLAG_BIGCOUNT); phase within 1e-9 of the reference, valid_codons identical on
+    every one (exact ties replayed), read_count / codon minimum exact.  Reference: detect_orfs.py:278-280."""
+    from oracle import c_oracle
+    from ribotricer_amd import _lib
+    from ribotricer_amd.engine import make_filter, score_sharded
+
+    n2 = 600
+    c2, o2 = g2["counts"][: g2["offsets"][n2]], g2["offsets"][: n2 + 1]
+    counts = np.concatenate([c2, g10["counts"], c2])
+    offsets = np.concatenate([o2, o2[-1] + g10["offsets"][1:], o2[-1] + g10["offsets"][-1] + o2[1:]])
+    want_phase = np.concatenate([g2["phase"][:n2], g10["phase"], g2["phase"][:n2]])
+    want_valid = np.concatenate([g2["valid"][:n2], g10["valid"], g2["valid"][:n2]])
+    n10 = g10["offsets"].size - 1
+    th = make_filter(phase_score_cutoff=0.3, min_valid_codons=3, min_reads_per_codon=0, min_valid_codons_ratio=0.05, min_density_over_orf=0.1)
+    o = c_oracle.phase_score_csr(counts, offsets)
+    for res in (eng.score_host(counts, offsets, thresholds=th, algo=algo),
+                score_sharded(counts, offsets, [0, 0, 0], thresholds=th, algo=algo)):
+        big = (res["flags"] & _lib.FLAG_BIGCOUNT) != 0
+        assert big[n2 : n2 + n10].all() and big.sum() == n10  # every G10 profile holds one; no other ORF does
+        assert np.abs(res["phase"][big] - want_phase[big]).max() <= 1e-9 and np.abs(res["phase"] - want_phase).max() <= 1e-6
+        assert np.array_equal(res["valid"], want_valid)
+        assert np.array_equal(res["read_count"], o.read_count) and np.array_equal(res["min_codon_cov"], o.min_codon_cov)
+        assert res["read_count"].max() > 2**32 and (res["min_codon_cov"] == 2**31 - 2).any()
+        from helpers import reference_status
+
+        prof_min = np.array([np.pad(counts[offsets[i] : offsets[i + 1]].astype(np.int64), (0, -int(offsets[i + 1] - offsets[i]) % 3)).reshape(-1, 3).sum(1).min()
+                             if offsets[i + 1] > offsets[i] else 2**31 - 1 for i in range(offsets.size - 1)])
+        want_status = reference_status(res["phase"], res["valid"], o.read_count, prof_min, np.diff(offsets), cutoff=0.3, min_valid=3,
+                                       min_reads=0, min_ratio=0.05, min_density=0.1)
+        assert np.array_equal(res["status"], want_status)
+
+
 def test_validate_rejects_bad_input(eng):
     from ribotricer_amd._lib import RibophaseError
 

@@ -18,7 +18,7 @@ def _csr_of(vectors, dtype):
     return flat, off
 
 
-@pytest.mark.parametrize("name", ["g2", "g3", "g4", "g8"])
+@pytest.mark.parametrize("name", ["g2", "g3", "g4", "g8", "g10"])
 def test_int_profiles_carry_the_references_bits(request, name):
     g = request.getfixturevalue(name)
     phase, valid = _lib.tie_replay_host(g["counts"], g["offsets"])
@@ -62,7 +62,7 @@ def test_bad_arguments():
     assert phase.size == 0 and valid.size == 0
 
 
-@pytest.mark.parametrize("name", ["g2", "g3", "g4", "g8"])
+@pytest.mark.parametrize("name", ["g2", "g3", "g4", "g8", "g10"])
 def test_host_batch_entry_point_equals_the_reference(request, name):
     """rp_phase_score_csr_host: phase and valid_codons are the reference's on EVERY ORF of
     the golden sets (bitwise), the integer results equal the C oracle's, status equals the predicate."""

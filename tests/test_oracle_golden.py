@@ -116,7 +116,7 @@ def test_literal_restatement_bit_exact_sample(g2, g3, g5):
 
 
 # ------------------------------------------------------------------ the scipy replay (oracle/scipy_replay.c)
-@pytest.mark.parametrize("name", ["g2", "g3", "g4"])
+@pytest.mark.parametrize("name", ["g2", "g3", "g4", "g10"])
 def test_scipy_replay_is_the_reference_bit_for_bit(request, name):
     """The C replay of the reference's numpy/scipy arithmetic reproduces the reference's
     phase score (every bit), valid_codons and per-frame coherence on EVERY golden ORF, the
@@ -135,3 +135,23 @@ def test_scipy_replay_known_answers(g1):
         c = np.array(row["input"], np.int32)
         r = c_oracle.replay_csr(c, np.array([0, c.size], np.int64))
         assert r.phase[0] == row["phase"] and r.valid[0] == row["valid"], row["input"]
+
+
+def test_c_oracle_counts_beyond_fp32(g10):
+    """G10: counts 2^24 .. 2^30 (the reference has no limit).  The float64 closed form stays within 1e-9 of the
+    reference, valid_codons equal off the exact ties, the integer sums are int64 and the int32 codon minimum
+    saturates below the 'empty' sentinel when a codon sum passes int32."""
+    r = c_oracle.phase_score_csr(g10["counts"], g10["offsets"])
+    assert np.abs(r.phase - g10["phase"]).max() <= 1e-9
+    tie = (r.flags & 1) != 0
+    assert np.array_equal(r.valid[~tie], g10["valid"][~tie]) and 0 < tie.sum() < tie.size
+    counts, offsets = g10["counts"].astype(np.int64), g10["offsets"]
+    assert int(counts.max()) >= 1 << 30 and int(counts.max()) > 16777215
+    sat = 0
+    for i in range(offsets.size - 1):
+        prof = counts[offsets[i] : offsets[i + 1]]
+        assert r.read_count[i] == prof.sum()
+        mn = np.pad(prof, (0, -prof.size % 3)).reshape(-1, 3).sum(axis=1).min()
+        assert r.min_codon_cov[i] == min(mn, 2**31 - 2)
+        sat += mn > 2**31 - 2
+    assert sat > 0  # (kind 2 of the generator: every codon of the ORF past 2^31)
