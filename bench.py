@@ -83,7 +83,9 @@ def parse_args():
     ap.add_argument("--cpu-cores", type=int, default=0, help="processes for the CPU baseline (default: the usable cores, at most 64)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of head / middle / tail slices (N = 1) and the concat == whole check (N > 1)")
     ap.add_argument("--no-tune-workspace", action="store_true", help="keep the record workspace where the first allocation put it (engine.tune_workspace off)")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the two-stream many-samples section (N = 1)")
     ap.add_argument("--no-fused", action="store_true", help="skip the fused gather + score section (N = 1)")
+    ap.add_argument("--no-fused-nested", action="store_true", help="skip the nested-index fused section (N = 1)")
     ap.add_argument("--fused-steps", type=int, default=10)
     ap.add_argument("--seed", type=int, default=20260213)
     return ap.parse_args()
@@ -216,20 +218,30 @@ def verify_slices(out, counts, offsets, n_orfs, profiles_of=None):
     return rep
 
 
-def fused_section(args, eng, dev, thresholds, n_set, csr_out):
+def fused_section(args, eng, dev, thresholds, n_set, layout="exons"):
     """What `export_orf_coverages` runs by default: gather + score FUSED (rp_phase_score_coverage_dev,
-    k_tile_score<true>) over a candidate index of the same length law laid out as exons over a dense
-    coverage array (synth_exon_layout: 1-4 exons per ORF, introns, half of the ORFs on '-')."""
+    k_tile_score<true>) over a candidate index laid out as exons over a dense coverage array.
+    layout "exons":  the run's own length law (synth_exon_layout: 1-4 exons per ORF, introns < 300 nt, half of the
+                     ORFs on '-', ORFs one after the other);
+    layout "nested": the law of scripts/gen_big_index.cpp (synth_nested_layout: transcripts with nested candidate ORFs
+                     that share coverage, 65 % of them 60-150 nt, ~2 exons per ORF, consecutive transcripts on
+                     different chromosomes -- the pieces of one tile lie gigabytes apart)."""
+    import statistics
     import time
 
     import numpy as np
     import torch
 
-    from ribotricer_amd.gather import GatherPlan, IntervalTable
-    from ribotricer_amd.synth import orf_lengths, profiles_from_coverage, synth_coverage_device, synth_exon_layout
+    from ribotricer_amd.gather import GatherPlan, IntervalTable, gather_profiles_device, select_orfs
+    from ribotricer_amd.synth import orf_lengths, profiles_from_coverage, synth_coverage_device, synth_exon_layout, synth_nested_layout
 
-    lengths = orf_lengths(n_set, args.seed, args.cfg)
-    iv_start, iv_len, orf_iv, reverse, offsets, coverage_len = synth_exon_layout(lengths, args.seed)
+    if layout == "nested":
+        iv_start, iv_len, orf_iv, reverse, offsets, coverage_len = synth_nested_layout(n_set, args.seed)
+        law = "nested candidate ORFs of the gen_big_index law (65 % 60-150 nt, transcripts on 48 chromosome / strand groups)"
+    else:
+        lengths = orf_lengths(n_set, args.seed, args.cfg)
+        iv_start, iv_len, orf_iv, reverse, offsets, coverage_len = synth_exon_layout(lengths, args.seed)
+        law = f"the {args.cfg} length law (introns < 300 nt, half of the ORFs on the '-' strand)"
     table = IntervalTable(iv_start, iv_len, orf_iv, reverse, offsets)
     cov = synth_coverage_device(coverage_len, args.seed, device=dev)
     torch.cuda.synchronize(dev)
@@ -241,14 +253,12 @@ def fused_section(args, eng, dev, thresholds, n_set, csr_out):
     if not args.no_tune_workspace and int(offsets[-1]) >= (64 << 20):  # (as for the CSR path: once per index, not timed)
         placement = eng.tune_workspace(cov, thresholds=thresholds, gather_plan=gplan)
         if placement.get("spacers"):
-            time.sleep(1.0)
+            time.sleep(min(3.0, 0.5 * placement["spacers"]))
     for _ in range(5):
         out = eng.score_coverage(cov, gplan, thresholds=thresholds, reuse_outputs=True)
     tm: list = []
     for _ in range(max(3, args.fused_steps)):
         out = eng.score_coverage(cov, gplan, thresholds=thresholds, reuse_outputs=True, timings=tm)
-    import statistics
-
     k_main = statistics.median(t[1] for t in tm)  # (medians: this section's clocks follow whatever ran before it)
     k_fin = statistics.median(t[2] for t in tm)
     k_all = statistics.median(t[3] for t in tm)
@@ -256,29 +266,34 @@ def fused_section(args, eng, dev, thresholds, n_set, csr_out):
     total_nt = int(offsets[-1])
     algo_bytes = 4 * total_nt + 8 * (n + 1) + 24 * n
     rep = {
-        "workload": f"{n} ORFs / {iv_len.size} exons of the {args.cfg} length law over a dense coverage of {coverage_len} positions "
-                    f"({total_nt} nt of profiles; introns < 300 nt, half of the ORFs on the '-' strand)",
+        "workload": f"{n} ORFs / {iv_len.size} exons over a dense coverage of {coverage_len} positions ({total_nt} nt of profiles): {law}",
         "kernel": "rp::k_tile_score<true> (tile staged from the coverage through the gather plan)",
         "kernel_ms": k_main, "finish_ms": k_fin, "step_device_ms": k_all,
         "achieved": algo_bytes / (k_main * 1e-3) / 1e9, "frac": algo_bytes / (k_main * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "step_frac": algo_bytes / (k_all * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "value": n / (k_all * 1e-3), "unit": "ORFs/s",
-        "gather_plan_build_ms": gplan_ms,
+        "gather_plan_build_ms": gplan_ms, "gather_plan": gplan.stats(),
         "workspace_placement": placement if placement is not None else "first allocation (engine.tune_workspace not run)",
         "algorithmic_bytes_per_launch": algo_bytes,
         "translating": int(out.status.sum()),
     }
-    traffic, traffic_src = measured_traffic(args.cfg, n, "tile", args.seed, kernel="rp::k_tile_score<true>")
+    traffic, traffic_src = measured_traffic(args.cfg if layout == "exons" else "nested", n, "tile", args.seed, kernel="rp::k_tile_score<true>")
     rep["traffic"], rep["traffic_source"] = traffic, traffic_src
     if not args.no_verify:
-        def profiles_of(lo, hi):
-            k0, k1 = int(orf_iv[lo]), int(orf_iv[hi])
-            w_lo = int(iv_start[k0:k1].min())
-            w_hi = int((iv_start[k0:k1] + iv_len[k0:k1]).max())
-            return profiles_from_coverage(cov[w_lo:w_hi].cpu().numpy(), w_lo, iv_start, iv_len, orf_iv, reverse, lo, hi)
+        if layout == "nested":  # neighbouring ORFs lie gigabytes apart: fetch the slices with the per-ORF gather kernel (a code path of its own)
+            def profiles_of(lo, hi):
+                c_dev, o_dev = gather_profiles_device(cov, select_orfs(table, np.arange(lo, hi, dtype=np.int64)), dev)
+                return c_dev.cpu().numpy(), o_dev.cpu().numpy()
+        else:
+            def profiles_of(lo, hi):
+                k0, k1 = int(orf_iv[lo]), int(orf_iv[hi])
+                w_lo = int(iv_start[k0:k1].min())
+                w_hi = int((iv_start[k0:k1] + iv_len[k0:k1]).max())
+                return profiles_from_coverage(cov[w_lo:w_hi].cpu().numpy(), w_lo, iv_start, iv_len, orf_iv, reverse, lo, hi)
 
         rep["verify"] = verify_slices(out, None, gplan.offsets, n, profiles_of)
     del cov, gplan
+    torch.cuda.empty_cache()
     return rep
 
 
@@ -483,7 +498,7 @@ def main():
         first_alloc_ms = e0.elapsed_time(e1) / n_first
         placement = eng.tune_workspace(counts, offsets, thresholds=thresholds)
         if placement.get("spacers"):
-            time.sleep(1.0)  # the driver wipes the memory handed back in the background (1-4 % off the next second's kernels)
+            time.sleep(min(3.0, 0.5 * placement["spacers"]))  # the driver wipes the memory handed back in the background (1-4 % off the kernels meanwhile)
 
     def barrier():
         if dist is not None:
@@ -536,6 +551,49 @@ def main():
         single_ms = e0.elapsed_time(e1) / n_single
         out = step()  # (the outputs checked below come from the planned path the headline times)
         torch.cuda.synchronize(dev)
+    # Many samples against one index, PIPELINED over two streams (round-3 verdict, item 4): sample k on stream k % 2,
+    # each stream with a record workspace and outputs of its own (the engine keeps both per stream), so the per-ORF
+    # finish pass of one sample -- latency-bound, 9 % of a step -- runs beside the scoring kernel of the next.  Same
+    # work per step as the headline (every sample is scored and finished, nothing is skipped); reported BESIDE
+    # `value`, never instead of it.
+    pipelined = None
+    if world == 1 and plan is not None and not args.no_pipelined and total_nt >= (64 << 20):
+        lanes = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        placements = []
+        for st in lanes:
+            st.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(st):
+                for _ in range(3):
+                    step()
+                if not args.no_tune_workspace:  # each stream's workspace placed like the headline's
+                    placements.append(eng.tune_workspace(counts, offsets, thresholds=thresholds)["step_ms"])
+        torch.cuda.synchronize(dev)
+        if placements:
+            time.sleep(1.0)
+        n_pipe = max(4, args.steps // 2 * 2)
+        for k in range(4):
+            with torch.cuda.stream(lanes[k % 2]):
+                step()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0p = time.perf_counter()
+        e0.record(lanes[0])
+        lanes[1].wait_event(e0)
+        for k in range(n_pipe):
+            with torch.cuda.stream(lanes[k % 2]):
+                out_p = step()
+        lanes[0].wait_stream(lanes[1])
+        e1.record(lanes[0])
+        torch.cuda.synchronize(dev)
+        wall_p = time.perf_counter() - t0p
+        ms_p = e0.elapsed_time(e1) / n_pipe
+        same = all(bool(torch.equal(getattr(out_p, k_), getattr(out, k_))) for k_ in ("phase", "valid", "read_count", "min_codon_cov", "status"))
+        pipelined = {"ms_per_step": ms_p, "wall_ms_per_step": 1e3 * wall_p / n_pipe, "steps": n_pipe, "streams": 2,
+                     "results_equal_headline": same, "workspace_search_step_ms": placements,
+                     "what": "sample k on stream k % 2, a record workspace and outputs per stream: finish(k) beside score(k + 1)"}
+        for st in lanes:
+            eng.release_stream(st)
+        del lanes, out_p
     rank_bytes = 4 * total_nt + 8 * (n_orfs + 1) + 24 * n_orfs  # SURVEY 8(d), this rank's slice
     per_rank = {"rank": rank, "device": local_dev, "orfs": n_orfs, "nt": total_nt, "kernel_ms": k_main, "finish_ms": k_fin,
                 "step_device_ms": dev_ms_per_step, "algorithmic_bytes_per_launch": rank_bytes,
@@ -585,7 +643,7 @@ def main():
             print(json.dumps({"error": "sharded results differ from the one-GPU result", "verify": verify}), flush=True)
             sys.exit(2)
 
-    fused = None
+    fused = fused_nested = None
     if rank == 0 and world == 1:
         if not args.no_verify and n_orfs > 0:
             concat_check = verify  # (RP_BENCH_FORCE_DIST: the N-rank check ran with one rank)
@@ -595,10 +653,12 @@ def main():
             verify["read_count_checksum_ok"] = bool(int(out.read_count.sum()) == int(counts.sum(dtype=torch.int64)))
             verify["ok"] = verify["ok"] and verify["read_count_checksum_ok"]
         if not args.no_fused and resolved == "tile" and n_orfs > 0:
-            fused = fused_section(args, eng, dev, thresholds, n_set, out)
-        bad = (verify is not None and not verify["ok"]) or (fused is not None and "verify" in fused and not fused["verify"]["ok"])
+            fused = fused_section(args, eng, dev, thresholds, n_set)
+            if not args.no_fused_nested:
+                fused_nested = fused_section(args, eng, dev, thresholds, n_set, layout="nested")
+        bad = (verify is not None and not verify["ok"]) or any(f is not None and "verify" in f and not f["verify"]["ok"] for f in (fused, fused_nested))
         if bad:
-            print(json.dumps({"error": "results differ from the oracle", "verify": verify, "fused": fused}), flush=True)
+            print(json.dumps({"error": "results differ from the oracle", "verify": verify, "fused": fused, "fused_nested": fused_nested}), flush=True)
             sys.exit(2)
 
     stream_read = None
@@ -708,6 +768,9 @@ def main():
             result["value_first_allocation"] = (n_job / (first_alloc_ms * 1e-3)) if world == 1 else None
             result["first_allocation"] = {"ms_per_step": first_alloc_ms, "steps": max(3, min(args.steps, 20)),
                                           "what": "the same step before engine.tune_workspace: the record workspace where the first allocation put it (rank 0's slice)"}
+        if pipelined is not None:
+            result["value_pipelined"] = n_job / (pipelined["ms_per_step"] * 1e-3)
+            result["pipelined"] = pipelined
         if single_ms is not None:
             result["value_single_sample"] = n_job / (single_ms * 1e-3) if world == 1 else None
             result["single_sample"] = {"ms_per_step": single_ms, "what": "tile index + segment descriptors + head rows rebuilt inside every step "
@@ -716,6 +779,8 @@ def main():
             result["verify"] = verify
         if fused is not None:
             result["fused"] = fused
+        if fused_nested is not None:
+            result["fused_nested"] = fused_nested
         if pool is not None:
             per_core = args.cpu_sample
             n_s = min(max(per_core * pool.n, 200_000), n_orfs)

@@ -243,7 +243,10 @@ class PhaseScoreEngine:
                 torch.cuda.empty_cache()
             while len(candidates) <= tries and not (len(times) > 1 and times[-1] <= (1.0 - spread) * max(times)):
                 try:
-                    spacers.append(torch.empty(int(spacer_gib * (1 << 30)), dtype=torch.uint8, device=dev))
+                    # (three candidates without a gain: longer strides -- a 16 GB counts array can span two classes,
+                    # and the third one may start 40 GiB further on)
+                    stride = spacer_gib * (2.0 if len(candidates) > 3 else 1.0)
+                    spacers.append(torch.empty(int(stride * (1 << 30)), dtype=torch.uint8, device=dev))
                     cand = torch.empty(need, dtype=torch.uint8, device=dev)
                 except torch.cuda.OutOfMemoryError:
                     oom = True
@@ -256,6 +259,8 @@ class PhaseScoreEngine:
             lib.rp_measurement_tag(was)
             candidates = candidates[: len(times)] if times else candidates[:1]
             best = min(range(len(times)), key=times.__getitem__) if times else 0
+            if times and times[best] > 0.99 * times[0]:
+                best = 0  # nothing to gain on this box: stay where the first allocation put it (no move for noise)
             if candidates:  # (an exception before the first timing leaves the workspace as it was)
                 self._workspace[stream_key] = candidates[best]
             n_spacers = len(spacers)

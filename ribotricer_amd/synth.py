@@ -179,6 +179,68 @@ def synth_exon_layout(lengths: np.ndarray, seed: int, max_intron: int = 300, max
     return iv_start.astype(np.int64), iv_len.astype(np.int32), orf_iv, reverse, offsets, coverage_len
 
 
+def synth_nested_layout(n_orfs: int, seed: int, n_groups: int = 48):
+    """The NESTED candidate-index law of scripts/gen_big_index.cpp without the text round trip: transcripts of 1-8
+    exons (60-420 nt, introns 80-3000) with 1-10 candidate ORFs each -- nested sub-ranges of the transcript, as
+    prepare-orfs emits them, so the ORFs of a transcript share coverage --, 65 % of the ORFs 60-150 nt, the others to
+    1 800 nt; consecutive transcripts sit on different (chromosome, strand) groups (``n_groups`` of them, laid one
+    after the other in the dense coverage: gigabytes apart).  Returns the fields of ``gather.IntervalTable`` plus the
+    coverage length, like :func:`synth_exon_layout`.  Vectorised numpy, ~1.5 s per million ORFs."""
+    rng = np.random.default_rng(seed + 31)
+    n_tx = max(1, int(n_orfs / 5.3) + 64)  # (1-10 ORFs per transcript, a few dropped as too short: ~5.4 kept on average)
+    while True:
+        n_ex = rng.integers(1, 9, size=n_tx)
+        n_here = rng.integers(1, 11, size=n_tx)
+        if int(n_here.sum()) >= int(n_orfs * 1.02) + 16:
+            break
+        n_tx = int(n_tx * 1.1) + 16
+    ex_tx = np.repeat(np.arange(n_tx), n_ex)
+    ex_first = np.zeros(n_tx + 1, np.int64)
+    np.cumsum(n_ex, out=ex_first[1:])
+    ex_len = rng.integers(60, 421, size=ex_tx.size).astype(np.int64)
+    intron = rng.integers(80, 3001, size=ex_tx.size).astype(np.int64)
+    tlen = np.add.reduceat(ex_len, ex_first[:-1])
+    # transcript coordinates, all transcripts in ONE ascending space: exon k covers [e_t0[k], e_t0[k] + ex_len[k])
+    e_t0 = np.cumsum(ex_len) - ex_len
+    tx_t0 = e_t0[ex_first[:-1]]
+    # genomic (coverage) coordinates: transcript t lies in group t % n_groups, behind the group's earlier transcripts
+    span = np.add.reduceat(ex_len + intron, ex_first[:-1]) + rng.integers(200, 5001, size=n_tx)
+    group = np.arange(n_tx) % n_groups
+    order = np.argsort(group, kind="stable")  # group-major order of the transcripts = their order in the coverage
+    start_in_cov = np.empty(n_tx, np.int64)
+    start_in_cov[order] = np.cumsum(span[order]) - span[order]
+    within = np.cumsum(ex_len + intron) - (ex_len + intron)  # exon start relative to ... (made per transcript below)
+    within -= within[ex_first[:-1]][ex_tx]
+    e_g0 = start_in_cov[ex_tx] + within + 16
+    coverage_len = int(span.sum()) + 64
+    # candidate ORFs: [a, a + len) in the transcript's own coordinates
+    orf_tx = np.repeat(np.arange(n_tx), n_here)
+    short = rng.random(orf_tx.size) < 0.65
+    length = 3 * np.where(short, rng.integers(20, 51, size=orf_tx.size), rng.integers(51, 601, size=orf_tx.size)).astype(np.int64)
+    length = np.minimum(length, tlen[orf_tx] // 3 * 3)
+    keep = length >= 60
+    orf_tx, length = orf_tx[keep][:n_orfs], length[keep][:n_orfs]
+    if orf_tx.size < n_orfs:
+        raise RuntimeError("synth_nested_layout: too few ORFs drawn")
+    a = np.floor(rng.random(n_orfs) * (tlen[orf_tx] - length + 1)).astype(np.int64)
+    t_a = tx_t0[orf_tx] + a
+    t_b = t_a + length
+    k0 = np.searchsorted(e_t0, t_a, side="right") - 1
+    k1 = np.searchsorted(e_t0, t_b - 1, side="right") - 1
+    n_iv = k1 - k0 + 1
+    orf_iv = np.zeros(n_orfs + 1, np.int64)
+    np.cumsum(n_iv, out=orf_iv[1:])
+    iv_orf = np.repeat(np.arange(n_orfs), n_iv)
+    iv_k = k0[iv_orf] + (np.arange(int(orf_iv[-1])) - orf_iv[iv_orf])
+    lo = np.maximum(t_a[iv_orf], e_t0[iv_k])
+    hi = np.minimum(t_b[iv_orf], e_t0[iv_k] + ex_len[iv_k])
+    iv_start = e_g0[iv_k] + (lo - e_t0[iv_k])
+    iv_len = (hi - lo).astype(np.int32)
+    reverse = ((orf_tx // (n_groups // 2)) % 2).astype(np.uint8) if n_groups >= 2 else np.zeros(n_orfs, np.uint8)
+    offsets = offsets_from_lengths(length)
+    return iv_start.astype(np.int64), iv_len, orf_iv, reverse, offsets, coverage_len
+
+
 def synth_coverage_device(coverage_len: int, seed: int, device="cuda"):
     """Dense int32 coverage drawn on the device: blocks of ``COVERAGE_BLOCK`` positions share a rate
     from ``LAMBDAS`` (so sparse and dense stretches -- exact frame ties and clear winners -- both

@@ -48,6 +48,9 @@ def test_bench_line_has_the_contract_fields():
     f = d["fused"]
     assert f["kernel_ms"] > 0 and 0 < f["frac"] < 1 and f["verify"]["ok"] is True and f["verify"]["orfs_checked"] >= 60000
     assert d["value_single_sample"] > 0 and d["single_sample"]["ms_per_step"] > 0  # (a 60 000-ORF set is launch-bound: no ordering claim)
+    fn = d["fused_nested"]  # the nested-index law (transcripts on different chromosomes: pieces of a tile gigabytes apart)
+    assert fn["kernel_ms"] > 0 and fn["verify"]["ok"] is True and fn["verify"]["orfs_checked"] >= 60000
+    assert fn["gather_plan"]["slow_tiles"] <= 0.01 * fn["gather_plan"]["tiles"] + 1 and "nested" in fn["workload"]
 
 
 def test_two_ranks_shard_one_set_and_concat_equals_whole():
@@ -126,3 +129,17 @@ def test_one_rank_has_the_same_value_definition_with_and_without_a_process_group
         assert d["roofline"]["rank"] == 0 and d["roofline"]["kernel_ms"] == d["per_rank"][0]["kernel_ms"]
     assert plain["config"]["control_backend"] is None and forced["config"]["control_backend"] == "nccl"
     assert forced["verify"]["concat_equals_whole"]["ok"] is True and "concat_equals_whole" not in plain["verify"]
+
+
+def test_pipelined_and_first_allocation_values_are_reported_beside_value():
+    """A set large enough for the placement search and the two-stream section: `value_first_allocation` (the step before
+    engine.tune_workspace) and `value_pipelined` (finish(k) beside score(k + 1), a workspace per stream) are extra
+    fields; `value` keeps its definition, and the pipelined results equal the headline's bit for bit."""
+    d = _bare_bench(1, 600000, extra=("--cpu-sample", "0", "--no-fused"))
+    assert d["value"] == pytest.approx(600000 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3), rel=1e-9)
+    assert d["value_first_allocation"] > 0 and d["first_allocation"]["ms_per_step"] > 0
+    wp = d["config"]["workspace_placement"]
+    assert wp["released_to_driver"] is True and wp["spacers"] == len(wp["step_ms"]) - 1
+    p = d["pipelined"]
+    assert d["value_pipelined"] == pytest.approx(600000 / (p["ms_per_step"] * 1e-3), rel=1e-9)
+    assert p["results_equal_headline"] is True and p["streams"] == 2 and d["verify"]["ok"] is True

@@ -510,9 +510,10 @@ def test_tune_workspace_changes_placement_not_results():
     after = eng.score(counts, offsets, thresholds=th, algo="tile")
     torch.cuda.synchronize()
     assert 1 <= len(rep["step_ms"]) <= 4 and 0 <= rep["chosen"] < len(rep["step_ms"])
-    assert rep["step_ms"][rep["chosen"]] == min(rep["step_ms"]) and rep["spacers"] == len(rep["step_ms"]) - 1
+    assert rep["step_ms"][rep["chosen"]] == min(rep["step_ms"]) or rep["chosen"] == 0  # (the first stays unless another gains > 1 %)
+    assert rep["spacers"] == len(rep["step_ms"]) - 1
     ws = next(iter(eng._workspace.values()))
-    assert ws.numel() == rep["workspace_bytes"]  # a candidate of the batch's own size, not a spacer-sized chunk
+    assert ws.numel() >= rep["workspace_bytes"] and ws.numel() < (64 << 20) + rep["workspace_bytes"]  # the batch's own size, not a spacer-sized chunk
     empty = PhaseScoreEngine("cuda:0").tune_workspace(counts[:0], offsets[:1], thresholds=th)  # (round-3 advisor: KeyError / UnboundLocalError)
     assert empty["chosen"] is None and empty["skipped"]
     for k in ("phase", "valid", "read_count", "min_codon_cov", "flags", "status"):
