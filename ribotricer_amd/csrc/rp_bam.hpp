@@ -24,6 +24,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -372,6 +374,8 @@ inline int split_bam(const char *path, int protocol, const int32_t *read_lengths
     std::vector<uint64_t> keys;
     std::vector<unsigned char> rec;
     std::vector<char> length_seen(1024, 0);
+    std::map<int64_t, std::map<uint64_t, int64_t>> long_reads;  // aligned length >= 1024 -> key (strand | chrom | pos) -> count
+    std::set<int64_t> long_seen;
     for (;;) {
         rc = rd.read(w, 4, &eof);
         if (rc != kOk) return fail(rc, "corrupt BGZF block");
@@ -446,7 +450,15 @@ inline int split_bam(const char *path, int protocol, const int32_t *read_lengths
             minus = !reverse_map;
             five = reverse_map ? first : last;
         }
-        if (aligned >= 1024 || five < 0 || five + 1 >= (1LL << 32)) continue;  // outside the key's fields (not a Ribo-seq read)
+        if (five < 0 || five + 1 >= (1LL << 32) || aligned > INT32_MAX) continue;  // (pos0 is an int32: cannot happen on a well-formed record)
+        if (aligned >= 1024) {
+            // longer than the packed key's 10-bit length field (never a Ribo-seq footprint, but the reference counts
+            // every read: bam.py:99-131): an ordered map, merged behind the packed keys below
+            if (long_seen.insert(aligned).second) out.length_order.push_back((int32_t)aligned);
+            long_reads[aligned][((uint64_t)(minus ? 1 : 0) << 53) | ((uint64_t)ref_id << 32) | (uint64_t)(five + 1)] += 1;
+            out.valid += 1;
+            continue;
+        }
         if (!length_seen[aligned]) {
             length_seen[aligned] = 1;
             out.length_order.push_back((int32_t)aligned);
@@ -467,6 +479,14 @@ inline int split_bam(const char *path, int protocol, const int32_t *read_lengths
         out.count.push_back((int64_t)(j - i));
         i = j;
     }
+    for (const auto &by_length : long_reads)  // ascending length, then (strand, chrom, pos): the packed keys' order continued
+        for (const auto &kv : by_length.second) {
+            out.length.push_back((int32_t)by_length.first);
+            out.strand.push_back((uint8_t)((kv.first >> 53) & 1));
+            out.chrom.push_back((int32_t)((kv.first >> 32) & ((1u << 21) - 1)));
+            out.pos.push_back((int64_t)(kv.first & 0xffffffffu));
+            out.count.push_back(kv.second);
+        }
     return kOk;
 }
 

@@ -115,17 +115,27 @@ def reg2bin(beg, end):
     return 0
 
 
-def record(read):
+def record(read, refs=None):
+    refs = REFS if refs is None else refs
     name, flag, ref, pos1, mapq, cigar_text, seq, tags = read
+    real_cigar = None
+    if isinstance(cigar_text, tuple):  # (placeholder, real CIGAR): > 65 535 operations, section 4.2.2
+        cigar_text, real_cigar = cigar_text
     cigar = parse_cigar(cigar_text)
+    if real_cigar is not None:
+        real = parse_cigar(real_cigar)
+        assert len(real) > 65535
+        tags = [("CG", "B", ("I", [(n << 4) | op for op, n in real]))] + list(tags)
     query_len = sum(n for op, n in cigar if CIGAR_OPS[op] in "MIS=X")
+    if real_cigar is not None:
+        query_len = sum(n for op, n in parse_cigar(real_cigar) if CIGAR_OPS[op] in "MIS=X")
     if seq is None:
-        seq = ("ACGT" * 64)[:query_len]
-    if cigar:
+        seq = ("ACGT" * (query_len // 4 + 1))[:query_len]
+    if cigar and real_cigar is None:
         assert len(seq) == query_len, name
-    ref_id = -1 if ref is None else [r[0] for r in REFS].index(ref)
+    ref_id = -1 if ref is None else [r[0] for r in refs].index(ref)
     pos0 = pos1 - 1
-    ref_len = sum(n for op, n in cigar if CIGAR_OPS[op] in "MDN=X")
+    ref_len = sum(n for op, n in (parse_cigar(real_cigar) if real_cigar is not None else cigar) if CIGAR_OPS[op] in "MDN=X")
     end0 = pos0 + (ref_len if ref_len else 1)
     bin_ = reg2bin(pos0, end0) if pos0 >= 0 else 4680  # reg2bin(-1, 0), the value for unplaced reads
     read_name = name.encode() + b"\0"
@@ -150,21 +160,81 @@ def record(read):
     body += b"\xff" * len(seq)                            # qual: 0xFF = not stored ('*')
     for tag, ty, val in tags:
         body += tag.encode() + ty.encode()
-        if ty == "Z":
+        fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "f": "<f"}
+        if ty in "ZH":  # NUL-terminated text (H: hex digits)
             body += val.encode() + b"\0"
         elif ty == "A":
             body += val.encode()
+        elif ty == "B":  # subtype, count, elements (section 4.2.4)
+            sub, items = val
+            body += sub.encode() + struct.pack("<I", len(items)) + b"".join(struct.pack(fmt[sub], x) for x in items)
         else:
-            body += struct.pack({"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I"}[ty], val)
+            body += struct.pack(fmt[ty], val)
     return struct.pack("<I", len(body)) + body            # block_size
 
 
-def bam_stream():
-    text = "@HD\tVN:1.6\tSO:unsorted\n" + "".join(f"@SQ\tSN:{n}\tLN:{ln}\n" for n, ln in REFS)
-    out = b"BAM\1" + struct.pack("<I", len(text)) + text.encode() + struct.pack("<I", len(REFS))
-    for n, ln in REFS:
+def bam_header(refs=None):
+    refs = REFS if refs is None else refs
+    text = "@HD\tVN:1.6\tSO:unsorted\n" + "".join(f"@SQ\tSN:{n}\tLN:{ln}\n" for n, ln in refs)
+    out = b"BAM\1" + struct.pack("<I", len(text)) + text.encode() + struct.pack("<I", len(refs))
+    for n, ln in refs:
         out += struct.pack("<I", len(n) + 1) + n.encode() + b"\0" + struct.pack("<I", ln)
-    return out + b"".join(record(r) for r in READS)
+    return out
+
+
+def bam_stream(reads=None, refs=None):
+    reads = READS if reads is None else reads
+    return bam_header(refs) + b"".join(record(r, refs) for r in reads)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# g11_spec_hard.bam (round 4): the corners of the format a Ribo-seq BAM rarely shows and a reader must still survive,
+# written as an UNCOMPRESSED BAM (`samtools view -u`: every BGZF block a stored deflate block).  Expected tables
+# (g11_spec_hard_expected.json) derived by hand, read by read:
+REFS_HARD = [("ref", 45), ("ref2", 40), ("long", 70000)]
+LONG_REAL = "1M1D" * 32768 + "1M"  # 65 537 operations: 32 769 aligned bases at 0, 2, 4, ..., 65 536 (0-based)
+HARD_READS = [
+    # --- more than 65 535 CIGAR operations (section 4.2.2): the record's own CIGAR is the placeholder <l_seq>S<ref span>N,
+    #     the real one sits in CG:B:I.  pysam hands the real one to get_reference_positions(): 32 769 positions,
+    #     first 0, last 65 536; flag 0, MAPQ 255 + NH:i:1 -> unique.  forward '+' (long, 1); reverse '-' (long, 65537)
+    ("lng", 0, "long", 1, 255, ("32769S65537N", LONG_REAL), None, [("NH", "i", 1)]),
+    # --- B arrays of every element width, a Z text that spells a tag and an H string IN FRONT of NH: the scanner has to
+    #     step over them by their declared sizes.  NH:i:1 with MAPQ 0 -> unique.  flag 16; 10M at POS 5 -> 4..13:
+    #     forward '-' last -> (ref, 14); reverse '+' first -> (ref, 5)
+    ("arr", 16, "ref", 5, 0, "10M", None, [("ZB", "B", ("c", [-1, 2, 3])), ("ZC", "B", ("S", [1, 65535])), ("ZF", "B", ("f", [1.5, 2.5])),
+                                           ("XZ", "Z", "text NH:i:7"), ("XH", "H", "1AE301"), ("NH", "i", 1)]),
+    # --- NH as a float: dict(read.get_tags())["NH"] == 1 holds for 1.0 (unique), not for 1.5 (multi).  12M at POS 20 ->
+    #     19..30: forward '+' (ref, 20); reverse '-' (ref, 31)
+    ("flt", 0, "ref", 20, 0, "12M", None, [("NH", "f", 1.0)]),
+    ("fl2", 0, "ref", 20, 255, "12M", None, [("NH", "f", 1.5)]),
+    # --- l_read_name at its maximum (254 characters + NUL) and at its minimum (the NUL alone); MAPQ 255, no NH -> unique.
+    #     10M at POS 5 -> 4..13: forward '+' (ref, 5); reverse '-' (ref, 14).  8M at POS 30 -> 29..36: (ref, 30) / (ref, 37)
+    ("n" * 254, 0, "ref", 5, 255, "10M", None, []),
+    ("", 0, "ref", 30, 255, "8M", None, []),
+    # --- NH twice: dict() keeps the LAST one.  28M at POS 3 on ref2 -> 2..29: forward '+' (ref2, 3); reverse '-' (ref2, 30)
+    ("two", 0, "ref2", 3, 255, "28M", None, [("NH", "i", 2), ("NH", "i", 1)]),   # -> 1 -> unique
+    ("tw2", 0, "ref2", 3, 255, "28M", None, [("NH", "i", 1), ("NH", "i", 2)]),   # -> 2 -> multi
+    # --- array BYTES that spell a tag: 'N' 'H' 'C' 1 inside ZB:B:C is data, not NH:C:1 -> no NH, MAPQ 0 -> multi;
+    #     'N' 'H' 'i' 2 0 0 0 is not NH:i:2 -> no NH, MAPQ 255 -> unique: the same keys as the 254-character read
+    ("byt", 0, "ref", 5, 0, "10M", None, [("ZB", "B", ("C", [78, 72, 67, 1]))]),
+    ("byu", 0, "ref", 5, 255, "10M", None, [("ZB", "B", ("C", [78, 72, 105, 2, 0, 0, 0]))]),
+]
+
+
+def write_hard():
+    raw = bam_stream(HARD_READS, REFS_HARD)
+    blocks, at = [], 0
+    sizes = [65280, 4096, 60000, 1, 65280]  # whole-payload stored blocks: the 311 KB record of `lng` straddles several
+    k = 0
+    while at < len(raw):
+        n = sizes[k % len(sizes)]
+        blocks.append(bgzf_block(raw[at : at + n], level=0))
+        at += n
+        k += 1
+    path = os.path.join(HERE, "g11_spec_hard.bam")
+    with open(path, "wb") as fh:
+        fh.write(b"".join(blocks) + EOF_MARKER)
+    print(f"g11_spec_hard.bam: {len(HARD_READS)} reads, {len(raw)} bytes of BAM in {len(blocks)} stored BGZF blocks + EOF marker, {os.path.getsize(path)} bytes")
 
 
 def bgzf_block(data: bytes, level: int, foreign_subfield: bool = False) -> bytes:
@@ -199,6 +269,7 @@ def main():
     with open(path, "wb") as fh:
         fh.write(b"".join(blocks) + EOF_MARKER)
     print(f"g9_spec.bam: {len(READS)} reads, {len(raw)} bytes of BAM in {len(blocks)} BGZF blocks + EOF marker, {os.path.getsize(path)} bytes")
+    write_hard()
 
 
 if __name__ == "__main__":

@@ -52,3 +52,9 @@ def test_bam_reader_is_clean_under_asan_ubsan(tmp_path):
     assert run.returncode == 0, run.stdout + run.stderr
     assert "split rc=0" in run.stdout and "ok mutated:" in run.stdout
     assert "huge isize rc=2" in run.stdout  # a damaged ISIZE trailer is a format error, not a 3.9 GB allocation
+    # the specification-derived hard file (tests/golden/g11_spec_hard.bam): STORED blocks, so the byte mutations land in
+    # the record fields themselves -- n_cigar_op, l_seq, l_read_name, tag types, B-array counts, the CG placeholder
+    hard = os.path.join(REPO, "tests", "golden", "g11_spec_hard.bam")
+    run = subprocess.run([exe, hard, str(tmp_path / "mut2.bam")], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "split rc=0 rows=6 total=10 valid=7" in run.stdout and "ok mutated:" in run.stdout and "huge isize rc=2" in run.stdout
