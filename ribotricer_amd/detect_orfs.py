@@ -274,31 +274,57 @@ def export_orf_coverages(
 
     import time
 
-    t0 = time.perf_counter()
-    index = _index_of(ribotricer_index)  # parsed once per file: detect-orfs scores one index against many samples
-    if timings is not None:
-        timings["index_parse"] = time.perf_counter() - t0
     if devices is None:
         devices = _devices_from_env()
+    t0 = time.perf_counter()
+    # the alignment columns go up to the device (and a Counter input becomes columns first) BESIDE the index parse:
+    # neither needs the other (the parser is C++ without the GIL, the copies release it too)
+    from concurrent.futures import ThreadPoolExecutor
+
+    from .alignments import UploadedColumns, upload_columns
+
+    with ThreadPoolExecutor(max_workers=1) as side:
+        uploaded = None
+        if not isinstance(merged_alignments, UploadedColumns):
+            uploaded = side.submit(upload_columns, merged_alignments, None if not devices else f"cuda:{int(devices[0])}")
+        index = _index_of(ribotricer_index)  # parsed once per file: detect-orfs scores one index against many samples
+        if timings is not None:
+            timings["index_parse"] = time.perf_counter() - t0
+        if uploaded is not None:
+            merged_alignments = uploaded.result()
+    if timings is not None:
+        timings["index_parse_and_column_upload"] = time.perf_counter() - t0
     counts, offsets, res = score_index(
         index, merged_alignments, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
         min_valid_codons_ratio, min_density_over_orf, report_all, devices, timings=timings, profiles_on_device=True,
     )
     t0 = time.perf_counter()
     tables = index.tables_native
-    with open(f"{prefix}_translating_ORFs.tsv", "wb") as output:
+    with open(f"{prefix}_translating_ORFs.tsv", "w+b") as output:  # (read-write: the writer maps the file)
         output.write(("\t".join(COLUMNS) + "\n").encode("utf-8"))
+        output.flush()
+        at = output.tell()
         # the profiles come back from the device in slices (pinned staging buffers, the copy of slice
-        # k+1 behind the rendering of slice k): a human-sized `report_all` run prints 14 GB of them
+        # k+1 behind the rendering of slice k): a human-sized `report_all` run prints 14 GB of them.  Every
+        # render thread writes its ranges at their final file offsets (tsv.write_rows_native): neither the
+        # rendering nor the copy into the page cache is serial.
+        import os
+
+        mapped = os.environ.get("RIBOTRICER_AMD_TSV_WRITER", TSV_WRITER) == "mapped"
         for a, b, part in _profile_slices(counts, offsets):
             sliced = (tables[0], tables[1][a : b + 1], tables[2], tables[3][a : b + 1])
-            for chunk in tsv.format_rows_native(
-                part, offsets[a : b + 1] - offsets[a], res["phase"][a:b], res["valid"][a:b], res["read_count"][a:b],
-                res["status"][a:b], sliced, report_all,
-            ):
-                output.write(chunk)
+            args = (part, offsets[a : b + 1] - offsets[a], res["phase"][a:b], res["valid"][a:b], res["read_count"][a:b],
+                    res["status"][a:b], sliced, report_all)
+            if mapped:
+                at += tsv.write_rows_native(output.fileno(), at, *args)
+            else:  # render threads hand their chunks, in order, to this one writer
+                for chunk in tsv.format_rows_native(*args):
+                    output.write(chunk)
     if timings is not None:
         timings["profiles_d2h_tsv_render_write"] = time.perf_counter() - t0
+
+
+TSV_WRITER = "stream"  # "mapped": tsv.write_rows_native (parallel copies into a mapping of the file); RIBOTRICER_AMD_TSV_WRITER overrides
 
 
 _INDEX_CACHE: dict = {}  # (real path, size, mtime_ns) -> NativeIndex; the interval table and gather plan hang on the index
@@ -326,20 +352,30 @@ def _index_of(path: str):
     return hit
 
 
-def _table_and_plan(index, base, coverage_len: int, device):
+def _layout_key(base, coverage_len: int, device):
+    return (str(get_engine(device).device), int(coverage_len), tuple(sorted((k, tuple(int(x) for x in v)) for k, v in base.items())))
+
+
+def _layout_cached(index, base, coverage_len: int, device) -> bool:
+    return _layout_key(base, coverage_len, device) in index.__dict__.get("_layout_cache", {})
+
+
+def _table_and_plan(index, base, coverage_len: int, device, table=None):
     """(interval table, gather plan, per-layout extras) of an index for a coverage layout, remembered on the index
     object: all depend on the index and the layout only (the layout on the index's group extents only), not on the
     sample.  ``extras`` is a dict that lives and dies with the layout: the multi-GPU shards (``engine.CsrShards`` /
     ``engine.CoverageShards``: per-device windows, gather plans, tile plans) are kept there."""
     from .gather import interval_table_from_index, make_gather_plan
 
-    key = (str(get_engine(device).device), int(coverage_len), tuple(sorted((k, tuple(int(x) for x in v)) for k, v in base.items())))
+    key = _layout_key(base, coverage_len, device)
     cache = index.__dict__.setdefault("_layout_cache", {})
     if key not in cache:
-        table = interval_table_from_index(index, base)
+        if table is None:
+            table = interval_table_from_index(index, base)
         for old in cache.values():
-            for shards in old[2].values():
-                shards.release()
+            for kept in old[2].values():  # (the extras also hold plain records: sample count, placement report)
+                if hasattr(kept, "release"):
+                    kept.release()
         cache.clear()  # (one layout per index: another one replaces it)
         cache[key] = (table, make_gather_plan(table, coverage_len, device), {})
     return cache[key]
@@ -433,15 +469,25 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     device = None if not devices else f"cuda:{int(devices[0])}"
     t = time.perf_counter()
     big: dict = {}  # positions whose count passes 2^24 - 1 (none on ordinary samples): their ORFs are finished in float64 below
-    coverage, base = build_coverage_device(merged_alignments, index, device, big=big)
-    t = lap("coverage_build", t)
-    table, plan, extras = _table_and_plan(index, base, coverage.numel(), device)
+    # the interval table of a new index (one native pass over its 23 M exons) beside the coverage build on the device
+    from concurrent.futures import ThreadPoolExecutor
+
+    from .gather import coverage_layout
+
+    base0, total0 = coverage_layout(index.extents)
+    with ThreadPoolExecutor(max_workers=1) as side:
+        early = None if _layout_cached(index, base0, total0, device) else side.submit(interval_table_from_index, index, base0)
+        coverage, base = build_coverage_device(merged_alignments, index, device, big=big)
+        t = lap("coverage_build", t)
+        table, plan, extras = _table_and_plan(index, base, coverage.numel(), device, table=None if early is None else early.result())
     t = lap("interval_table_gather_plan", t)
     sharded = devices is not None and len(devices) > 1
-    if plan is not None and not sharded and "workspace_placement" not in extras and _place_workspace_for(table):
-        # once per cached index (like the plans): put the record workspace where its writes cost the coverage reads
-        # least (engine.tune_workspace: +8-15 % on the scoring kernel in most processes; 0.1 s; nothing but ONE
-        # workspace stays allocated).  Pays from the second sample on; RIBOTRICER_AMD_PLACE_WORKSPACE=0 switches it off.
+    extras["samples"] = extras.get("samples", 0) + 1
+    if plan is not None and not sharded and "workspace_placement" not in extras and extras["samples"] >= 2 and _place_workspace_for(table):
+        # once per cached index, when its SECOND sample arrives (a job that scores one index against many samples: the
+        # search costs 0.07 s and gains a fraction of a millisecond per sample, so a single-sample run skips it): put
+        # the record workspace where its writes cost the coverage reads least (engine.tune_workspace; nothing but ONE
+        # workspace stays allocated).  RIBOTRICER_AMD_PLACE_WORKSPACE=0 switches it off.
         extras["workspace_placement"] = get_engine(device).tune_workspace(
             coverage, thresholds=make_filter(phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio,
                                              min_density_over_orf), gather_plan=plan, tries=3, spread=0.03)  # (a coverage far larger than a memory class: little to find, profiles/r04_placement_check.txt)

@@ -148,3 +148,149 @@ def format_rows_native(
                 yield from window.popleft().result()
         while window:
             yield from window.popleft().result()
+
+
+class _OrderedOffsets:
+    """File offsets for ranges that are rendered concurrently but must land in range order: range r learns where it
+    starts once the ranges before it have declared their sizes (not finished writing)."""
+
+    def __init__(self, base: int):
+        self.cond = threading.Condition()
+        self.next_range = 0
+        self.at = base
+
+    def claim(self, r: int, nbytes: int) -> int:
+        with self.cond:
+            while self.next_range != r:
+                self.cond.wait()
+            start = self.at
+            self.at += nbytes
+            self.next_range += 1
+            self.cond.notify_all()
+            return start
+
+
+def write_rows_native(
+    fd: int,
+    file_offset: int,
+    counts: np.ndarray,
+    offsets: np.ndarray,
+    phase: np.ndarray,
+    valid: np.ndarray,
+    read_count: np.ndarray,
+    status: np.ndarray,
+    tables,
+    report_all: bool,
+    threads: int | None = None,
+    range_bytes: int = 16 << 20,
+) -> int:
+    """Render the TSV body of all ORFs of the arrays into the file behind ``fd`` (open for reading AND writing: it is
+    mapped) from ``file_offset`` on; returns the
+    number of bytes written (the file ends there afterwards).  The same bytes as ``b"".join(format_rows_native(...))``
+    -- but every render thread copies its own ranges to their final offsets (ranges are sized as they are rendered,
+    ``_OrderedOffsets``) through a shared MAPPING of the file, so neither the rendering nor the copy into the page cache
+    is serial and no intermediate ``bytes`` object is made: a human-sized `report_all` export writes 12.8 GB
+    (detect_orfs.py:301-324 writes them row by row).  (``pwrite`` from many threads was measured first: buffered writes
+    to one file serialise on the inode lock -- 5.2 s against 2.5 s for a single writer, profiles/r04_export_e2e_11M_pwrite.json.)
+    The file is extended to an upper bound of the text first (sparse) and cut to the exact end afterwards."""
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    phase = np.ascontiguousarray(phase, dtype=np.float64)
+    valid = np.ascontiguousarray(valid, dtype=np.int32)
+    read_count = np.ascontiguousarray(read_count, dtype=np.int64)
+    status = np.ascontiguousarray(status, dtype=np.uint8)
+    head, head_off, tail, tail_off = tables
+    n = offsets.size - 1
+    if not (phase.size == valid.size == read_count.size == status.size == n == head_off.size - 1 == tail_off.size - 1):
+        raise ValueError("per-ORF arrays and string tables must all have n_orfs entries")
+    if n <= 0:
+        return 0
+
+    def c_buffer(table):
+        if isinstance(table, (bytes, bytearray)):
+            return ctypes.create_string_buffer(bytes(table), len(table)) if table else ctypes.create_string_buffer(1)
+        return table
+
+    arrays = (counts, offsets, phase, valid, read_count, status)
+    tables_c = (c_buffer(head), np.ascontiguousarray(head_off, dtype=np.int64), c_buffer(tail), np.ascontiguousarray(tail_off, dtype=np.int64))
+    total_nt = int(offsets[n] - offsets[0])
+    # rows cost ~3.2 bytes of text per nucleotide + ~120 bytes of columns: ranges of about range_bytes of text
+    weight = (offsets[1:] - offsets[0]) * 4 + np.arange(1, n + 1, dtype=np.int64) * 128
+    per_range = max(1, range_bytes)
+    cuts = np.searchsorted(weight, np.arange(per_range, int(weight[-1]), per_range), side="left") + 1
+    bounds = np.unique(np.concatenate(([0], np.minimum(cuts, n), [n])))
+    ranges = list(zip(bounds[:-1].tolist(), bounds[1:].tolist()))
+    if threads is None:
+        threads = min(32, _lib.usable_cores()) if total_nt > (4 << 20) or n > 100000 else 1
+    threads = max(1, min(threads, len(ranges)))
+    order = _OrderedOffsets(file_offset)
+    chunk_bytes = 2 * range_bytes + (1 << 20)  # (a range nearly always fits one buffer: one claim per range)
+    # upper bound of the text: <= 12 bytes per printed count ("-2147483648, "), the index columns as they are, < 200
+    # bytes of numbers, tabs and brackets per row
+    import mmap
+
+    upper = 12 * total_nt + int(head_off[n] - head_off[0]) + int(tail_off[n] - tail_off[0]) + 200 * n + 4096
+    gran = mmap.ALLOCATIONGRANULARITY
+    map_base = file_offset // gran * gran
+    os.ftruncate(fd, max(os.fstat(fd).st_size, file_offset + upper))
+    mm = mmap.mmap(fd, file_offset - map_base + upper, offset=map_base)
+    anchor = ctypes.c_char.from_buffer(mm)
+    mm_addr = ctypes.addressof(anchor) - map_base  # address of file offset 0 in this mapping's coordinates
+
+    lib = _lib.load()
+    head_buf, head_off_c, tail_buf, tail_off_c = tables_c
+
+    def pwrite_all(view, at: int) -> None:  # (a memcpy into the mapping; ctypes releases the GIL for its duration)
+        if len(view):
+            ctypes.memmove(mm_addr + at, (ctypes.c_char * len(view)).from_buffer(view) if not isinstance(view, bytes) else view, len(view))
+
+    def work(r: int) -> int:
+        a, b = ranges[r]
+        cap = chunk_bytes
+        out = getattr(_tls, "wout", None)  # one reusable render buffer per thread (first touch is the costly part)
+        if out is None or len(out) < cap:
+            out = _tls.wout = ctypes.create_string_buffer(cap)
+        cap = len(out)
+        nxt = ctypes.c_int64(a)
+        ln = ctypes.c_size_t(0)
+        cur = a
+        pieces: list = []  # (rare: a range that did not fit one buffer is collected and written as one)
+        while cur < b:
+            rc = lib.rp_format_rows_host(
+                counts.ctypes.data, offsets.ctypes.data, b, phase.ctypes.data, valid.ctypes.data, read_count.ctypes.data,
+                status.ctypes.data, ctypes.cast(head_buf, ctypes.c_void_p), head_off_c.ctypes.data,
+                ctypes.cast(tail_buf, ctypes.c_void_p), tail_off_c.ctypes.data, int(bool(report_all)), cur,
+                ctypes.cast(out, ctypes.c_void_p), cap, ctypes.byref(nxt), ctypes.byref(ln),
+            )
+            if rc == RP_ERR_SIZE and ln.value > cap:  # one row longer than the buffer: give it room and retry
+                cur = nxt.value
+                cap = int(ln.value)
+                out = _tls.wout = ctypes.create_string_buffer(cap)
+                continue
+            _lib.check(rc)
+            cur = nxt.value
+            if cur >= b and not pieces:  # the common case: the whole range in one buffer -> straight from it to the file
+                start = order.claim(r, ln.value)
+                if ln.value:
+                    ctypes.memmove(mm_addr + start, out, ln.value)
+                return int(ln.value)
+            pieces.append(out.raw[: ln.value])
+        blob = b"".join(pieces)
+        start = order.claim(r, len(blob))
+        pwrite_all(blob, start)
+        return len(blob)
+
+    try:
+        if threads == 1:
+            written = sum(work(r) for r in range(len(ranges)))
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+
+            with ThreadPoolExecutor(max_workers=threads) as pool:  # (ranges are taken in order: a claim never waits for an unstarted range)
+                written = sum(pool.map(work, range(len(ranges))))
+    finally:
+        del anchor  # (the mapping cannot be closed while a ctypes view of it lives)
+        mm.close()
+    os.ftruncate(fd, file_offset + written)
+    return written
+

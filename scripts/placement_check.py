@@ -44,7 +44,7 @@ def child(n_orfs: int) -> None:
                          [f"chr{k}" for k in range(1, 25)])
     del ex, pick, pos
     walls, stages = [], []
-    for k in range(2):
+    for k in range(3):  # (the placement search runs when the second sample of a cached index arrives)
         tm: dict = {}
         t0 = time.perf_counter()
         d.export_orf_coverages(index_path, cols, prefix + f"_s{k}", timings=tm)
@@ -70,7 +70,7 @@ def child(n_orfs: int) -> None:
     full = eng.tune_workspace(coverage, thresholds=th, gather_plan=plan, spread=1.0)  # try every candidate
     best = kernel_ms()
     print(json.dumps({"n_orfs": n_orfs, "total_nt": int(table.offsets[-1]), "export_wall_s": walls,
-                      "placement_in_export": extras.get("workspace_placement"), "placement_stage_s": stages[0].get("workspace_placement"),
+                      "placement_in_export": extras.get("workspace_placement"), "placement_stage_s": stages[1].get("workspace_placement"),
                       "product_kernel_ms": product[0], "product_step_ms": product[1], "reserved_bytes": reserved, "allocated_bytes": allocated,
                       "exhaustive_search_step_ms": full["step_ms"], "kernel_ms_after_exhaustive_search": best[0],
                       "product_over_best": product[0] / min(best[0], product[0])}))

@@ -367,3 +367,33 @@ def test_reference_orf_test_vectors():
             assert rec.tid == "tx1" and rec.category == "annotated" and rec.chrom == "chr1" and rec.strand == "+"
             assert rec.gid == "gene1" and rec.gname == "Gene1" and rec.intervals == ((100, 200),)
             assert rec.start_codon == codon and rec.oid == "tx1_100_200_101"
+
+
+def test_parallel_mapped_writer_equals_the_chunk_generator(tmp_path):
+    """tsv.write_rows_native (every render thread copies its ranges to their final offsets in a mapping of the file) produces the bytes of
+    format_rows_native, whatever the thread count and range size -- ranges that do not fit one buffer, rows longer than
+    a buffer, ranges without a printed row (default mode) included."""
+    from ribotricer_amd import tsv
+
+    rng = np.random.default_rng(1)
+    n = 20000
+    lengths = rng.integers(0, 400, size=n)
+    lengths[5] = 90000
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    counts = rng.poisson(0.7, size=int(offsets[-1])).astype(np.int32)
+    phase, valid = rng.random(n), rng.integers(0, 50, n).astype(np.int32)
+    reads, status = rng.integers(0, 1000, n).astype(np.int64), (rng.random(n) < 0.3).astype(np.uint8)
+    status[8000:16000] = 0  # whole ranges without a translating ORF
+    tables = tsv.string_table([f"id{k}\ttype" for k in range(n)]) + tsv.string_table([f"t{k}\ta\tb\tc\td\tchr\t+\tATG" for k in range(n)])
+    for report_all in (True, False):
+        want = b"".join(tsv.format_rows_native(counts, offsets, phase, valid, reads, status, tables, report_all))
+        for threads, range_bytes in ((1, 16 << 20), (4, 1 << 20), (8, 4096), (3, 100)):
+            path = tmp_path / f"w{int(report_all)}_{threads}_{range_bytes}"
+            with open(path, "w+b") as fh:  # (read-write: the writer maps the file)
+                fh.write(b"HEADER\n")
+                fh.flush()
+                written = tsv.write_rows_native(fh.fileno(), 7, counts, offsets, phase, valid, reads, status, tables, report_all,
+                                                threads=threads, range_bytes=range_bytes)
+            assert written == len(want) and path.read_bytes() == b"HEADER\n" + want, (report_all, threads, range_bytes)
+    assert tsv.write_rows_native(0, 0, counts[:0], offsets[:1], phase[:0], valid[:0], reads[:0], status[:0],
+                                 (b"", np.zeros(1, np.int64), b"", np.zeros(1, np.int64)), True) == 0
