@@ -181,7 +181,7 @@ template <int TILE, int HALO>
 __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, long long n_pieces, long long total_nt)
 {
     __shared__ long long s_j0, s_lo, s_hi;
-    __shared__ int s_total, s_base, s_full;
+    __shared__ int s_total, s_base, s_full, s_wide;
     __shared__ int s_wave[kRowBlock / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const long long b = blockIdx.x;
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
         plan.tile_lo[2 * b + 1] = s_total;
         s_base = 0;
         s_full = 0;
+        s_wide = 0;
     }
     if (!fast) return;  // (the row stays unwritten: never read)
     // pass 2: the chunks, numbered by a prefix sum over the pieces
@@ -258,7 +259,11 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
         int c0 = s_base + incl - nch;
         for (int w = 0; w < wave; ++w) c0 += s_wave[w];
         bool full = false;
-        for (int k = 0; k < nch; ++k) row[c0 + k] = make_chunk(c, tile_lo, k, &full);
+        for (int k = 0; k < nch; ++k) {
+            const chunk_desc_t cd = make_chunk(c, tile_lo, k, &full);
+            row[c0 + k] = cd;
+            if ((cd >> 52) != 0) s_wide = 1;  // (benign race: every writer stores 1)
+        }
         if (full) s_full = 1;
         __syncthreads();
         if (t == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
@@ -270,6 +275,7 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
         if (t == 0) plan.tile_lo[2 * b] = kTileSlow;
         return;
     }
+    if (s_wide && t == 0) plan.tile_lo[2 * b + 1] = (long long)s_total | (1ll << 32);  // (kTileWide, defined below with its reader)
     // pad: the slots past the last chunk repeat chunk 0 (written by the thread that owns position t0)
     __threadfence_block();
     const chunk_desc_t first = row[0];
@@ -290,10 +296,22 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
 #ifndef RP_CHUNK_POLICY
 #define RP_CHUNK_POLICY " nt"  // the coverage is read once per launch: tile gather -5 % on gapped / 60-nt layouts, else unchanged
 #endif
-// w1 = LDS address | (64 - positions) << 16 | dir << 24 | (byte offset >> 32) << 25; the scalar base of a step is
-// s[20:21] = {base low, base high + the chunk's high offset half} (named registers: an asm operand cannot be
-// addressed by halves; both are on the clobber list)
-#define RP_DMA_STEP(I)                                          \
+// w1 = LDS address | (64 - positions) << 16 | dir << 24 | (byte offset >> 32) << 25.
+// NARROW step (all chunks of the tile within 4 GiB of its lowest source: every chromosome-sorted index): the scalar
+// base is the tile's own.  WIDE step (pieces of one tile anywhere in 512 GiB: two more scalar instructions): the base of
+// a step is s[20:21] = {base low, base high + the chunk's high offset half} (named registers: an asm operand cannot be
+// addressed by halves; both are on the clobber list).
+#define RP_DMA_STEP_NARROW(I)                                   \
+    "v_readlane_b32 %[so], %[w0], " #I "\n\t"                   \
+    "v_readlane_b32 %[s1], %[w1], " #I "\n\t"                   \
+    "s_and_b32 m0, %[s1], 0xffff\n\t"                           \
+    "s_lshr_b32 %[st], %[s1], 16\n\t"                           \
+    "s_lshr_b64 exec, -1, %[st]\n\t"                            \
+    "s_lshr_b32 %[sd], %[st], 8\n\t"                            \
+    "v_mad_i32_i24 %[vt], %[sd], %[vdelta], %[vup]\n\t"         \
+    "v_add_u32 %[vt], %[so], %[vt]\n\t"                         \
+    "global_load_lds_dword %[vt], s[20:21]" RP_CHUNK_POLICY "\n\t"
+#define RP_DMA_STEP_WIDE(I)                                     \
     "v_readlane_b32 %[so], %[w0], " #I "\n\t"                   \
     "v_readlane_b32 %[s1], %[w1], " #I "\n\t"                   \
     "s_and_b32 m0, %[s1], 0xffff\n\t"                           \
@@ -305,11 +323,19 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
     "v_mad_i32_i24 %[vt], %[sd], %[vdelta], %[vup]\n\t"         \
     "v_add_u32 %[vt], %[so], %[vt]\n\t"                         \
     "global_load_lds_dword %[vt], s[20:21]" RP_CHUNK_POLICY "\n\t"
-#define RP_DMA_STEP8(A, B, C, D, E, F, G, H, LIM)               \
-    RP_DMA_STEP(A) RP_DMA_STEP(B) RP_DMA_STEP(C) RP_DMA_STEP(D) \
-    RP_DMA_STEP(E) RP_DMA_STEP(F) RP_DMA_STEP(G) RP_DMA_STEP(H) \
+#define RP_DMA_STEP8(S, A, B, C, D, E, F, G, H, LIM)            \
+    S(A) S(B) S(C) S(D) S(E) S(F) S(G) S(H)                     \
     "s_cmp_le_u32 %[steps], " #LIM "\n\t"                       \
     "s_cbranch_scc1 1f\n\t"
+#define RP_DMA_STEPS64(S)                                       \
+    RP_DMA_STEP8(S, 0, 1, 2, 3, 4, 5, 6, 7, 8)                  \
+    RP_DMA_STEP8(S, 8, 9, 10, 11, 12, 13, 14, 15, 16)           \
+    RP_DMA_STEP8(S, 16, 17, 18, 19, 20, 21, 22, 23, 24)         \
+    RP_DMA_STEP8(S, 24, 25, 26, 27, 28, 29, 30, 31, 32)         \
+    RP_DMA_STEP8(S, 32, 33, 34, 35, 36, 37, 38, 39, 40)         \
+    RP_DMA_STEP8(S, 40, 41, 42, 43, 44, 45, 46, 47, 48)         \
+    RP_DMA_STEP8(S, 48, 49, 50, 51, 52, 53, 54, 55, 56)         \
+    RP_DMA_STEP8(S, 56, 57, 58, 59, 60, 61, 62, 63, 64)
 
 // Call sites must be wave-uniform with all 64 lanes active: the block overwrites EXEC and leaves
 // it all-ones (stage_tile_chunks is reached through workgroup-uniform branches only).  M0 and EXEC
@@ -318,6 +344,7 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
 // are reserved registers, which is the point.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
+template <bool WIDE>
 __device__ __forceinline__ void issue_chunks(const int32_t *base, unsigned w0, unsigned w1, int steps, int lane)
 {
     const int vup = lane * 4, vdelta = (63 - 2 * lane) * 4;  // vup + vdelta = (63 - lane) * 4
@@ -326,25 +353,32 @@ __device__ __forceinline__ void issue_chunks(const int32_t *base, unsigned w0, u
     const unsigned long long u = (unsigned long long)base;
     const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
     const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
-    asm volatile(
-        "s_mov_b32 s20, %[blo]\n\t"
-        RP_DMA_STEP8(0, 1, 2, 3, 4, 5, 6, 7, 8)
-        RP_DMA_STEP8(8, 9, 10, 11, 12, 13, 14, 15, 16)
-        RP_DMA_STEP8(16, 17, 18, 19, 20, 21, 22, 23, 24)
-        RP_DMA_STEP8(24, 25, 26, 27, 28, 29, 30, 31, 32)
-        RP_DMA_STEP8(32, 33, 34, 35, 36, 37, 38, 39, 40)
-        RP_DMA_STEP8(40, 41, 42, 43, 44, 45, 46, 47, 48)
-        RP_DMA_STEP8(48, 49, 50, 51, 52, 53, 54, 55, 56)
-        RP_DMA_STEP8(56, 57, 58, 59, 60, 61, 62, 63, 64)
-        "1:\n\t"
-        "s_mov_b64 exec, -1"
-        : [so] "=&s"(so), [s1] "=&s"(s1), [st] "=&s"(st), [sd] "=&s"(sd), [vt] "=&v"(vt)
-        : [w0] "v"(w0), [w1] "v"(w1), [vdelta] "v"(vdelta), [vup] "v"(vup), [blo] "s"(blo), [bhi] "s"(bhi), [steps] "s"(steps)
-        : "memory", "scc", "m0", "exec", "s20", "s21");  // every step rewrites M0 and EXEC (EXEC is left all-ones, as it came in)
+    if constexpr (WIDE) {
+        asm volatile(
+            "s_mov_b32 s20, %[blo]\n\t"
+            RP_DMA_STEPS64(RP_DMA_STEP_WIDE)
+            "1:\n\t"
+            "s_mov_b64 exec, -1"
+            : [so] "=&s"(so), [s1] "=&s"(s1), [st] "=&s"(st), [sd] "=&s"(sd), [vt] "=&v"(vt)
+            : [w0] "v"(w0), [w1] "v"(w1), [vdelta] "v"(vdelta), [vup] "v"(vup), [blo] "s"(blo), [bhi] "s"(bhi), [steps] "s"(steps)
+            : "memory", "scc", "m0", "exec", "s20", "s21");  // every step rewrites M0 and EXEC (EXEC is left all-ones, as it came in)
+    } else {
+        asm volatile(
+            "s_mov_b32 s20, %[blo]\n\t"
+            "s_mov_b32 s21, %[bhi]\n\t"
+            RP_DMA_STEPS64(RP_DMA_STEP_NARROW)
+            "1:\n\t"
+            "s_mov_b64 exec, -1"
+            : [so] "=&s"(so), [s1] "=&s"(s1), [st] "=&s"(st), [sd] "=&s"(sd), [vt] "=&v"(vt)
+            : [w0] "v"(w0), [w1] "v"(w1), [vdelta] "v"(vdelta), [vup] "v"(vup), [blo] "s"(blo), [bhi] "s"(bhi), [steps] "s"(steps)
+            : "memory", "scc", "m0", "exec", "s20", "s21");
+    }
 }
 #pragma clang diagnostic pop
+#undef RP_DMA_STEPS64
 #undef RP_DMA_STEP8
-#undef RP_DMA_STEP
+#undef RP_DMA_STEP_NARROW
+#undef RP_DMA_STEP_WIDE
 
 // pin a workgroup-uniform pointer to scalar registers (an "s" asm operand alone does not)
 __device__ __forceinline__ const int32_t *scalar_ptr(const int32_t *p)
@@ -367,9 +401,14 @@ __device__ __forceinline__ const chunk_desc_t *chunk_slot(const PiecePlan &pp, l
 }
 
 // `e`: the thread's round-0 chunk (already loaded); total: the tile's chunk count
+// `total`: the tile's chunk count, with kTileWide set when a chunk's offset does not fit 32 bits
+constexpr long long kTileWide = 1ll << 32;
+
 __device__ __forceinline__ void stage_tile_chunks(const int32_t *__restrict__ cov, const PiecePlan &pp, long long b,
-                                                  long long tile_lo, int total, chunk_desc_t e, int *s_counts, int lane, int wave)
+                                                  long long tile_lo, long long total_word, chunk_desc_t e, int *s_counts, int lane, int wave)
 {
+    const int total = (int)(unsigned)total_word;
+    const bool wide = (total_word & kTileWide) != 0;  // workgroup-uniform
     const unsigned lds0 = lds_address(s_counts);
     const int32_t *base = scalar_ptr(cov + tile_lo);
     for (int r0 = 0;; r0 += 256) {  // workgroup-uniform; one round unless the tile has > 256 chunks
@@ -377,7 +416,12 @@ __device__ __forceinline__ void stage_tile_chunks(const int32_t *__restrict__ co
         const unsigned w1 = (lds0 + (hi & 0x1fffu) * 4u) | (((hi >> 13) & 0x3fu) << 16) | (((hi >> 19) & 1u) << 24) | (((hi >> 20) & 0x7fu) << 25);
         int steps = (total - r0 - wave + 3) >> 2;  // chunks r0 + wave, r0 + wave + 4, ... < total
         steps = __builtin_amdgcn_readfirstlane(steps > 64 ? 64 : steps);
-        if (steps > 0) issue_chunks(base, (unsigned)e, w1, steps, lane);
+        if (steps > 0) {
+            if (wide)
+                issue_chunks<true>(base, (unsigned)e, w1, steps, lane);
+            else
+                issue_chunks<false>(base, (unsigned)e, w1, steps, lane);
+        }
         if (r0 + 256 >= total) break;
         const int c = r0 + 256 + 4 * lane + wave;
         e = pp.rows[b * kMaxChunks + (c < kMaxChunks ? c : 0)];
@@ -474,7 +518,7 @@ __global__ __launch_bounds__(kGatherTileBlock) void k_tile_gather(const int32_t 
     const long long b = blockIdx.x;
     const long long tile_lo = pp.tile_lo[2 * b];
     if (tile_lo != kTileSlow)
-        stage_tile_chunks(cov, pp, b, tile_lo, (int)pp.tile_lo[2 * b + 1], *chunk_slot(pp, b, lane, wave), s_counts, lane, wave);
+        stage_tile_chunks(cov, pp, b, tile_lo, pp.tile_lo[2 * b + 1], *chunk_slot(pp, b, lane, wave), s_counts, lane, wave);
     else
         stage_tile_slow<TILE, HALO>(cov, pp, b, total_nt, s_counts, lane, wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -903,7 +903,7 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
         // The thread's chunk of the tile's row (rp_pieces.hpp) arrives with the head row: one wait
         // for both, here -- the DMA issued next must not sit in front of them.
         const long long tile_lo = pp.tile_lo[2 * b];
-        const int n_chunks = (int)pp.tile_lo[2 * b + 1];
+        const long long n_chunks = pp.tile_lo[2 * b + 1];  // (count | kTileWide)
         chunk_desc_t mine;
         asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(mine) : "v"(chunk_slot(pp, b, lane, wave)) : "memory");
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(d), "+v"(vmap), "+v"(mine) : : "memory");

@@ -216,12 +216,13 @@ class GatherPlan:
         at = 128 + 2 * up((self.n_intervals + 1) * 8) + up((self.n_orfs + 1) * 8) + up(n_tiles * 8)
         torch.cuda.synchronize(self.device)
         words = self._mem[at : at + 16 * n_tiles].cpu().numpy().view(np.int64).reshape(n_tiles, 2)
-        lo, chunks = words[:, 0], words[:, 1]
+        lo, chunks = words[:, 0], words[:, 1] & 0xFFFFFFFF
+        wide = (words[:, 1] >> 32) != 0  # a chunk of the tile lies > 4 GiB from the tile's lowest source: the two-instructions-longer issue loop
         slow = lo == np.iinfo(np.int64).min
         q = np.percentile(chunks, [50, 90, 99]) if n_tiles else [0, 0, 0]
         return {"tile_positions": tile, "tiles": int(n_tiles), "slow_tiles": int(slow.sum()), "chunks_per_tile_mean": float(chunks.mean()),
                 "chunks_per_tile_p50_p90_p99": [float(x) for x in q], "chunks_per_tile_max": int(chunks.max()),
-                "tiles_over_256_chunks": int((chunks > 256).sum()), "positions_per_chunk_mean": float(self.total_nt / max(1, chunks[~slow].sum())),
+                "tiles_over_256_chunks": int((chunks > 256).sum()), "wide_tiles": int((wide & ~slow).sum()), "positions_per_chunk_mean": float(self.total_nt / max(1, chunks[~slow].sum())),
                 "pieces_per_tile_mean": float(self.n_intervals / n_tiles)}
 
     def __del__(self):

@@ -52,6 +52,7 @@ def test_tile_gather(case):
     cov = rng.poisson(0.7, size=400000).astype(np.int32)
     t = random_table(rng, cov_len=cov.size, **CASES[case])
     plan = GatherPlan(t, cov.size)
+    assert plan.stats()["wide_tiles"] == 0  # (a 1.6 MB coverage: every tile takes the 32-bit issue loop)
     got, off = gather_profiles_device(cov, t, plan=plan)
     legacy, _ = gather_profiles_device(cov, t)
     torch.cuda.synchronize()
@@ -137,6 +138,7 @@ def test_pieces_of_one_tile_gigabytes_apart():
     # own 252 bytes would wrap -- such a tile is planned slow (6e-8 of the chunks on an ordinary layout, ~4 % of the
     # tiles here): both staging paths are compared with the per-ORF gather below
     assert 0 < st["slow_tiles"] < 0.1 * st["tiles"] and st["tiles"] >= 100, st
+    assert st["wide_tiles"] > 0.8 * st["tiles"], st  # (offsets past 32 bits: the longer issue loop)
     eng = get_engine("cuda:0")
     th = make_filter()
     counts = plan.gather(cov)
