@@ -86,6 +86,7 @@ def parse_args():
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-stream many-samples section (N = 1)")
     ap.add_argument("--no-fused", action="store_true", help="skip the fused gather + score section (N = 1)")
     ap.add_argument("--no-fused-nested", action="store_true", help="skip the nested-index fused section (N = 1)")
+    ap.add_argument("--no-fused-exons", action="store_true", help="skip the fused section on the run's own length law (N = 1; counter passes that want the nested launches alone)")
     ap.add_argument("--fused-steps", type=int, default=10)
     ap.add_argument("--seed", type=int, default=20260213)
     return ap.parse_args()
@@ -653,7 +654,8 @@ def main():
             verify["read_count_checksum_ok"] = bool(int(out.read_count.sum()) == int(counts.sum(dtype=torch.int64)))
             verify["ok"] = verify["ok"] and verify["read_count_checksum_ok"]
         if not args.no_fused and resolved == "tile" and n_orfs > 0:
-            fused = fused_section(args, eng, dev, thresholds, n_set)
+            if not args.no_fused_exons:
+                fused = fused_section(args, eng, dev, thresholds, n_set)
             if not args.no_fused_nested:
                 fused_nested = fused_section(args, eng, dev, thresholds, n_set, layout="nested")
         bad = (verify is not None and not verify["ok"]) or any(f is not None and "verify" in f and not f["verify"]["ok"] for f in (fused, fused_nested))

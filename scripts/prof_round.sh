@@ -1,7 +1,7 @@
 #!/bin/bash
 # One box, one call: the default bench line, the same command under rocprofv3 (kernel-trace
-# stats) and four separate --pmc passes (SQ wave/VALU counters; LDS/SALU/VMEM + GRBM_GUI_ACTIVE;
-# FETCH_SIZE; WRITE_SIZE), summarised per kernel.  usage: bash scripts/prof_round.sh <tag> [bench args]
+# stats) and six separate --pmc passes (SQ wave/VALU counters; LDS/SALU/VMEM + GRBM_GUI_ACTIVE;
+# FETCH_SIZE; WRITE_SIZE; the last two again for the nested fused section alone), summarised per kernel.  usage: bash scripts/prof_round.sh <tag> [bench args]
 TAG=${1:-r02}; shift
 ARGS="$@"
 export TMPDIR=/tmp
@@ -13,10 +13,13 @@ rm -rf $W; mkdir -p $W $OUT
 timeout 600 python3 bench.py $ARGS > $OUT/bench_default.json 2> $OUT/bench_default.err
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $W/stats -o stats -- python3 $R/bench.py $ARGS --steps 20 --warmup 3 --cpu-sample 0 > $OUT/bench_under_rocprofv3.json 2> $OUT/stats.err
-timeout 600 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $W/pmc1 -o pmc1 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 > $OUT/pmc1_bench.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $W/pmc2 -o pmc2 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 > $OUT/pmc2_bench.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $W/pmc3 -o pmc3 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 > $OUT/pmc3_bench.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $W/pmc4 -o pmc4 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 > $OUT/pmc4_bench.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $W/pmc1 -o pmc1 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-fused-nested > $OUT/pmc1_bench.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $W/pmc2 -o pmc2 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-fused-nested > $OUT/pmc2_bench.log 2>&1
+# (the two fused layouts launch the same kernel name: counted in separate passes -- pmc3/4 the run's own length law, pmc5/6 the nested index)
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $W/pmc3 -o pmc3 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-fused-nested > $OUT/pmc3_bench.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $W/pmc4 -o pmc4 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-fused-nested > $OUT/pmc4_bench.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $W/pmc5 -o pmc5 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-fused-exons > $OUT/pmc5_bench.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $W/pmc6 -o pmc6 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-fused-exons > $OUT/pmc6_bench.log 2>&1
 cd $R
 cp $(find $W/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 python3 - "$W" "$OUT" <<'PY'
@@ -36,7 +39,7 @@ with open(f"{OUT}/kernel_durations.csv", "w") as fh:
         d = [x[1] for x in v]
         fh.write(f"\"{name}\",{len(d)},{statistics.mean(d):.0f},{statistics.median(d):.0f},{min(d)},{max(d)},{statistics.mean(d[-40:]):.0f}\n")
 print(open(f"{OUT}/kernel_durations.csv").read())
-for tag in ("pmc1", "pmc2", "pmc3", "pmc4"):
+for tag in ("pmc1", "pmc2", "pmc3", "pmc4", "pmc5", "pmc6"):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for f in glob.glob(f"{W}/{tag}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
