@@ -43,6 +43,10 @@
 namespace rp {
 
 constexpr int kTileBlock = 256;
+#ifndef RP_ROW_PREFETCH
+#define RP_ROW_PREFETCH 0  // fused kernel: prefetch the plan rows of tile b + this many into L2 (a multiple of 8).  A/B knob, OFF: measured
+                          // 2-3 % SLOWER at 512 / 1024 / 2048 on both layouts (profiles/r04_ab_fused_row_prefetch.txt)
+#endif
 #ifndef RP_LOADERS
 #define RP_LOADERS 1
 #endif
@@ -881,6 +885,7 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
     const int wave = tid >> 6;
     const long long t0 = b * (long long)TILE - plan.mis;  // position of LDS index 0 (may be < 0 for b == 0)
     if (b == 0 && tid == 0) *ws.long_count = 0;  // (k_orf_finish, next in the stream, appends)
+    unsigned prefetched = 0;  // (fused: destination of the row prefetch; kept live up to the wait that covers it)
     RP_STAMP_DECL
     RP_STAMP();  // 0: entry
     // The tile's head row first -- its [a0, a1) ORF range through the scalar unit, its segment
@@ -913,6 +918,23 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
         else
             stage_tile_slow<TILE, kHalo>(counts, pp, b, plan.total_nt, s_counts, lane, wave);
         __builtin_amdgcn_s_setprio(0);
+#if RP_ROW_PREFETCH > 0
+        // The plan rows of the tile this CU slot will most likely run NEXT (b + the number of workgroups in flight; a
+        // multiple of 8, so it is dispatched to the same XCD and finds the lines in ITS L2): 7 lines of head row, 22 of
+        // chunk row, the tile_lo entry -- one load per line by wave 0, into a register nobody reads.  In the fused kernel
+        // the rows are on the critical path (no DMA can be issued before the chunks are known): an L2 hit instead of an
+        // HBM miss takes ~1 k cycles off a workgroup's ~13 k.  Issued BEHIND this tile's DMA, so it lands with it and
+        // adds nothing to the wait at barrier 1.
+        {
+            const long long bn = b + RP_ROW_PREFETCH;
+            if (wave == 0 && bn < plan.n_tiles && lane < 30) {
+                const char *line = lane < 7    ? reinterpret_cast<const char *>(ws.head + bn * kHeadRow) + 128 * lane
+                                   : lane < 29 ? reinterpret_cast<const char *>(pp.rows + bn * kMaxChunks) + 128 * (lane - 7)
+                                               : reinterpret_cast<const char *>(pp.tile_lo + 2 * bn);
+                asm volatile("global_load_dword %0, %1, off" : "=v"(prefetched) : "v"(line) : "memory");
+            }
+        }
+#endif
     } else {
         load_tile_to_lds<TILE>(counts, t0, plan.total_nt, s_counts, tid);
     }
@@ -964,7 +986,7 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
             s_geom[lane] = seg_geom(d);
         }
         RP_STAMP();  // 3: mapped, arrived at barrier 1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-DMA completion is tracked by vmcnt only
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(prefetched) : : "memory");  // LDS-DMA completion is tracked by vmcnt only
         __syncthreads();
         RP_STAMP();  // 4: tile landed (barrier 1)
         if (pass) tile_pass<kRun>(s_counts, s_rec, q0, lim, active, seg, vl);
@@ -991,7 +1013,7 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
         const long long orf = a0 - 1 + lane;
         if (orf >= 0 && orf < a1) dc = ws.desc[orf + b];  // chunk 0, in flight with the tile
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(prefetched) : : "memory");
     for (long long c0 = 0; c0 < n_slots; c0 += kSegChunk) {
         if (c0 > 0) {
             __syncthreads();  // the previous chunk's record stage is done with the tables
