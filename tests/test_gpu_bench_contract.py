@@ -101,7 +101,7 @@ def test_bare_command_runs_n_ranks(n):
     assert d["n_gpus"] == n and d["scaling"] == "strong" and d["config"]["launcher"] == "bench.py self_launch"
     phys = torch.cuda.device_count()
     assert d["config"]["physical_gpus"] == phys and d["config"]["ranks_share_gpus"] == (n > phys)
-    assert d["config"]["control_backend"] == ("nccl" if phys >= n else "gloo")
+    assert d["config"]["control_backend"] == ("nccl" if phys >= n else "gloo")  # (RCCL is probed first; "gloo (RCCL probe failed ...)" would say so)
     ranks = d["per_rank"]
     assert [r["rank"] for r in ranks] == list(range(n)) and sum(r["orfs"] for r in ranks) == 400000
     nts = [r["nt"] for r in ranks]
