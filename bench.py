@@ -442,6 +442,9 @@ def main():
         backend = "gloo"
         if want == "nccl":
             ok, why = 1, ""
+            # (a collective that hangs must end in an exception on the waiting thread, not in the watchdog tearing the
+            # process down: blocking waits raise on their timeout)
+            os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
             try:
                 rccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(minutes=3))
                 probe = torch.ones(1, dtype=torch.float64, device=dev)

@@ -241,6 +241,10 @@ struct rp_gather_plan {
     rp::PiecePlanMem mem;  // device, caller-owned (inside d_plan_mem)
 };
 
+#ifndef RP_LONG_GRID
+#define RP_LONG_GRID 512  // workgroups of k_rewalk_long (grid-stride over the queue of long too-close-to-call ORFs, usually empty)
+#endif
+
 namespace {
 
 constexpr size_t kPlanHeader = 128;
@@ -354,7 +358,7 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
         // 4. the long too-close-to-call ORFs it queued (usually none): a workgroup each
         if (total_nt > rp::kLongWalk) {
             const long long cap = rp::long_capacity(total_nt);
-            const dim3 lgrid((unsigned)(cap < 512 ? cap : 512));
+            const dim3 lgrid((unsigned)(cap < RP_LONG_GRID ? cap : RP_LONG_GRID));
             if (gather != nullptr)
                 RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_rewalk_long<TILE, rp::CoverageSource>), lgrid, dim3(rp::kLongBlock), 0, stream,
                                                       rp::CoverageSource{d_counts, piece_plan_of(gather)}, d_offsets, plan, ws, out, fp));
