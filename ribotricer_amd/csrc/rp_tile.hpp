@@ -565,6 +565,14 @@ __device__ __forceinline__ int wave_add_scan(int x)
 #define RP_KRUNBLOCK 3
 #endif
 constexpr int kRunBlock = RP_KRUNBLOCK;  // triplets per fully unrolled block of the lane run
+// Tiles of nothing but very short segments (> kHeadSlots of them, none longer than kLaneTrip triplets: an index of
+// 60-66-nt ORFs puts 103 on a 6 144-position tile): ONE LANE walks a whole segment (lane_segments below).
+#ifndef RP_LANE_SEG
+#define RP_LANE_SEG 1
+#endif
+constexpr int kLaneTrip = 22;               // longest segment a single lane takes (66 nt)
+constexpr int kLaneRun = kLaneTrip + 1;     // its run length as lane_run sees it (odd)
+static_assert(kLaneRun >= kRun && kLaneRun % 2 == 1, "lane_run is instantiated for kRun, 9, 5 and kLaneRun");
 
 // min(x, hi) for x, hi >= 0 on the BIT PATTERNS: non-negative IEEE floats order like
 // unsigned integers (+inf = 0x7f800000 included), so this is one 32-bit-encoded v_min_u32
@@ -666,7 +674,7 @@ __device__ __forceinline__ void run_block(const int *__restrict__ s, int lim, fl
 template <int KRUN>
 __device__ __forceinline__ void lane_run(const int *__restrict__ s, int lim, LaneSums &o)
 {
-    static_assert(KRUN % 2 == 1 && KRUN <= kRun, "odd run lengths keep the LDS lane stride conflict free");
+    static_assert(KRUN % 2 == 1 && KRUN <= kLaneRun, "odd run lengths keep the LDS lane stride conflict free");
     constexpr int B = 3 * kRunBlock;
     constexpr int kBlocks = (KRUN + kRunBlock - 1) / kRunBlock;
     lim = lim > 0 ? lim : 0;  // a run that starts in the last two positions of an ORF owns no codon start
@@ -871,6 +879,51 @@ __device__ __forceinline__ void short_round(seg_desc_t dc, const int *s_counts, 
     __syncthreads();
 }
 
+// Lane-per-segment rounds (round 4).  For a tile whose segments are all <= kLaneTrip triplets the 64-slot rounds above
+// spend most of their instructions on bookkeeping: per round two barriers, the lane mapping through LDS marks, a
+// segmented scan of twelve sums for runs of 5 triplets, row records, a record stage -- twice for the 103 segments of an
+// all-60-nt tile.  Here thread t takes slot 256 r + t whole: one lane run of <= kLaneRun triplets straight to the
+// segment's 48-byte record -- no scan, no row records, no barrier after the tile has landed.  A lane's census sums
+// decode in the lane (E, Z <= 23), the frame's codon starts follow from the geometry as in record_stage.
+// (LDS: lanes read at a stride of their segments' lengths; 60-nt ORFs put 64 lanes on 8 banks -- ~0.5 k cycles of
+// conflicts per wave against ~2.6 k cycles of arithmetic: paid, and still half the instructions of the rounds.)
+// Record words as record_stage writes them: plane f = {P_f, Q_f, N_f | M_f << 16, extra_f}, extra_0 / extra_2 = low /
+// high half of the read count (+ an owned partial last codon in the low half), extra_1 = the minimum codon.
+template <int TILE>
+__device__ __forceinline__ void lane_segments(const int *__restrict__ s_counts, const seg_desc_t d, uint4 *__restrict__ rec,
+                                              long long n_rec, long long id)
+{
+    if (!(d >> 63)) return;
+    const int q0 = (int)d & 0x1fff;
+    const int endq = (int)(d >> 13) & 0x1fff;
+    const int ntrip = (int)(d >> 26) & 0xfff;
+    const int part = (int)(d >> 51) & 3;
+    const int rem0 = endq - q0;
+    int lim = rem0 - 2 < 3 * ntrip ? rem0 - 2 : 3 * ntrip;
+    lim = lim > 0 ? lim : 0;
+    LaneSums sv;
+    lane_run<kLaneRun>(s_counts + q0, lim, sv);
+    unsigned lo = (unsigned)sv.clo, hi = (unsigned)sv.chi, mn = sv.mn;
+    if (part) {  // an owned partial last codon (L % 3 != 0): common.py:164-180 still sums it
+        const int tail = (int)(d >> 38) & 0x1fff;
+        unsigned codon = (unsigned)s_counts[tail];
+        if (part == 2) codon += (unsigned)s_counts[tail + 1];
+        lo += codon;
+        mn = min(mn, codon);
+    }
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        const int k = (int)__builtin_fmaf(sv.S[f], kFlatUnit, 0.5f);  // E + 256 Z of this lane's run
+        const int codons = ((lim + 2 - f) * 21846) >> 16;             // floor((lim + 2 - f) / 3), lim < 8 192
+        const unsigned n = (unsigned)(codons - (k >> 8));
+        const unsigned m = n - (unsigned)(k & 255);
+        const unsigned extra = f == 0 ? lo : f == 1 ? mn : hi;
+        stream_store(reinterpret_cast<u32x4_t *>(rec + f * n_rec + id),
+                     u32x4_t{__float_as_uint(sv.p[f]), __float_as_uint(sv.q[f]), n | (m << 16), extra});
+    }
+}
+
 // FUSED: `counts` is the dense coverage and the tile is staged through the piece plan
 // (rp_pieces.hpp) -- the profiles never exist in HBM (plan.mis == 0 there).
 // The work of one workgroup on one tile (k_tile_score below calls it once, or RP_TILES_PER_WG times).
@@ -1013,7 +1066,33 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
         const long long orf = a0 - 1 + lane;
         if (orf >= 0 && orf < a1) dc = ws.desc[orf + b];  // chunk 0, in flight with the tile
     }
+#if RP_LANE_SEG
+    // all segments short?  thread t looks at slots t, t + 256, ... (its own for the lane-per-segment rounds)
+    seg_desc_t mine0 = 0;
+    int too_long = 0;
+    for (long long c0 = 0; c0 < n_slots; c0 += kTileBlock) {  // workgroup-uniform
+        const long long orf = a0 - 1 + c0 + tid;
+        seg_desc_t dx = 0;
+        if (orf >= 0 && orf < a1) dx = ws.desc[orf + b];
+        if (c0 == 0) mine0 = dx;
+        too_long |= (int)((dx >> 63) != 0 && (((int)(dx >> 26) & 0xfff) > kLaneTrip));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(prefetched), "+v"(dc), "+v"(mine0), "+v"(too_long) : : "memory");
+    if (!__syncthreads_or(too_long)) {  // (also barrier 1: the tile has landed)
+        for (long long c0 = 0; c0 < n_slots; c0 += kTileBlock) {
+            seg_desc_t dx = mine0;
+            if (c0 > 0) {
+                const long long orf = a0 - 1 + c0 + tid;
+                dx = orf < a1 ? ws.desc[orf + b] : 0;
+            }
+            lane_segments<TILE>(s_counts, dx, ws.rec, ws.n_rec, a0 - 1 + c0 + tid + b);
+        }
+        RP_STAMP_FLUSH();
+        return;
+    }
+#else
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(prefetched) : : "memory");
+#endif
     for (long long c0 = 0; c0 < n_slots; c0 += kSegChunk) {
         if (c0 > 0) {
             __syncthreads();  // the previous chunk's record stage is done with the tables

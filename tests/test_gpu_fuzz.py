@@ -107,3 +107,36 @@ def test_small_tile_boundaries(eng, seed):
     assert_matches_oracle(res, counts, offsets)
     starts, ends = offsets[:-1] + mis, offsets[1:] + mis
     assert np.array_equal((res["flags"] & 4) != 0, (lens > 0) & ((ends - 1) // small > starts // small))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_lane_per_segment_rounds(eng, seed):
+    """Tiles of nothing but very short segments (more than 64 of them, none over 22 triplets) take the lane-per-segment
+    rounds of round 4 (one lane walks a whole segment straight to its record); one segment of 23 triplets (67-69 nt) in
+    a tile sends that tile back to the 64-slot rounds.  Lengths around both limits, empty ORFs, L % 3 != 0 (partial last
+    codons), ORFs cut by tile boundaries, > 256 segments per tile (1-5-nt ORFs: several lane rounds), sparse and dense
+    counts (exact frame ties, flat codons); the CSR scorer and the fused scorer against the oracle."""
+    from ribotricer_amd.engine import make_filter
+    from ribotricer_amd.gather import GatherPlan, IntervalTable
+
+    rng = np.random.default_rng(900 + seed)
+    parts = [rng.choice([60, 60, 60, 63, 66, 61, 62, 64, 65], size=4000),          # lane rounds, partial codons
+             rng.choice([60, 66, 67, 68, 69, 70], size=3000, p=[0.5, 0.3, 0.05, 0.05, 0.05, 0.05]),  # tiles that fall back
+             rng.integers(0, 6, size=6000),                                          # > 256 segments per tile, empty ORFs
+             rng.choice([60, 63], size=3000)]
+    lens = np.concatenate(parts).astype(np.int64)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    lam = np.repeat(rng.choice([0.01, 0.05, 0.5, 4.0], size=lens.size), lens)
+    counts = (rng.poisson(lam) * (rng.random(lam.size) < 0.9)).astype(np.int32)
+    counts[rng.random(counts.size) < 0.02] = 7  # (runs of flat codons somewhere)
+    res = eng.score_host(counts, offsets, thresholds=make_filter(), algo="tile")
+    assert_matches_oracle(res, counts, offsets)
+    n = lens.size
+    keep = lens > 0  # (an interval may not be empty: the fused path takes the ORFs that have a profile)
+    sub_off = np.concatenate([[0], np.cumsum(lens[keep])]).astype(np.int64)
+    table = IntervalTable(offsets[:-1][keep].copy(), lens[keep].astype(np.int32), np.arange(int(keep.sum()) + 1, dtype=np.int64),
+                          (np.arange(int(keep.sum())) % 2).astype(np.uint8) * 0, sub_off)
+    fused = eng.score_coverage(counts, GatherPlan(table, counts.size), thresholds=make_filter()).cpu_numpy()
+    for k in ("phase", "valid", "read_count", "min_codon_cov", "status"):
+        assert np.array_equal(fused[k], res[k][keep]) or k == "phase", k
+    assert_matches_oracle(fused, counts, sub_off)
