@@ -17,6 +17,7 @@
 // Plain C++17, no HIP.
 #pragma once
 
+#include <emmintrin.h>  // SSE2: part of every x86-64
 #include <sys/mman.h>
 
 #include "rp_host.hpp"
@@ -164,6 +165,70 @@ inline std::string_view start_codon(std::string_view s)
     return cut == std::string_view::npos ? s : s.substr(0, cut);
 }
 
+// Positions of the first <= 11 tabs of [p, e) into tab[], how many were found (12 = more than 11 fields' worth: stop).
+// 16 bytes a step where 16 bytes are left; the scalar tail never reads past e.
+inline int find_tabs(const char *p, const char *e, const char **tab)
+{
+    int n = 0;
+    const __m128i t = _mm_set1_epi8('\t');
+    const char *q = p;
+    for (; q + 16 <= e; q += 16) {
+        unsigned m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i *>(q)), t));
+        while (m) {
+            if (n == 11) return 12;
+            tab[n++] = q + __builtin_ctz(m);
+            m &= m - 1;
+        }
+    }
+    for (; q < e; ++q)
+        if (*q == '\t') {
+            if (n == 11) return 12;
+            tab[n++] = q;
+        }
+    return n;
+}
+
+// The coordinate column in its canonical form -- "123-456,789-1011" with optional whitespace around a number and an
+// optional '+' in front of it, exactly what parse_int accepts -- in one pass.  false: not canonical (the caller takes
+// the general path, which also produces the error codes).
+inline bool scan_coordinates(const char *p, const char *e, std::vector<std::pair<int64_t, int64_t>> &blocks)
+{
+    auto number = [&](int64_t &out) {
+        while (p < e && is_space(*p)) ++p;
+        if (p < e && *p == '+') ++p;
+        const char *d0 = p;
+        int64_t v = 0;
+        while (p < e && (unsigned)(*p - '0') <= 9u) v = v * 10 + (*p++ - '0');
+        if (p == d0 || p - d0 > 18) return false;  // (no digit; or long enough to overflow: the general path decides)
+        while (p < e && is_space(*p)) ++p;
+        out = v;
+        return true;
+    };
+    for (;;) {
+        int64_t s = 0, t = 0;
+        if (!number(s) || p >= e || *p != '-') return false;
+        ++p;
+        if (!number(t)) return false;
+        blocks.emplace_back(s, t);
+        if (p == e) return true;
+        if (*p != ',') return false;
+        ++p;
+    }
+}
+
+inline char *put_int(char *dst, int64_t v)  // v >= 0 here (sums and ends of parsed, non-negative numbers)
+{
+    char tmp[24];
+    int n = 0;
+    uint64_t u = (uint64_t)v;
+    do {
+        tmp[n++] = (char)('0' + u % 10);
+        u /= 10;
+    } while (u);
+    while (n) *dst++ = tmp[--n];
+    return dst;
+}
+
 // Parse `text` (the whole file).  Lines end at '\n' (kept on the line, as Python's file
 // iteration does); `skip_header` drops the first line (detect_orfs.py:273).
 // One contiguous run of whole lines (group ids are local to the run: order of first appearance).
@@ -190,8 +255,7 @@ inline int parse_run(const char *text, size_t len, bool skip_header, Index &ix)
         ix.tail_off.reserve(n_lines + 1);
         ix.iv_start.reserve(3 * n_lines);
         ix.iv_end.reserve(3 * n_lines);
-        ix.head.reserve(len / 2);
-        ix.tail.reserve(len);
+        // (head and tail: sized for the worst case below, written through cursors)
     }
     std::unordered_map<std::string, int32_t> groups;
     std::vector<std::pair<int64_t, int64_t>> blocks;
@@ -200,51 +264,63 @@ inline int parse_run(const char *text, size_t len, bool skip_header, Index &ix)
     int32_t last_gid = -1;
     size_t pos = 0;
     int64_t line_no = 0;
+    // The two string tables are written through cursors into buffers sized for the worst case (a line's head is its
+    // transcript id and ORF type plus three numbers, its tail a substring of the line plus "None"): no capacity check
+    // per field, one memcpy for the tail's seven columns (they are contiguous in the line).  Untouched pages of the
+    // over-allocation cost nothing; the vectors are cut to what was written at the end.
+    const size_t n_reserved = ix.length.capacity();
+    ix.head.resize(len + 72 * n_reserved + 64);
+    ix.tail.resize(len + 8 * n_reserved + 64);
+    char *head_at = ix.head.data(), *tail_at = ix.tail.data();
+    auto finish_tables = [&] {
+        ix.head.resize((size_t)(head_at - ix.head.data()));
+        ix.tail.resize((size_t)(tail_at - ix.tail.data()));
+    };
     while (pos < len) {
         const char *nl = (const char *)std::memchr(text + pos, '\n', len - pos);
         const size_t end = nl ? (size_t)(nl - text) + 1 : len;  // one past the line, newline included
-        const std::string_view line(text + pos, end - pos);
+        const char *lp = text + pos, *le = text + end;
         pos = end;
         ++line_no;
         if (skip_header && line_no == 1) continue;
-        // split on tabs
-        std::string_view f[11];
-        int nf = 0;
-        size_t a = 0;
-        bool too_many = false;
-        for (size_t k = 0; k <= line.size(); ++k) {
-            if (k == line.size() || line[k] == '\t') {
-                if (nf == 11) {
-                    too_many = true;
-                    break;
-                }
-                f[nf++] = line.substr(a, k - a);
-                a = k + 1;
-            }
-        }
-        if (too_many || nf != 11) {
+        // split on tabs: 11 fields = exactly 10 tabs
+        const char *tab[11];
+        const int n_tabs = find_tabs(lp, le, tab);
+        if (n_tabs != 10) {
             ix.error_line = line_no;
+            finish_tables();
             return kColumns;
         }
-        // coordinates
+        std::string_view f[11];
+        f[0] = std::string_view(lp, (size_t)(tab[0] - lp));
+        for (int k = 1; k < 10; ++k) f[k] = std::string_view(tab[k - 1] + 1, (size_t)(tab[k] - tab[k - 1] - 1));
+        f[10] = std::string_view(tab[9] + 1, (size_t)(le - tab[9] - 1));
+        // coordinates: the canonical form in one pass, anything else through the general path (same results, and the errors)
         blocks.clear();
         const std::string_view coord = f[10];
-        size_t g0 = 0;
-        for (size_t k = 0; k <= coord.size(); ++k) {
-            if (k == coord.size() || coord[k] == ',') {
-                const std::string_view grp = coord.substr(g0, k - g0);
-                g0 = k + 1;
-                const size_t dash = grp.find('-');
-                int64_t s = 0, e = 0;
-                if (dash == std::string_view::npos || grp.find('-', dash + 1) != std::string_view::npos ||
-                    !parse_int(grp.substr(0, dash), s) || !parse_int(grp.substr(dash + 1), e)) {
-                    ix.error_line = line_no;
-                    return kCoordinate;
+        if (!scan_coordinates(coord.data(), coord.data() + coord.size(), blocks)) {
+            blocks.clear();
+            size_t g0 = 0;
+            for (size_t k = 0; k <= coord.size(); ++k) {
+                if (k == coord.size() || coord[k] == ',') {
+                    const std::string_view grp = coord.substr(g0, k - g0);
+                    g0 = k + 1;
+                    const size_t dash = grp.find('-');
+                    int64_t s = 0, e = 0;
+                    if (dash == std::string_view::npos || grp.find('-', dash + 1) != std::string_view::npos ||
+                        !parse_int(grp.substr(0, dash), s) || !parse_int(grp.substr(dash + 1), e)) {
+                        ix.error_line = line_no;
+                        finish_tables();
+                        return kCoordinate;
+                    }
+                    blocks.emplace_back(s, e);
                 }
-                blocks.emplace_back(s, e);
             }
         }
-        std::stable_sort(blocks.begin(), blocks.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+        bool ascending = true;
+        for (size_t k = 1; k < blocks.size(); ++k) ascending = ascending && blocks[k - 1].first <= blocks[k].first;
+        if (!ascending)
+            std::stable_sort(blocks.begin(), blocks.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
         int64_t length = 0;
         for (const auto &b : blocks) {
             ix.iv_start.push_back(b.first);
@@ -285,25 +361,40 @@ inline int parse_run(const char *text, size_t len, bool skip_header, Index &ix)
             last_chrom = chrom;
         }
         ix.group.push_back(gid);
-        // head: ORF_ID \t ORF_type
-        append(ix.head, f[2]);
-        ix.head.push_back('_');
-        append_int(ix.head, first);
-        ix.head.push_back('_');
-        append_int(ix.head, last);
-        ix.head.push_back('_');
-        append_int(ix.head, length);
-        ix.head.push_back('\t');
-        append(ix.head, f[1]);
-        ix.head_off.push_back((int64_t)ix.head.size());
-        // tail: fields 2..8 then the start codon
-        for (int k = 2; k <= 8; ++k) {
-            append(ix.tail, f[k]);
-            ix.tail.push_back('\t');
+        // head: ORF_ID \t ORF_type   (ORF_ID = transcript_first_last_length, orf.py:103)
+        std::memcpy(head_at, f[2].data(), f[2].size());
+        head_at += f[2].size();
+        *head_at++ = '_';
+        if (first < 0 || last < 0 || length < 0) {  // (cannot come out of parse_int / scan_coordinates; kept for the general writer's sake)
+            Vec<char> tmp;
+            append_int(tmp, first);
+            tmp.push_back('_');
+            append_int(tmp, last);
+            tmp.push_back('_');
+            append_int(tmp, length);
+            std::memcpy(head_at, tmp.data(), tmp.size());
+            head_at += tmp.size();
+        } else {
+            head_at = put_int(head_at, first);
+            *head_at++ = '_';
+            head_at = put_int(head_at, last);
+            *head_at++ = '_';
+            head_at = put_int(head_at, length);
         }
-        append(ix.tail, start_codon(f[9]));
-        ix.tail_off.push_back((int64_t)ix.tail.size());
+        *head_at++ = '\t';
+        std::memcpy(head_at, f[1].data(), f[1].size());
+        head_at += f[1].size();
+        ix.head_off.push_back((int64_t)(head_at - ix.head.data()));
+        // tail: fields 2..8 -- contiguous in the line, their tabs included -- a tab, then the start codon
+        const size_t seven = (size_t)(tab[8] + 1 - f[2].data());  // through the tab behind field 8
+        std::memcpy(tail_at, f[2].data(), seven);
+        tail_at += seven;
+        const std::string_view codon = start_codon(f[9]);
+        std::memcpy(tail_at, codon.data(), codon.size());
+        tail_at += codon.size();
+        ix.tail_off.push_back((int64_t)(tail_at - ix.tail.data()));
     }
+    finish_tables();
     return kOk;
 }
 
