@@ -1185,7 +1185,11 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score_probe(c
 // piece by piece and coalesced ('-' strand pieces backwards): walk and replay then read plain
 // LDS instead of finding the piece of every position they touch.
 // ---------------------------------------------------------------------------
-constexpr int kFinishBlock = kWave;  // one wave per workgroup: a re-walk holds up nobody else
+#ifndef RP_FINISH_BLOCK
+#define RP_FINISH_BLOCK 64
+#endif
+constexpr int kFinishBlock = RP_FINISH_BLOCK;  // threads per workgroup; the waves of a workgroup never synchronise (a re-walk holds up nobody else)
+static_assert(kFinishBlock % kWave == 0 && kFinishBlock <= 1024, "whole waves");
 #ifndef RP_STAGE_NT
 #define RP_STAGE_NT 1016
 #endif
@@ -1249,10 +1253,13 @@ __global__ __launch_bounds__(kFinishBlock, RP_FINISH_WAVES) void k_orf_finish(So
                                                              FilterParams fp)
 {
     constexpr bool kStaged = sizeof(Source) != sizeof(CsrSource);  // the fused path reads through the gather plan
-    __shared__ ReplayLds s_replay;  // (one wave per workgroup)
-    __shared__ int s_stage[kStaged ? kStageNt + 8 : 1];
-    const int lane = threadIdx.x;
-    const long long orf = (long long)blockIdx.x * kFinishBlock + lane;
+    constexpr int kWaves = kFinishBlock / kWave;
+    __shared__ ReplayLds s_replay_w[kWaves];  // (per wave: the waves of a workgroup work independently)
+    __shared__ int s_stage_w[kWaves][kStaged ? kStageNt + 8 : 1];
+    const int lane = threadIdx.x & (kWave - 1);
+    ReplayLds &s_replay = s_replay_w[threadIdx.x / kWave];
+    int *const s_stage = s_stage_w[threadIdx.x / kWave];
+    const long long orf = (long long)blockIdx.x * kFinishBlock + threadIdx.x;
     long long beg = 0, len = 0, count = 0;
     int min_codon = RP_MIN_CODON_COV_EMPTY;
     unsigned split = 0;
