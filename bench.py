@@ -379,19 +379,41 @@ def launch_only(rank: int, world: int) -> None:
     dist.all_gather_object(ranks, {"rank": rank, "orfs": hi - lo, "nt": int(offsets_set[hi] - offsets_set[lo]),
                                    "local_rank": int(os.environ.get("LOCAL_RANK", "-1")), "pid": os.getpid()})
     if rank == 0:
-        print(json.dumps({"launch_only": True, "n_gpus": world, "max_over_ranks": float(t.item()), "per_rank": ranks,
+        emit_line(json.dumps({"launch_only": True, "n_gpus": world, "max_over_ranks": float(t.item()), "per_rank": ranks,
                           "orfs_total": n_set, "nt_total": int(offsets_set[-1]),
-                          "self_launched": os.environ.get("RP_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+                          "self_launched": os.environ.get("RP_BENCH_SELF_LAUNCHED") == "1"}))
     dist.barrier()
     dist.destroy_process_group()
     if os.environ.get("RP_BENCH_LAUNCH_ONLY_FAIL_RANK") == str(rank):  # (the launcher's status relay, under test)
         sys.exit(7)
 
 
+_json_out = None
+
+
+def claim_stdout() -> None:
+    """The process's stdout is for the ONE JSON line.  Libraries write there too -- RCCL prints its version banner
+    through C stdio, which on a pipe is flushed at exit, i.e. BEHIND the JSON line -- so file descriptor 1 is pointed at
+    stderr for everybody else (C level: every library; Python's own `print` included) and the line goes out through a
+    private duplicate of the original."""
+    global _json_out
+    if _json_out is None:
+        sys.stdout.flush()
+        _json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit_line(text: str) -> None:
+    out = _json_out if _json_out is not None else sys.stdout
+    out.write(text + "\n")
+    out.flush()
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
+    claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -687,7 +709,7 @@ def main():
                 dist.send(mine[k].contiguous().cpu(), dst=0, group=side)
         barrier()
         if rank == 0 and not verify["ok"]:
-            print(json.dumps({"error": "sharded results differ from the one-GPU result", "verify": verify}), flush=True)
+            emit_line(json.dumps({"error": "sharded results differ from the one-GPU result", "verify": verify}))
             sys.exit(2)
 
     fused = fused_nested = None
@@ -706,7 +728,7 @@ def main():
                 fused_nested = fused_section(args, eng, dev, thresholds, n_set, layout="nested")
         bad = (verify is not None and not verify["ok"]) or any(f is not None and "verify" in f and not f["verify"]["ok"] for f in (fused, fused_nested))
         if bad:
-            print(json.dumps({"error": "results differ from the oracle", "verify": verify, "fused": fused, "fused_nested": fused_nested}), flush=True)
+            emit_line(json.dumps({"error": "results differ from the oracle", "verify": verify, "fused": fused, "fused_nested": fused_nested}))
             sys.exit(2)
 
     stream_read = None
@@ -840,7 +862,7 @@ def main():
             result["cpu_baseline_1core"] = one
             result["cpu_closed_form_c"] = extra
             result["cpu_reference_arithmetic_cpp"] = exact
-        print(json.dumps(result), flush=True)
+        emit_line(json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

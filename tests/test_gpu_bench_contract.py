@@ -85,9 +85,22 @@ def _bare_bench(n, orfs, extra=(), env_extra=None):
         capture_output=True, text=True, timeout=1500, cwd=REPO, env=env,
     )
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1, lines
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), lines  # stdout is the ONE JSON line (RCCL's banner and the like go to stderr)
     return json.loads(lines[0])
+
+
+def test_a_failing_rccl_probe_falls_back_to_gloo():
+    """RCCL forced on two ranks that share the one GPU ("Duplicate GPU detected"): the probe fails on both ranks, they
+    agree over gloo, and the run goes on -- the scaling line is still produced and says what happened.  (A node whose
+    RCCL cannot come up must not cost the 1/2/4/8 curve.)"""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs ranks sharing a GPU to make RCCL fail")
+    d = _bare_bench(2, 200000, env_extra={"RP_BENCH_BACKEND": "nccl"})
+    assert d["n_gpus"] == 2 and d["verify"]["ok"] is True and d["verify"]["orfs_checked"] == 200000
+    assert d["config"]["control_backend"].startswith("gloo (RCCL probe failed")
 
 
 @pytest.mark.parametrize("n", [2, 8])
