@@ -289,6 +289,19 @@ int rp_gather_plan_create_dev(int device, const int64_t *d_iv_start, const int32
 void rp_gather_plan_free(rp_gather_plan *plan);
 
 /*
+ * The profiles of a SUBSET of the index's ORFs through the plan (default mode of the export prints the translating
+ * ORFs only: detect_orfs.py:301-303 skips the others before `profile` is formatted, :323): one wave per chosen ORF.
+ *   d_chosen       int64[n_chosen]      ORF numbers (any order; each < n_orfs of the plan -- not checked)
+ *   d_out_offsets  int64[n_chosen]      where each chosen ORF's profile starts in d_counts (the caller's prefix sum of
+ *                                       the chosen ORFs' lengths)
+ *   d_counts       int32[sum of the chosen lengths]
+ * Asynchronous.  Same bytes as rp_gather_profiles_dev over the sub-table of the chosen ORFs.
+ */
+int rp_gather_selected_plan_dev(const rp_gather_plan *plan, const int32_t *d_coverage, int64_t coverage_len,
+                                const int64_t *d_chosen, int64_t n_chosen, const int64_t *d_out_offsets,
+                                int32_t *d_counts, void *hip_stream);
+
+/*
  * rp_gather_profiles_dev through a gather plan: one workgroup per tile stages its positions
  * from the coverage with LDS-DMA (64 consecutive positions of one piece per instruction) and
  * writes them out 16 bytes per lane.  d_counts: int32[total_nt], 16-byte aligned.  Asynchronous.

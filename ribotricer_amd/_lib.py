@@ -81,6 +81,7 @@ SYMBOLS = {
     "rp_gather_plan_create_dev": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, ctypes.c_size_t, _vp, ctypes.POINTER(_vp)]),
     "rp_gather_plan_free": (None, [_vp]),
     "rp_gather_profiles_plan_dev": (_int, [_vp, _vp, _i64, _vp, _vp]),
+    "rp_gather_selected_plan_dev": (_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "rp_phase_score_coverage_dev": (_int, [_int, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(FilterParams),
                                            _vp, ctypes.c_size_t, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_float * 4)]),
     "rp_validate_csr_dev": (_int, [_int, _vp, _vp, _i64, _i64, _vp]),

@@ -785,6 +785,26 @@ int rp_gather_profiles_plan_dev(const rp_gather_plan *plan, const int32_t *d_cov
     return RP_OK;
 }
 
+int rp_gather_selected_plan_dev(const rp_gather_plan *plan, const int32_t *d_coverage, int64_t coverage_len,
+                                const int64_t *d_chosen, int64_t n_chosen, const int64_t *d_out_offsets,
+                                int32_t *d_counts, void *hip_stream)
+{
+    if (!plan) return fail(RP_ERR_NULL, "plan is null");
+    if (coverage_len != plan->coverage_len) return fail(RP_ERR_ARG, "plan was built for a coverage of %lld positions, got %lld", plan->coverage_len, (long long)coverage_len);
+    if (n_chosen < 0) return fail(RP_ERR_SIZE, "n_chosen=%lld must be >= 0", (long long)n_chosen);
+    if (n_chosen == 0) return RP_OK;
+    if (!d_coverage || !d_chosen || !d_out_offsets || !d_counts) return fail(RP_ERR_NULL, "d_coverage / d_chosen / d_out_offsets / d_counts is null");
+    RP_ON_DEVICE(plan->device);
+    const long long per_block = rp::kSelectedBlock / 64;
+    const long long grid = (n_chosen + per_block - 1) / per_block;
+    if (grid > 0x7fffffffLL) return fail(RP_ERR_SIZE, "too many ORFs chosen for one launch");
+    hipLaunchKernelGGL(rp::k_gather_selected, dim3((unsigned)grid), dim3(rp::kSelectedBlock), 0, (hipStream_t)hip_stream, d_coverage,
+                       piece_plan_of(plan), reinterpret_cast<const long long *>(d_chosen), (long long)n_chosen,
+                       reinterpret_cast<const long long *>(d_out_offsets), d_counts);
+    RP_HIP(hipGetLastError());
+    return RP_OK;
+}
+
 int rp_phase_score_coverage_dev(int device, const int32_t *d_coverage, int64_t coverage_len,
                                 const int64_t *d_offsets, int64_t n_orfs, int64_t total_nt, double *d_phase,
                                 int32_t *d_valid, int64_t *d_read_count, int32_t *d_min_codon_cov,

@@ -502,6 +502,36 @@ struct CoverageSource {
 };
 
 // ---------------------------------------------------------------------------------------
+// The profiles of a SUBSET of the ORFs (default mode prints the translating ORFs only, detect_orfs.py:301-303:
+// ~14-23 % of an index) straight through the plan's pieces: one wave per chosen ORF copies its pieces, coalesced,
+// '-' strand pieces backwards, to out[out_off[w] ...].  Nothing of the interval table is needed on the host (round 3
+// built a sub-table of the chosen ORFs with numpy and uploaded it: 0.1 s of a 0.8 s export).
+// ---------------------------------------------------------------------------------------
+constexpr int kSelectedBlock = 256;
+
+__global__ __launch_bounds__(kSelectedBlock) void k_gather_selected(const int32_t *__restrict__ cov, PiecePlan pp,
+                                                                    const long long *__restrict__ chosen, long long n_chosen,
+                                                                    const long long *__restrict__ out_off, int32_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long long w = (long long)blockIdx.x * (kSelectedBlock / 64) + (threadIdx.x >> 6);
+    if (w >= n_chosen) return;  // (wave-uniform)
+    const long long orf = chosen[w];
+    const long long j0 = pp.orf_piece[orf], j1 = pp.orf_piece[orf + 1];
+    if (j1 <= j0) return;
+    const long long beg = (long long)(pp.start[j0] & ~kPieceNeg);  // the ORF's first profile position
+    int32_t *dst = out + out_off[w] - beg;
+    for (long long j = j0; j < j1; ++j) {  // wave-uniform
+        const unsigned long long sw = pp.start[j];
+        const long long s = (long long)(sw & ~kPieceNeg);
+        const long long e = (long long)(pp.start[j + 1] & ~kPieceNeg);  // (the next piece of the profile space, or the sentinel)
+        const long long base = pp.base[j];
+        const bool neg = (sw & kPieceNeg) != 0;
+        for (long long pos = s + lane; pos < e; pos += 64) dst[pos] = cov[neg ? base - pos : base + pos];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // The CSR `counts` array of a whole index (report_all mode, detect_orfs.py:301-324 prints
 // every profile): a workgroup stages its tile exactly as the fused scorer does and writes
 // it out, 16 bytes per lane.  8 bytes of traffic per nucleotide, the coverage read once.

@@ -387,7 +387,7 @@ PLACE_WORKSPACE_MIN_NT = 64 << 20  # below this a step is launch-bound: nothing 
 def _place_workspace_for(table) -> bool:
     import os
 
-    return os.environ.get("RIBOTRICER_AMD_PLACE_WORKSPACE", "1") != "0" and int(table.offsets[-1]) >= PLACE_WORKSPACE_MIN_NT
+    return os.environ.get("RIBOTRICER_AMD_PLACE_WORKSPACE", "0") == "1" and int(table.offsets[-1]) >= PLACE_WORKSPACE_MIN_NT
 
 
 def _shards(extras: dict, kind: str, devices, build):
@@ -484,10 +484,13 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     sharded = devices is not None and len(devices) > 1
     extras["samples"] = extras.get("samples", 0) + 1
     if plan is not None and not sharded and "workspace_placement" not in extras and extras["samples"] >= 2 and _place_workspace_for(table):
-        # once per cached index, when its SECOND sample arrives (a job that scores one index against many samples: the
-        # search costs 0.07 s and gains a fraction of a millisecond per sample, so a single-sample run skips it): put
-        # the record workspace where its writes cost the coverage reads least (engine.tune_workspace; nothing but ONE
-        # workspace stays allocated).  RIBOTRICER_AMD_PLACE_WORKSPACE=0 switches it off.
+        # OPT-IN (RIBOTRICER_AMD_PLACE_WORKSPACE=1), once per cached index when its second sample arrives: put the record
+        # workspace where its writes cost the coverage reads least (engine.tune_workspace; nothing but ONE workspace stays
+        # allocated).  Off by default because it does not pay here: a human-sized dense coverage (25-85 GB) spans every
+        # class of physical memory, so the candidates differ by 2-3 % of a 3 ms kernel (0.1 ms per sample), while the
+        # search costs 0.07 s -- 0.56 s on boxes whose driver takes 20 ms per GiB allocated (profiles/r04_placement_check.txt,
+        # r04_export_e2e_11M_selected_gather.json).  The CSR path with a 16 GB counts array is where it gains 14 %:
+        # bench.py runs it there.
         extras["workspace_placement"] = get_engine(device).tune_workspace(
             coverage, thresholds=make_filter(phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio,
                                              min_density_over_orf), gather_plan=plan, tries=3, spread=0.03)  # (a coverage far larger than a memory class: little to find, profiles/r04_placement_check.txt)
@@ -518,7 +521,7 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     if sharded:
         from .engine import CoverageShards
 
-        del plan  # per-device windows, gather plans and tile plans: once per index, not per sample
+        # per-device windows, gather plans and tile plans: once per index, not per sample
         res = _shards(extras, "coverage", devices, lambda: CoverageShards(table, devices, coverage.numel())).score(coverage, thresholds)
     else:
         eng = get_engine(device)
@@ -530,10 +533,13 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
         rescore_big_count_orfs(res, orfs_touching(table, big["positions"]), coverage_profiles_of(coverage, table, device), thresholds, device)
     t = lap("fused_score_results_d2h", t)
     keep = res["status"] != 0
-    chosen = np.flatnonzero(keep)
-    d_counts, _ = gather_profiles_device(coverage, select_orfs(table, chosen), device)
-    offsets = np.zeros(index.n_orfs + 1, np.int64)
-    np.cumsum(np.where(keep, np.diff(table.offsets), 0), out=offsets[1:])
+    if plan is not None and not sharded:  # through the plan's pieces: ids and prefix sums on the device (GatherPlan.gather_selected)
+        d_counts, offsets = plan.gather_selected(coverage, keep)
+    else:
+        chosen = np.flatnonzero(keep)
+        d_counts, _ = gather_profiles_device(coverage, select_orfs(table, chosen), device)
+        offsets = np.zeros(index.n_orfs + 1, np.int64)
+        np.cumsum(np.where(keep, np.diff(table.offsets), 0), out=offsets[1:])
     if profiles_on_device:
         lap("translating_profiles_gather", t)
         return d_counts, offsets, res

@@ -25,6 +25,7 @@ def child(n_orfs: int) -> None:
     import numpy as np
     import torch
 
+    os.environ["RIBOTRICER_AMD_PLACE_WORKSPACE"] = "1"  # (opt-in in the product: this script measures what it would buy)
     from ribotricer_amd import detect_orfs as d
     from ribotricer_amd.alignments import MergedColumns, build_coverage_device
     from ribotricer_amd.engine import get_engine, make_filter

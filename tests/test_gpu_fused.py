@@ -62,6 +62,32 @@ def test_tile_gather(case):
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+def test_gather_selected_equals_the_sub_table_gather():
+    """GatherPlan.gather_selected (one wave per chosen ORF through the plan's pieces; ids and prefix sums on the device)
+    against the per-ORF gather over select_orfs' sub-table and against numpy: none / some / all ORFs chosen, multi-exon
+    and '-' strand ORFs, every other ORF with an empty range in the returned offsets."""
+    import torch
+
+    from ribotricer_amd.gather import GatherPlan, gather_profiles_device, select_orfs
+
+    rng = np.random.default_rng(77)
+    cov = rng.poisson(0.7, size=400000).astype(np.int32)
+    t = random_table(rng, cov_len=cov.size, **CASES["exons"])
+    plan = GatherPlan(t, cov.size)
+    whole = numpy_gather(cov, t)
+    n = len(t.offsets) - 1
+    for frac in (0.0, 0.2, 1.0):
+        keep = rng.random(n) < frac
+        counts, offsets = plan.gather_selected(cov, keep)
+        torch.cuda.synchronize()
+        lengths = np.diff(t.offsets)
+        assert np.array_equal(np.diff(offsets), np.where(keep, lengths, 0))
+        want = np.concatenate([whole[t.offsets[i] : t.offsets[i + 1]] for i in np.flatnonzero(keep)]) if keep.any() else np.zeros(0, np.int32)
+        assert np.array_equal(counts.cpu().numpy(), want)
+        sub, _ = gather_profiles_device(cov, select_orfs(t, np.flatnonzero(keep)))
+        assert torch.equal(sub, counts)
+
+
 def test_unplannable_tables():
     from ribotricer_amd import _lib
     from ribotricer_amd.gather import GatherPlan, IntervalTable, make_gather_plan
