@@ -534,7 +534,7 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     t = lap("fused_score_results_d2h", t)
     keep = res["status"] != 0
     if plan is not None and not sharded:  # through the plan's pieces: ids and prefix sums on the device (GatherPlan.gather_selected)
-        d_counts, offsets = plan.gather_selected(coverage, keep)
+        d_counts, offsets = plan.gather_selected(coverage, keep, lengths=np.diff(table.offsets))
     else:
         chosen = np.flatnonzero(keep)
         d_counts, _ = gather_profiles_device(coverage, select_orfs(table, chosen), device)

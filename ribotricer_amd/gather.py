@@ -206,26 +206,32 @@ class GatherPlan:
         _lib.check(_lib.load().rp_gather_profiles_plan_dev(self.handle, _ptr(cov), cov.numel(), _ptr(counts), stream))
         return counts
 
-    def gather_selected(self, coverage, keep: np.ndarray):
+    def gather_selected(self, coverage, keep: np.ndarray, lengths: np.ndarray = None):
         """Profiles of the ORFs with ``keep[i]`` true (host bool array of n_orfs), packed one after the other on the
         device: ``(counts int32 device tensor, offsets int64 host array [n_orfs + 1])`` where every other ORF has an
         empty range -- what the TSV writer takes in default mode (only translating ORFs are printed,
-        detect_orfs.py:301-303).  The selection arithmetic (ids, prefix sums) runs on the device; the host sends the
-        mask and receives the offsets."""
+        detect_orfs.py:301-303).  One wave per chosen ORF copies its pieces (``rp_gather_selected_plan_dev``); the ids and
+        the two prefix sums are three numpy passes on the host (torch ops would do them in a millisecond, but each op's
+        first use in a process costs ~0.1 s of code loading on ROCm: a single-sample run is the common case).
+        ``lengths``: profile lengths of all ORFs (default: from this plan's offsets, one device read-back)."""
         cov = _as_device(coverage, torch.int32, self.device)
-        keep_dev = torch.from_numpy(np.ascontiguousarray(keep, dtype=np.bool_)).to(self.device, non_blocking=True)
-        lengths = self.offsets[1:] - self.offsets[:-1]
-        kept_len = torch.where(keep_dev, lengths, torch.zeros_like(lengths))
-        full_off = torch.zeros(self.n_orfs + 1, dtype=torch.int64, device=self.device)
-        torch.cumsum(kept_len, 0, out=full_off[1:])
-        chosen = torch.nonzero(keep_dev).squeeze(1)
-        out_off = full_off[:-1][chosen].contiguous()
-        total = int(full_off[-1])
-        counts = torch.empty(total, dtype=torch.int32, device=self.device)
+        keep = np.ascontiguousarray(keep, dtype=np.bool_)
+        if lengths is None:
+            lengths = np.diff(self.offsets.cpu().numpy())
+        chosen = np.flatnonzero(keep)
+        sel_len = np.asarray(lengths, np.int64)[chosen]
+        out_off = np.zeros(chosen.size + 1, np.int64)
+        np.cumsum(sel_len, out=out_off[1:])
+        offsets = np.zeros(self.n_orfs + 1, np.int64)
+        offsets[chosen + 1] = sel_len
+        np.cumsum(offsets, out=offsets)
+        counts = torch.empty(int(out_off[-1]), dtype=torch.int32, device=self.device)
+        d_chosen = torch.from_numpy(chosen).to(self.device, non_blocking=True)
+        d_off = torch.from_numpy(out_off[:-1].copy()).to(self.device, non_blocking=True)
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _lib.check(_lib.load().rp_gather_selected_plan_dev(self.handle, _ptr(cov), cov.numel(), _ptr(chosen), chosen.numel(),
-                                                          _ptr(out_off), _ptr(counts), stream))
-        return counts, full_off.cpu().numpy()
+        _lib.check(_lib.load().rp_gather_selected_plan_dev(self.handle, _ptr(cov), cov.numel(), _ptr(d_chosen), d_chosen.numel(),
+                                                          _ptr(d_off), _ptr(counts), stream))
+        return counts, offsets
 
     def stats(self) -> dict:
         """Diagnostics (scripts): how the tiles of this plan are staged -- chunk rows per tile (<= 64
