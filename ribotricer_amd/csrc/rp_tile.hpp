@@ -570,7 +570,10 @@ constexpr int kRunBlock = RP_KRUNBLOCK;  // triplets per fully unrolled block of
 #ifndef RP_LANE_SEG
 #define RP_LANE_SEG 1
 #endif
-constexpr int kLaneTrip = 22;               // longest segment a single lane takes (66 nt)
+#ifndef RP_LANE_TRIP
+#define RP_LANE_TRIP 22
+#endif
+constexpr int kLaneTrip = RP_LANE_TRIP;     // longest segment a single lane takes (22 triplets = 66 nt; even: kLaneRun is odd)
 constexpr int kLaneRun = kLaneTrip + 1;     // its run length as lane_run sees it (odd)
 static_assert(kLaneRun >= kRun && kLaneRun % 2 == 1, "lane_run is instantiated for kRun, 9, 5 and kLaneRun");
 
