@@ -92,6 +92,23 @@ def parse_args():
     return ap.parse_args()
 
 
+def vbios_versions():
+    """The GPUs' VBIOS versions as the amdgpu driver reports them (sysfs; no GPU call).  Round 4 found the boxes on which
+    no workspace placement helps (kernel 2.86-3.06 ms) on 113-M355-01-1K1-020F and the ones where it does (2.6-2.7 ms) on
+    -030A (profiles/r04_box_kinds.txt): the line carries the version so that a reader can tell which kind a run met."""
+    import glob
+
+    seen = []
+    for path in sorted(glob.glob("/sys/class/drm/card*/device/vbios_version")):
+        try:
+            v = open(path).read().strip()
+        except OSError:
+            continue
+        if v and v not in seen:
+            seen.append(v)
+    return seen
+
+
 def usable_cores():
     """Cores this process may really use: the scheduler affinity, capped by the cgroup CPU quota
     (the GPU boxes show 256 CPUs with a 16-CPU quota)."""
@@ -801,6 +818,7 @@ def main():
                 "sharding": "nt-balanced contiguous ORF-index slices of one set, host-side concat, no collective on the data path"
                 if strong else "independent per-GPU sets (weak scaling)",
                 "physical_gpus": n_dev,
+                "vbios": vbios_versions(),
                 "ranks_share_gpus": world > n_dev,
                 "launcher": "bench.py self_launch" if os.environ.get("RP_BENCH_SELF_LAUNCHED") == "1" else
                             ("external (torch.distributed.run)" if world > 1 else "none"),
