@@ -159,3 +159,60 @@ def test_bench_launcher_relays_a_failing_rank():
     assert out.returncode == 7, (out.returncode, out.stderr[-2000:])
     out, lines = _bench_launch_only(2, {"RP_BENCH_LAUNCH_ONLY_FAIL_RANK": "0"}, orfs=5000)
     assert out.returncode == 7
+
+
+def test_orfs_touching_names_exactly_the_orfs_that_hold_a_position():
+    """gather.orfs_touching (who holds the coverage positions whose count passes 2^24 - 1): against a brute-force scan
+    over random interval tables with nested / overlapping ORFs, positions inside exons, in introns, at interval edges
+    and off every interval."""
+    from ribotricer_amd.gather import IntervalTable, orfs_touching
+
+    rng = np.random.default_rng(12)
+    for trial in range(20):
+        n = int(rng.integers(1, 300))
+        n_iv = rng.integers(1, 5, size=n)
+        orf_iv = np.concatenate([[0], np.cumsum(n_iv)]).astype(np.int64)
+        iv_start = rng.integers(0, 5000, size=int(orf_iv[-1])).astype(np.int64)
+        iv_len = rng.integers(1, 200, size=int(orf_iv[-1])).astype(np.int32)
+        table = IntervalTable(iv_start, iv_len, orf_iv, np.zeros(n, np.uint8), np.zeros(n + 1, np.int64))
+        edges = np.concatenate([iv_start[:5], iv_start[:5] + iv_len[:5] - 1, iv_start[:5] + iv_len[:5], iv_start[:5] - 1])
+        positions = np.unique(np.concatenate([rng.integers(-10, 5300, size=int(rng.integers(0, 12))), edges[edges >= 0][: trial % 7]]))
+        want = [i for i in range(n) if any(((iv_start[k] <= positions) & (positions < iv_start[k] + iv_len[k])).any()
+                                           for k in range(orf_iv[i], orf_iv[i + 1]))]
+        got = orfs_touching(table, positions)
+        assert got.tolist() == want, (trial, positions)
+    assert orfs_touching(table, np.zeros(0, np.int64)).size == 0
+
+
+def test_shard_objects_cut_the_index_without_touching_a_device():
+    """engine.CsrShards / engine.CoverageShards do their slicing on the host when they are made (streams, uploads and
+    plans come with the first sample, on the slices' own threads): nt-balanced bounds, per-slice tables re-based onto
+    the windows of the coverage their exons touch -- which together read exactly what the whole table reads."""
+    from ribotricer_amd.engine import CoverageShards, CsrShards
+    from ribotricer_amd.gather import IntervalTable
+    from ribotricer_amd.synth import synth_nested_layout
+
+    iv_start, iv_len, orf_iv, reverse, offsets, cov_len = synth_nested_layout(20000, 5, n_groups=6)
+    shards = CsrShards(offsets, [0, 1, 2, 3])
+    assert np.array_equal(shards.bounds, slice_bounds(offsets, 4)) and shards.total_nt == int(offsets[-1])
+    assert shards.matches(offsets, [0, 1, 2, 3]) and not shards.matches(offsets, [0, 1]) and not shards.matches(offsets[:-1], [0, 1, 2, 3])
+    table = IntervalTable(iv_start, iv_len, orf_iv, reverse, offsets)
+    cs = CoverageShards(table, [0, 1, 2], cov_len)
+    cov = np.random.default_rng(1).integers(0, 9, size=cov_len).astype(np.int32)
+    seen = 0
+    for k, part in enumerate(cs.parts):
+        lo, hi = int(cs.bounds[k]), int(cs.bounds[k + 1])
+        w_start, w_len, w_base, total = part["windows"]
+        compact = np.zeros(total, np.int32)
+        for a, ln, at in zip(w_start, w_len, w_base):
+            b = min(a + ln, cov_len)
+            compact[at : at + (b - a)] = cov[a:b]
+        sub = part["table"]
+        assert len(sub.offsets) - 1 == hi - lo
+        k0, k1 = int(orf_iv[lo]), int(orf_iv[hi])
+        for j in range(0, k1 - k0, 97):  # the re-based intervals read the same counts out of the compacted windows
+            assert np.array_equal(compact[sub.iv_start[j] : sub.iv_start[j] + sub.iv_len[j]],
+                                  cov[iv_start[k0 + j] : iv_start[k0 + j] + iv_len[k0 + j]])
+        assert total < cov_len  # a slice needs its own windows only
+        seen += hi - lo
+    assert seen == 20000
