@@ -245,6 +245,15 @@ def write_rows_native(
             ctypes.memmove(mm_addr + at, (ctypes.c_char * len(view)).from_buffer(view) if not isinstance(view, bytes) else view, len(view))
 
     def work(r: int) -> int:
+        claimed = [False]
+        try:
+            return render(r, claimed)
+        except BaseException:
+            if not claimed[0]:  # the ranges behind this one must not wait for a claim that will never come
+                order.claim(r, 0)
+            raise
+
+    def render(r: int, claimed: list) -> int:
         a, b = ranges[r]
         cap = chunk_bytes
         out = getattr(_tls, "wout", None)  # one reusable render buffer per thread (first touch is the costly part)
@@ -271,12 +280,14 @@ def write_rows_native(
             cur = nxt.value
             if cur >= b and not pieces:  # the common case: the whole range in one buffer -> straight from it to the file
                 start = order.claim(r, ln.value)
+                claimed[0] = True
                 if ln.value:
                     ctypes.memmove(mm_addr + start, out, ln.value)
                 return int(ln.value)
             pieces.append(out.raw[: ln.value])
         blob = b"".join(pieces)
         start = order.claim(r, len(blob))
+        claimed[0] = True
         pwrite_all(blob, start)
         return len(blob)
 
