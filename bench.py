@@ -348,6 +348,17 @@ def self_launch(args) -> int:
             else:
                 sys.stderr.write(f"[rank {rank}] {line}")
 
+    import signal
+
+    def stop_ranks(signum=None, frame=None):  # the parent is being stopped (a driver's timeout): do not leave ranks on the GPUs
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        if signum is not None:
+            sys.exit(128 + signum)
+
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, stop_ranks)
     threads = [threading.Thread(target=relay, args=(p, r), daemon=True) for r, p in enumerate(procs)]
     for t in threads:
         t.start()
@@ -384,6 +395,8 @@ def launch_only(rank: int, world: int) -> None:
     from ribotricer_amd.synth import offsets_from_lengths, orf_lengths
 
     args = parse_args()
+    if os.environ.get("RP_BENCH_LAUNCH_ONLY_SLEEP"):  # (the launcher's clean-up, under test: ranks that are still busy when the parent is stopped)
+        time.sleep(float(os.environ["RP_BENCH_LAUNCH_ONLY_SLEEP"]))
     dist.init_process_group(backend="gloo")
     n_set = args.orfs if args.orfs > 0 else DEFAULT_ORFS[args.cfg]
     offsets_set = offsets_from_lengths(orf_lengths(n_set, args.seed, args.cfg))

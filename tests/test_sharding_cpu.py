@@ -216,3 +216,28 @@ def test_shard_objects_cut_the_index_without_touching_a_device():
         assert total < cov_len  # a slice needs its own windows only
         seen += hi - lo
     assert seen == 20000
+
+
+def test_bench_launcher_takes_its_ranks_down_when_it_is_stopped():
+    """A parent that is stopped (a driver's timeout sends SIGTERM) must not leave its ranks behind on the GPUs."""
+    import signal
+    import subprocess
+    import sys
+    import time
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RP_BENCH_LAUNCH_ONLY="1", RP_BENCH_LAUNCH_ONLY_SLEEP="60")
+    parent = subprocess.Popen([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--orfs", "5000"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=repo)
+    time.sleep(6.0)  # (the ranks are up and asleep)
+    kids = subprocess.run(["pgrep", "-P", str(parent.pid)], capture_output=True, text=True).stdout.split()
+    assert len(kids) == 2, kids
+    parent.send_signal(signal.SIGTERM)
+    parent.wait(timeout=30)
+    assert parent.returncode == 128 + signal.SIGTERM
+    deadline = time.time() + 20
+    while time.time() < deadline and any(os.path.exists(f"/proc/{k}") and "bench.py" in open(f"/proc/{k}/cmdline").read() for k in kids if os.path.exists(f"/proc/{k}")):
+        time.sleep(0.2)
+    alive = [k for k in kids if os.path.exists(f"/proc/{k}") and "bench.py" in open(f"/proc/{k}/cmdline").read()]
+    assert not alive, alive
