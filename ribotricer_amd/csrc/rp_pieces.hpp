@@ -416,6 +416,9 @@ __device__ __forceinline__ void stage_tile_chunks(const int32_t *__restrict__ co
         const unsigned w1 = (lds0 + (hi & 0x1fffu) * 4u) | (((hi >> 13) & 0x3fu) << 16) | (((hi >> 19) & 1u) << 24) | (((hi >> 20) & 0x7fu) << 25);
         int steps = (total - r0 - wave + 3) >> 2;  // chunks r0 + wave, r0 + wave + 4, ... < total
         steps = __builtin_amdgcn_readfirstlane(steps > 64 ? 64 : steps);
+#ifdef RP_EXPERIMENT_CHUNK_DIV  // timing experiment only (results wrong): issue 1 / RP_EXPERIMENT_CHUNK_DIV of the chunks
+        steps = (steps + RP_EXPERIMENT_CHUNK_DIV - 1) / RP_EXPERIMENT_CHUNK_DIV;
+#endif
         if (steps > 0) {
             if (wide)
                 issue_chunks<true>(base, (unsigned)e, w1, steps, lane);

@@ -967,14 +967,25 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
         const long long n_chunks = pp.tile_lo[2 * b + 1];  // (count | kTileWide)
         chunk_desc_t mine;
         asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(mine) : "v"(chunk_slot(pp, b, lane, wave)) : "memory");
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(d), "+v"(vmap), "+v"(mine) : : "memory");
+#if RP_ROW_PREFETCH > 0 && defined(RP_ROW_PREFETCH_EARLY)
+        {   // (A/B: the same prefetch issued at ENTRY, beside the tile's own row loads -- it returns with them)
+            const long long bn = b + RP_ROW_PREFETCH;
+            if (wave == 0 && bn < plan.n_tiles && lane < 30) {
+                const char *line = lane < 7    ? reinterpret_cast<const char *>(ws.head + bn * kHeadRow) + 128 * lane
+                                   : lane < 29 ? reinterpret_cast<const char *>(pp.rows + bn * kMaxChunks) + 128 * (lane - 7)
+                                               : reinterpret_cast<const char *>(pp.tile_lo + 2 * bn);
+                asm volatile("global_load_dword %0, %1, off" : "=v"(prefetched) : "v"(line) : "memory");
+            }
+        }
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(d), "+v"(vmap), "+v"(mine), "+v"(prefetched) : : "memory");
         __builtin_amdgcn_s_setprio(3);  // scalar-heavy and on the critical path: ahead of the other workgroups' lane runs
         if (tile_lo != kTileSlow)
             stage_tile_chunks(counts, pp, b, tile_lo, n_chunks, mine, s_counts, lane, wave);
         else
             stage_tile_slow<TILE, kHalo>(counts, pp, b, plan.total_nt, s_counts, lane, wave);
         __builtin_amdgcn_s_setprio(0);
-#if RP_ROW_PREFETCH > 0
+#if RP_ROW_PREFETCH > 0 && !defined(RP_ROW_PREFETCH_EARLY)
         // The plan rows of the tile this CU slot will most likely run NEXT (b + the number of workgroups in flight; a
         // multiple of 8, so it is dispatched to the same XCD and finds the lines in ITS L2): 7 lines of head row, 22 of
         // chunk row, the tile_lo entry -- one load per line by wave 0, into a register nobody reads.  In the fused kernel
