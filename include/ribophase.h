@@ -366,7 +366,22 @@ int rp_coverage_build_rows_dev(int device, const uint8_t *d_strand, const int32_
                                const int64_t *d_count, int64_t n_rows, const int32_t *d_lut, int32_t n_chroms,
                                const int64_t *d_group_start, const int64_t *d_group_lo, const int64_t *d_group_hi,
                                int32_t n_groups, int32_t *d_coverage, int64_t coverage_len, void *hip_stream,
-                               int32_t *big_counts);
+                               int32_t *big_counts, const void *d_block_map, int64_t dense_len);
+
+/*
+ * Compact coverage (round 4).  The dense layout above gives every position of every (strand, chromosome) extent a slot
+ * -- 25 GB for a human index -- although only positions under an exon interval are ever read (the reference looks nothing
+ * else up: detect_orfs.py:176-187).  rp_coverage_map_create_dev keeps the 64-position blocks that an interval touches and
+ * packs them in order (one bit per block + a running count per 4 096 positions, in caller-owned d_map_mem of
+ * rp_coverage_map_bytes(dense_len) bytes), REWRITES d_iv_start from dense to compact coordinates (an interval stays
+ * contiguous) and returns the compact length.  rp_coverage_build_rows_dev with that d_block_map (and the dense_len it was
+ * built for) accumulates straight into a compact coverage of compact_len positions; rows under no exon are dropped.
+ * Everything downstream (gather plan, fused scoring, gathers) takes the compact coverage and the rewritten table as
+ * they are.  Synchronous.  RP_ERR_INTERVALS for an empty or off-layout interval.
+ */
+int rp_coverage_map_bytes(int64_t dense_len, size_t *bytes);
+int rp_coverage_map_create_dev(int device, int64_t *d_iv_start, const int32_t *d_iv_len, int64_t n_intervals, int64_t dense_len,
+                               void *d_map_mem, size_t map_bytes, void *hip_stream, int64_t *compact_len);
 
 /*
  * The positions of a dense coverage whose count passes RP_MAX_COUNT (after a coverage build reported

@@ -242,7 +242,7 @@ def upload_columns(merged, device=None) -> UploadedColumns:
                            to_dev(cols.count, np.int64), list(cols.chroms), dev)
 
 
-def build_coverage_device(merged, index, device=None, big=None):
+def build_coverage_device(merged, index, device=None, big=None, cmap=None):
     """Dense P-site coverage of every (strand, chrom) group of ``index`` (a ``NativeIndex``) in
     HBM: ``(coverage int32 device tensor, base)`` with ``base[(strand, chrom)] = (index of position
     lo, lo)`` -- what ``gather.interval_table_from_index`` takes.  ``merged``: :class:`MergedColumns`
@@ -255,7 +255,11 @@ def build_coverage_device(merged, index, device=None, big=None):
     ordinary samples) -- the caller finishes the ORFs that hold one with
     ``engine.rescore_big_count_orfs``; without it (callers that hand the coverage to the fp32 scorers
     themselves) such a count raises ``RibophaseError`` (status -7).  A negative count or a sum past 2^31 - 1
-    raises either way."""
+    raises either way.
+
+    ``cmap`` (``gather.CoverageMap`` of this index): the COMPACT coverage -- only the 64-position blocks under an exon
+    interval have a slot (``cmap.compact_len`` positions instead of the dense layout's; ``cmap.table`` is the interval
+    table that goes with it); rows under no exon are dropped on the device, as the reference never looks them up."""
     import torch
 
     from .engine import _ptr, get_engine
@@ -268,7 +272,9 @@ def build_coverage_device(merged, index, device=None, big=None):
     extent = index.extents
     base, total = coverage_layout(extent)
     keys = index.group_keys
-    coverage = torch.zeros(total, dtype=torch.int32, device=dev)
+    if cmap is not None and cmap.dense_len != total:
+        raise ValueError(f"the coverage map was built for a dense layout of {cmap.dense_len} positions, this index spans {total}")
+    coverage = torch.zeros(total if cmap is None else cmap.compact_len, dtype=torch.int32, device=dev)
     if big is not None:
         big["positions"] = np.zeros(0, np.int64)
     if int(cols.pos.numel() if up is not None else cols.pos.size) == 0 or total == 0:
@@ -303,7 +309,7 @@ def build_coverage_device(merged, index, device=None, big=None):
         _lib.load().rp_coverage_build_rows_dev(
             dev.index, _ptr(d_strand), _ptr(d_chrom), _ptr(d_pos), _ptr(d_count), d_pos.numel(), _ptr(d_lut), n_chroms,
             _ptr(d_start), _ptr(d_lo), _ptr(d_hi), len(keys), _ptr(coverage), coverage.numel(), stream,
-            ctypes.byref(flag) if big is not None else None,
+            ctypes.byref(flag) if big is not None else None, cmap.ptr if cmap is not None else None, total if cmap is not None else 0,
         )
     )
     if big is not None and flag.value:

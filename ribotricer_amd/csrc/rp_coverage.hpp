@@ -17,6 +17,132 @@
 
 namespace rp {
 
+// ---------------------------------------------------------------------------
+// Compact coverage (round 4).  The dense layout gives every position of every (strand, chromosome) extent a slot --
+// 25 GB for a human index, 85 GB for the 11 M-ORF synthetic one -- although only positions under an exon are ever
+// read (the reference looks nothing else up: detect_orfs.py:176-187).  A BLOCK MAP keeps the 64-position blocks that
+// an exon interval touches and packs them in order: one bit per block, and per 64-bit word (4 096 positions) the number
+// of kept blocks in front of it.  position -> slot is a shift, a popcount and an add; an interval stays contiguous
+// (the blocks it covers are all kept, and consecutive kept blocks are consecutive slots).  The coverage shrinks to the
+// exonic part (+ at most 126 positions per interval): 85 GB -> 9 GB, and with it the allocation, the memset and the
+// address range the scoring kernels wander over.
+// ---------------------------------------------------------------------------
+struct BlockMap {
+    const unsigned long long *bits;  // [n_words]      bit b of word w: block 64 w + b (positions 64 (64 w + b) ...) is kept
+    const long long *rank;           // [n_words + 1]  kept blocks in words < w; rank[n_words] = all of them
+    long long n_words;
+};
+constexpr int kMapChunk = 1024;  // words per scan chunk
+
+inline long long map_words(long long dense_len) { return (dense_len + 4095) / 4096; }
+inline long long map_chunks(long long n_words) { return (n_words + kMapChunk - 1) / kMapChunk; }
+inline size_t map_bytes(long long dense_len)
+{
+    const long long w = map_words(dense_len);
+    return (size_t)w * 8 + (size_t)(w + 1) * 8 + (size_t)(map_chunks(w) + 1) * 8 + 256;
+}
+
+// slot of dense position idx, or -1 when its block is not kept (no exon interval touches it)
+__device__ __forceinline__ long long map_position(const BlockMap &m, long long idx)
+{
+    const long long block = idx >> 6, w = block >> 6;
+    if (idx < 0 || w >= m.n_words) return -1;
+    const unsigned long long word = m.bits[w];
+    const int b = (int)(block & 63);
+    if (!((word >> b) & 1ull)) return -1;
+    const long long kept = m.rank[w] + __builtin_popcountll(word & ((1ull << b) - 1ull));
+    return (kept << 6) | (idx & 63);
+}
+
+__global__ void k_map_mark(const int64_t *__restrict__ iv_start, const int32_t *__restrict__ iv_len, long long n_iv,
+                           long long dense_len, unsigned long long *__restrict__ bits, int *__restrict__ err)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_iv) return;
+    const long long s = iv_start[k], n = iv_len[k];
+    if (n <= 0 || s < 0 || s + n > dense_len) {  // (not plannable: rp_gather_plan_create_dev reports it)
+        atomicOr(err, 1);
+        return;
+    }
+    for (long long b = s >> 6; b <= (s + n - 1) >> 6; ++b) {
+        const unsigned long long bit = 1ull << (b & 63);
+        if (!(bits[b >> 6] & bit)) atomicOr(&bits[b >> 6], bit);
+    }
+}
+
+// exclusive scan of popcount(bits[w]) in three steps: per-chunk sums, the chunks' scan (one workgroup), per-chunk scans
+__global__ __launch_bounds__(256) void k_map_chunk_sums(const unsigned long long *__restrict__ bits, long long n_words,
+                                                        long long *__restrict__ partial)
+{
+    __shared__ int s_sum[4];
+    const long long w0 = (long long)blockIdx.x * kMapChunk;
+    int mine = 0;
+    for (int i = threadIdx.x; i < kMapChunk; i += 256)
+        if (w0 + i < n_words) mine += __builtin_popcountll(bits[w0 + i]);
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+}
+
+__global__ __launch_bounds__(1024) void k_map_scan_partials(long long *__restrict__ partial, long long n_chunks)
+{
+    __shared__ long long s_carry;
+    __shared__ long long s_wave[16];
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (long long c0 = 0; c0 < n_chunks + 1; c0 += 1024) {  // (entry n_chunks receives the total)
+        const long long c = c0 + threadIdx.x;
+        const long long v = c < n_chunks ? partial[c] : 0;
+        long long incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long up = __shfl_up(incl, off, 64);
+            if ((int)(threadIdx.x & 63) >= off) incl += up;
+        }
+        if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        long long before = s_carry;
+        for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) before += s_wave[wv];
+        if (c <= n_chunks) partial[c] = before + incl - v;  // exclusive
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_map_rank(const unsigned long long *__restrict__ bits, long long n_words,
+                                                  const long long *__restrict__ partial, long long *__restrict__ rank)
+{
+    __shared__ int s_wave[4];
+    const long long w0 = (long long)blockIdx.x * kMapChunk;
+    long long carry = partial[blockIdx.x];
+    for (int pass = 0; pass < kMapChunk / 256; ++pass) {
+        const long long w = w0 + pass * 256 + threadIdx.x;
+        const int v = w < n_words ? __builtin_popcountll(bits[w]) : 0;
+        int incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if ((int)(threadIdx.x & 63) >= off) incl += up;
+        }
+        if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) before += s_wave[wv];
+        if (w < n_words) rank[w] = carry + before + incl - v;
+        const int total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+        carry += total;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) rank[n_words] = partial[gridDim.x];
+}
+
+__global__ void k_map_remap(int64_t *__restrict__ iv_start, long long n_iv, BlockMap m)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_iv) return;
+    iv_start[k] = map_position(m, iv_start[k]);  // (every interval's blocks were marked: never -1)
+}
+
 // err[0] |= 1 when an accumulated count passes RP_MAX_COUNT (what the fp32 codon arithmetic of the scorers takes
 // exactly: the caller finishes the ORFs that hold such a position in float64, rp_coverage_big_positions_dev),
 // err[0] |= 2 when a count is negative or a sum passes INT32_MAX (not representable in the coverage array)
@@ -55,7 +181,8 @@ __global__ void k_coverage_build_rows(const uint8_t *__restrict__ strand, const 
                                       const int64_t *__restrict__ pos, const int64_t *__restrict__ count, long long n,
                                       const int32_t *__restrict__ lut, int n_chroms, const int64_t *__restrict__ group_start,
                                       const int64_t *__restrict__ group_lo, const int64_t *__restrict__ group_hi, int n_groups,
-                                      int32_t *__restrict__ coverage, long long coverage_len, int *__restrict__ err)
+                                      int32_t *__restrict__ coverage, long long coverage_len, int *__restrict__ err,
+                                      BlockMap map)
 {
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
@@ -65,7 +192,8 @@ __global__ void k_coverage_build_rows(const uint8_t *__restrict__ strand, const 
         if (g < 0 || g >= n_groups) continue;
         const long long p = pos[k];
         if (p < group_lo[g] || p > group_hi[g]) continue;
-        const long long idx = group_start[g] + (p - group_lo[g]);
+        long long idx = group_start[g] + (p - group_lo[g]);
+        if (map.bits != nullptr) idx = map_position(map, idx);  // compact coverage: positions under no exon have no slot (never looked up)
         if (idx < 0 || idx >= coverage_len) continue;
         const long long cnt = count[k];
         if (cnt < 0 || cnt > 2147483647ll) {

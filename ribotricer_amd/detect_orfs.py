@@ -360,12 +360,21 @@ def _layout_cached(index, base, coverage_len: int, device) -> bool:
     return _layout_key(base, coverage_len, device) in index.__dict__.get("_layout_cache", {})
 
 
+def _compact_coverage() -> bool:
+    import os
+
+    return os.environ.get("RIBOTRICER_AMD_COMPACT_COVERAGE", "1") != "0"
+
+
 def _table_and_plan(index, base, coverage_len: int, device, table=None):
     """(interval table, gather plan, per-layout extras) of an index for a coverage layout, remembered on the index
     object: all depend on the index and the layout only (the layout on the index's group extents only), not on the
-    sample.  ``extras`` is a dict that lives and dies with the layout: the multi-GPU shards (``engine.CsrShards`` /
-    ``engine.CoverageShards``: per-device windows, gather plans, tile plans) are kept there."""
-    from .gather import interval_table_from_index, make_gather_plan
+    sample.  ``coverage_len`` is the length of the DENSE layout.  With the compact coverage (default;
+    ``RIBOTRICER_AMD_COMPACT_COVERAGE=0`` keeps the dense one) ``extras["coverage_map"]`` is the ``gather.CoverageMap``
+    of the layout, the table is in compact coordinates and the plan is built for the compact length.  ``extras`` is a
+    dict that lives and dies with the layout: the multi-GPU shards (``engine.CsrShards`` / ``engine.CoverageShards``:
+    per-device windows, gather plans, tile plans) are kept there too."""
+    from .gather import CoverageMap, interval_table_from_index, make_gather_plan
 
     key = _layout_key(base, coverage_len, device)
     cache = index.__dict__.setdefault("_layout_cache", {})
@@ -377,7 +386,20 @@ def _table_and_plan(index, base, coverage_len: int, device, table=None):
                 if hasattr(kept, "release"):
                     kept.release()
         cache.clear()  # (one layout per index: another one replaces it)
-        cache[key] = (table, make_gather_plan(table, coverage_len, device), {})
+        extras: dict = {}
+        plan_len = coverage_len
+        if _compact_coverage() and len(table.iv_start):
+            from ._lib import ERR_INTERVALS, RibophaseError
+
+            try:
+                cmap = CoverageMap(table, coverage_len, device)
+            except RibophaseError as e:  # (an interval off the layout: not mappable, not plannable either -- the dense path copes)
+                if e.status != ERR_INTERVALS:
+                    raise
+            else:
+                extras["coverage_map"] = cmap
+                table, plan_len = cmap.table, cmap.compact_len
+        cache[key] = (table, make_gather_plan(table, plan_len, device), extras)
     return cache[key]
 
 
@@ -469,18 +491,15 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     device = None if not devices else f"cuda:{int(devices[0])}"
     t = time.perf_counter()
     big: dict = {}  # positions whose count passes 2^24 - 1 (none on ordinary samples): their ORFs are finished in float64 below
-    # the interval table of a new index (one native pass over its 23 M exons) beside the coverage build on the device
-    from concurrent.futures import ThreadPoolExecutor
-
     from .gather import coverage_layout
 
     base0, total0 = coverage_layout(index.extents)
-    with ThreadPoolExecutor(max_workers=1) as side:
-        early = None if _layout_cached(index, base0, total0, device) else side.submit(interval_table_from_index, index, base0)
-        coverage, base = build_coverage_device(merged_alignments, index, device, big=big)
-        t = lap("coverage_build", t)
-        table, plan, extras = _table_and_plan(index, base, coverage.numel(), device, table=None if early is None else early.result())
+    # everything that depends on the index alone first (kept on the cached index: table, coverage map, plans), then
+    # this sample's coverage -- compact: only the blocks under an exon have a slot (gather.CoverageMap)
+    table, plan, extras = _table_and_plan(index, base0, total0, device)
     t = lap("interval_table_gather_plan", t)
+    coverage, base = build_coverage_device(merged_alignments, index, device, big=big, cmap=extras.get("coverage_map"))
+    t = lap("coverage_build", t)
     sharded = devices is not None and len(devices) > 1
     extras["samples"] = extras.get("samples", 0) + 1
     if plan is not None and not sharded and "workspace_placement" not in extras and extras["samples"] >= 2 and _place_workspace_for(table):

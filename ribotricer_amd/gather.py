@@ -166,6 +166,35 @@ def interval_table_from_index(index, base) -> IntervalTable:
     return IntervalTable(iv_start, iv_len, arrays[2].copy(), np.ascontiguousarray(index.reverse, dtype=np.uint8).copy(), offsets)
 
 
+class CoverageMap:
+    """Block map of a COMPACT coverage (``rp_coverage_map_create_dev``): of the dense layout only the 64-position blocks
+    under an exon interval get a slot -- the reference never looks anything else up (detect_orfs.py:176-187) -- so the
+    coverage of a human-sized index takes a tenth of the dense array's memory, allocation time and memset.  Built once per
+    index (it depends on the interval table only); ``table`` is the interval table in COMPACT coordinates (an interval
+    stays contiguous), ``compact_len`` the coverage length, ``dense_len`` what the alignment rows' layout spans.  Owns its
+    device memory."""
+
+    def __init__(self, dense_table: IntervalTable, dense_len: int, device=None):
+        dev = get_engine(device).device
+        self.device = dev
+        self.dense_len = int(dense_len)
+        nbytes = ctypes.c_size_t(0)
+        _lib.check(_lib.load().rp_coverage_map_bytes(self.dense_len, ctypes.byref(nbytes)))
+        self._mem = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+        iv_start = _as_device(dense_table.iv_start, torch.int64, dev).clone()  # (rewritten in place: dense -> compact)
+        iv_len = _as_device(dense_table.iv_len, torch.int32, dev)
+        compact = ctypes.c_int64(0)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(_lib.load().rp_coverage_map_create_dev(dev.index, _ptr(iv_start), _ptr(iv_len), iv_start.numel(), self.dense_len,
+                                                         _ptr(self._mem), self._mem.numel(), stream, ctypes.byref(compact)))
+        self.compact_len = int(compact.value)
+        self.table = IntervalTable(iv_start.cpu().numpy(), dense_table.iv_len, dense_table.orf_iv, dense_table.reverse, dense_table.offsets)
+
+    @property
+    def ptr(self):
+        return _ptr(self._mem)
+
+
 class GatherPlan:
     """A gather plan (``rp_gather_plan``): the profile space of an index as pieces of the dense
     coverage, one fixed-stride row of clipped pieces per tile.  Depends on the interval table

@@ -53,7 +53,7 @@ def child(n_orfs: int) -> None:
         stages.append(tm)
     index = next(reversed(d._INDEX_CACHE.values()))
     (table, plan, extras), = index.__dict__["_layout_cache"].values()
-    coverage, _ = build_coverage_device(cols, index)
+    coverage, _ = build_coverage_device(cols, index, cmap=extras.get("coverage_map"))
     eng = get_engine("cuda:0")
     th = make_filter()
 

@@ -88,6 +88,36 @@ def test_export_with_counts_beyond_fp32_matches_reference(tmp_path, name, device
     assert saturated >= (10 if name != "default" else 1)
 
 
+@pytest.mark.parametrize("report_all", [False, True])
+def test_compact_and_dense_coverage_write_the_same_file(tmp_path, report_all):
+    """The export builds a COMPACT coverage by default (only the blocks under an exon keep a slot: gather.CoverageMap);
+    RIBOTRICER_AMD_COMPACT_COVERAGE=0 keeps the dense one.  Same bytes either way, one GPU and sharded, counts beyond
+    2^24 - 1 included (their positions are named in the coordinates of whichever coverage is in use)."""
+    from ribotricer_amd import detect_orfs as d
+
+    index = os.path.join(GOLDEN, "g6_index.tsv")
+    outs = {}
+    for mode in ("1", "0"):
+        os.environ["RIBOTRICER_AMD_COMPACT_COVERAGE"] = mode
+        d._INDEX_CACHE.clear()
+        try:
+            for tag, align, devices in (("plain", load_alignments(), None), ("big", load_g10_alignments(), None), ("sharded", load_g10_alignments(), [0, 0, 0])):
+                prefix = str(tmp_path / f"{tag}{mode}")
+                d.export_orf_coverages(index, align, prefix, report_all=report_all, devices=devices)
+                outs[(tag, mode)] = open(prefix + "_translating_ORFs.tsv", "rb").read()
+            cached = next(reversed(d._INDEX_CACHE.values()))
+            (table, plan, extras), = cached.__dict__["_layout_cache"].values()
+            assert ("coverage_map" in extras) == (mode == "1")
+            if mode == "1":
+                assert extras["coverage_map"].compact_len < extras["coverage_map"].dense_len
+        finally:
+            del os.environ["RIBOTRICER_AMD_COMPACT_COVERAGE"]
+    d._INDEX_CACHE.clear()
+    for tag in ("plain", "big", "sharded"):
+        assert outs[(tag, "1")] == outs[(tag, "0")], tag
+    assert outs[("big", "1")] == outs[("sharded", "1")] or not report_all  # (default mode: another tiling may move an unflagged phase by <= 2e-7)
+
+
 def test_phasescore_mirror(g1, g5):
     from ribotricer_amd.statistics import phasescore, phasescore_batch
 

@@ -88,6 +88,42 @@ def test_gather_selected_equals_the_sub_table_gather():
         assert torch.equal(sub, counts)
 
 
+def test_compact_coverage_map():
+    """gather.CoverageMap: only the 64-position blocks under an exon interval keep a slot.  The table in compact
+    coordinates reads out of the compact coverage exactly what the dense table reads out of the dense one (per-ORF gather,
+    tile gather, fused scores bit for bit), the compact length is the number of kept blocks x 64, and positions under no
+    exon have no slot."""
+    import torch
+
+    from ribotricer_amd.engine import get_engine, make_filter
+    from ribotricer_amd.gather import CoverageMap, GatherPlan, gather_profiles_device
+
+    rng = np.random.default_rng(123)
+    dense_len = 3_000_000
+    cov = rng.poisson(0.5, size=dense_len).astype(np.int32)
+    t = random_table(rng, 5000, dense_len, max_exons=5, exon_len=(1, 500))
+    cmap = CoverageMap(t, dense_len)
+    blocks = np.zeros((dense_len + 63) // 64, bool)
+    for s0, n in zip(t.iv_start, t.iv_len):
+        blocks[s0 // 64 : (s0 + n - 1) // 64 + 1] = True
+    assert cmap.compact_len == 64 * int(blocks.sum()) < dense_len
+    slot_of_block = np.cumsum(blocks) - 1
+    want_start = slot_of_block[t.iv_start // 64] * 64 + t.iv_start % 64
+    assert np.array_equal(cmap.table.iv_start, want_start)
+    compact = np.zeros(cmap.compact_len, np.int32)
+    kept = np.flatnonzero(blocks)
+    for k, b in enumerate(kept):  # the compact coverage as the build kernel would fill it
+        seg = cov[64 * b : 64 * b + 64]
+        compact[64 * k : 64 * k + seg.size] = seg
+    dense_counts, _ = gather_profiles_device(cov, t)
+    compact_counts, _ = gather_profiles_device(compact, cmap.table)
+    assert torch.equal(dense_counts, compact_counts)
+    eng = get_engine("cuda:0")
+    a = eng.score_coverage(cov, GatherPlan(t, dense_len), thresholds=make_filter()).cpu_numpy()
+    b = eng.score_coverage(compact, GatherPlan(cmap.table, cmap.compact_len), thresholds=make_filter()).cpu_numpy()
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+
+
 def test_unplannable_tables():
     from ribotricer_amd import _lib
     from ribotricer_amd.gather import GatherPlan, IntervalTable, make_gather_plan
