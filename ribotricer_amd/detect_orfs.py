@@ -399,7 +399,11 @@ def _table_and_plan(index, base, coverage_len: int, device, table=None):
             else:
                 extras["coverage_map"] = cmap
                 table, plan_len = cmap.table, cmap.compact_len
-        cache[key] = (table, make_gather_plan(table, plan_len, device), extras)
+        cmap = extras.get("coverage_map")
+        plan = make_gather_plan(table, plan_len, device, device_intervals=None if cmap is None else cmap.device_intervals)
+        if cmap is not None:
+            cmap.release_device_intervals()  # (0.3 GB of device memory the plan has digested)
+        cache[key] = (table, plan, extras)
     return cache[key]
 
 
@@ -500,6 +504,9 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     t = lap("interval_table_gather_plan", t)
     coverage, base = build_coverage_device(merged_alignments, index, device, big=big, cmap=extras.get("coverage_map"))
     t = lap("coverage_build", t)
+    if timings is not None:
+        timings["coverage_positions"] = int(coverage.numel())
+        timings["dense_layout_positions"] = int(total0)
     sharded = devices is not None and len(devices) > 1
     extras["samples"] = extras.get("samples", 0) + 1
     if plan is not None and not sharded and "workspace_placement" not in extras and extras["samples"] >= 2 and _place_workspace_for(table):

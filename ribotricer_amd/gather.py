@@ -189,6 +189,10 @@ class CoverageMap:
                                                          _ptr(self._mem), self._mem.numel(), stream, ctypes.byref(compact)))
         self.compact_len = int(compact.value)
         self.table = IntervalTable(iv_start.cpu().numpy(), dense_table.iv_len, dense_table.orf_iv, dense_table.reverse, dense_table.offsets)
+        self.device_intervals = (iv_start, iv_len)  # (for the gather plan that follows; dropped by release_device_intervals)
+
+    def release_device_intervals(self) -> None:
+        self.device_intervals = None
 
     @property
     def ptr(self):
@@ -203,7 +207,9 @@ class GatherPlan:
     an empty or off-array interval (the per-ORF kernel behind :func:`gather_profiles_device`
     handles those)."""
 
-    def __init__(self, table: IntervalTable, coverage_len: int, device=None):
+    def __init__(self, table: IntervalTable, coverage_len: int, device=None, device_intervals=None):
+        """``device_intervals``: ``(iv_start int64, iv_len int32)`` of ``table`` already on the device (a
+        :class:`CoverageMap` has them: no second upload)."""
         dev = get_engine(device).device
         self.device = dev
         self.n_orfs = int(len(table.offsets) - 1)
@@ -211,8 +217,8 @@ class GatherPlan:
         self.total_nt = int(table.offsets[-1])
         self.coverage_len = int(coverage_len)
         self.offsets = _as_device(table.offsets, torch.int64, dev)
-        iv_start = _as_device(table.iv_start, torch.int64, dev)
-        iv_len = _as_device(table.iv_len, torch.int32, dev)
+        iv_start = _as_device(table.iv_start if device_intervals is None else device_intervals[0], torch.int64, dev)
+        iv_len = _as_device(table.iv_len if device_intervals is None else device_intervals[1], torch.int32, dev)
         orf_iv = _as_device(table.orf_iv, torch.int64, dev)
         reverse = _as_device(table.reverse, torch.uint8, dev)
         self._mem = torch.empty(_lib.gather_plan_bytes(self.n_orfs, self.n_intervals, self.total_nt), dtype=torch.uint8, device=dev)
@@ -290,11 +296,11 @@ class GatherPlan:
                 pass
 
 
-def make_gather_plan(table: IntervalTable, coverage_len: int, device=None):
+def make_gather_plan(table: IntervalTable, coverage_len: int, device=None, device_intervals=None):
     """:class:`GatherPlan`, or None when the table cannot be planned (an interval hangs off the
     coverage array: the per-ORF kernel reads such positions as 0)."""
     try:
-        return GatherPlan(table, coverage_len, device)
+        return GatherPlan(table, coverage_len, device, device_intervals=device_intervals)
     except _lib.RibophaseError as e:
         if e.status == _lib.ERR_INTERVALS:
             return None
