@@ -88,6 +88,7 @@ def parse_args():
     ap.add_argument("--no-fused-nested", action="store_true", help="skip the nested-index fused section (N = 1)")
     ap.add_argument("--no-fused-exons", action="store_true", help="skip the fused section on the run's own length law (N = 1; counter passes that want the nested launches alone)")
     ap.add_argument("--dense-coverage", action="store_true", help="fused sections over the dense coverage layout (default: the compact one the export builds)")
+    ap.add_argument("--coverage-block", type=int, default=None, help="positions per block of the compact coverage (default: the export's, gather.COVERAGE_BLOCK)")
     ap.add_argument("--fused-steps", type=int, default=10)
     ap.add_argument("--seed", type=int, default=20260213)
     return ap.parse_args()
@@ -263,15 +264,16 @@ def fused_section(args, eng, dev, thresholds, n_set, layout="exons"):
         law = f"the {args.cfg} length law (introns < 300 nt, half of the ORFs on the '-' strand)"
     table = IntervalTable(iv_start, iv_len, orf_iv, reverse, offsets)
     dense_len = coverage_len
-    map_ms = None
+    map_ms = block = None
     if not args.dense_coverage:
-        # what the export does since round 4: a COMPACT coverage -- only the 64-position blocks under an exon keep a slot
-        # (gather.CoverageMap); the synthetic counts are drawn straight into the compact array
+        # what the export does since round 4: a COMPACT coverage -- only the positions (blocks of --coverage-block) under an
+        # exon keep a slot (gather.CoverageMap); the synthetic counts are drawn straight into the compact array
         from ribotricer_amd.gather import CoverageMap
 
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        cmap = CoverageMap(table, dense_len, dev)
+        cmap = CoverageMap(table, dense_len, dev, block_positions=args.coverage_block)
+        block = cmap.block_positions
         torch.cuda.synchronize(dev)
         map_ms = 1e3 * (time.perf_counter() - t0)
         table, coverage_len = cmap.table, cmap.compact_len
@@ -301,9 +303,9 @@ def fused_section(args, eng, dev, thresholds, n_set, layout="exons"):
     algo_bytes = 4 * total_nt + 8 * (n + 1) + 24 * n
     rep = {
         "workload": f"{n} ORFs / {iv_len.size} exons over a " + (f"dense coverage of {coverage_len} positions" if args.dense_coverage else
-                    f"compact coverage of {coverage_len} positions (the 64-position blocks under an exon; the dense layout spans {dense_len})")
+                    f"compact coverage of {coverage_len} positions (the {block}-position blocks under an exon; the dense layout spans {dense_len})")
                     + f" ({total_nt} nt of profiles): {law}",
-        "coverage_positions": coverage_len, "dense_layout_positions": dense_len, "coverage_map_build_ms": map_ms,
+        "coverage_positions": coverage_len, "dense_layout_positions": dense_len, "coverage_block": block, "coverage_map_build_ms": map_ms,
         "kernel": "rp::k_tile_score<true> (tile staged from the coverage through the gather plan)",
         "kernel_ms": k_main, "finish_ms": k_fin, "step_device_ms": k_all,
         "achieved": algo_bytes / (k_main * 1e-3) / 1e9, "frac": algo_bytes / (k_main * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -366,22 +366,26 @@ int rp_coverage_build_rows_dev(int device, const uint8_t *d_strand, const int32_
                                const int64_t *d_count, int64_t n_rows, const int32_t *d_lut, int32_t n_chroms,
                                const int64_t *d_group_start, const int64_t *d_group_lo, const int64_t *d_group_hi,
                                int32_t n_groups, int32_t *d_coverage, int64_t coverage_len, void *hip_stream,
-                               int32_t *big_counts, const void *d_block_map, int64_t dense_len);
+                               int32_t *big_counts, const void *d_block_map, int64_t dense_len, int32_t block_positions);
 
 /*
  * Compact coverage (round 4).  The dense layout above gives every position of every (strand, chromosome) extent a slot
  * -- 25 GB for a human index -- although only positions under an exon interval are ever read (the reference looks nothing
- * else up: detect_orfs.py:176-187).  rp_coverage_map_create_dev keeps the 64-position blocks that an interval touches and
- * packs them in order (one bit per block + a running count per 4 096 positions, in caller-owned d_map_mem of
- * rp_coverage_map_bytes(dense_len) bytes), REWRITES d_iv_start from dense to compact coordinates (an interval stays
- * contiguous) and returns the compact length.  rp_coverage_build_rows_dev with that d_block_map (and the dense_len it was
- * built for) accumulates straight into a compact coverage of compact_len positions; rows under no exon are dropped.
+ * else up: detect_orfs.py:176-187).  rp_coverage_map_create_dev keeps the blocks of block_positions (a power of two, 1 ...
+ * 64) positions that an interval touches and packs them in order (one bit per block + a running count per 64 blocks, in
+ * caller-owned d_map_mem of rp_coverage_map_bytes(dense_len, block_positions) bytes), REWRITES d_iv_start from dense to
+ * compact coordinates (an interval stays contiguous) and returns the compact length.  block_positions 64: the map takes
+ * dense_len / 256 bytes and the coverage keeps up to 126 unread positions per interval; block_positions 1: dense_len / 4
+ * bytes of map and nothing but exonic positions in the coverage -- exons that face each other across an intron become
+ * neighbours in memory, so the gather plan merges a spliced ORF's pieces into one run and consecutive pieces share their
+ * cache lines.  rp_coverage_build_rows_dev with that d_block_map (and the dense_len and block_positions it was built for)
+ * accumulates straight into a compact coverage of compact_len positions; rows under no exon are dropped.
  * Everything downstream (gather plan, fused scoring, gathers) takes the compact coverage and the rewritten table as
- * they are.  Synchronous.  RP_ERR_INTERVALS for an empty or off-layout interval.
+ * they are.  Synchronous.  RP_ERR_INTERVALS for an empty or off-layout interval, RP_ERR_ARG for another block size.
  */
-int rp_coverage_map_bytes(int64_t dense_len, size_t *bytes);
+int rp_coverage_map_bytes(int64_t dense_len, int32_t block_positions, size_t *bytes);
 int rp_coverage_map_create_dev(int device, int64_t *d_iv_start, const int32_t *d_iv_len, int64_t n_intervals, int64_t dense_len,
-                               void *d_map_mem, size_t map_bytes, void *hip_stream, int64_t *compact_len);
+                               int32_t block_positions, void *d_map_mem, size_t map_bytes, void *hip_stream, int64_t *compact_len);
 
 /*
  * The positions of a dense coverage whose count passes RP_MAX_COUNT (after a coverage build reported

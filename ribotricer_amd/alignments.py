@@ -257,7 +257,7 @@ def build_coverage_device(merged, index, device=None, big=None, cmap=None):
     themselves) such a count raises ``RibophaseError`` (status -7).  A negative count or a sum past 2^31 - 1
     raises either way.
 
-    ``cmap`` (``gather.CoverageMap`` of this index): the COMPACT coverage -- only the 64-position blocks under an exon
+    ``cmap`` (``gather.CoverageMap`` of this index): the COMPACT coverage -- only the blocks (positions, by default) under an exon
     interval have a slot (``cmap.compact_len`` positions instead of the dense layout's; ``cmap.table`` is the interval
     table that goes with it); rows under no exon are dropped on the device, as the reference never looks them up."""
     import torch
@@ -310,6 +310,7 @@ def build_coverage_device(merged, index, device=None, big=None, cmap=None):
             dev.index, _ptr(d_strand), _ptr(d_chrom), _ptr(d_pos), _ptr(d_count), d_pos.numel(), _ptr(d_lut), n_chroms,
             _ptr(d_start), _ptr(d_lo), _ptr(d_hi), len(keys), _ptr(coverage), coverage.numel(), stream,
             ctypes.byref(flag) if big is not None else None, cmap.ptr if cmap is not None else None, total if cmap is not None else 0,
+            cmap.block_positions if cmap is not None else 0,
         )
     )
     if big is not None and flag.value:

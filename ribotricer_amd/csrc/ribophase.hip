@@ -825,45 +825,48 @@ int rp_phase_score_coverage_dev(int device, const int32_t *d_coverage, int64_t c
 
 namespace {
 // the block map of a compact coverage inside caller-owned device memory (rp_coverage_map_bytes): bits, rank, chunk sums
-rp::BlockMap block_map_of(const void *mem, int64_t dense_len)
+rp::BlockMap block_map_of(const void *mem, int64_t dense_len, int shift)
 {
-    if (!mem) return rp::BlockMap{nullptr, nullptr, 0};
-    const long long w = rp::map_words(dense_len);
+    if (!mem) return rp::BlockMap{nullptr, nullptr, 0, 0};
+    const long long w = rp::map_words(dense_len, shift);
     const char *p = static_cast<const char *>(mem);
-    return rp::BlockMap{reinterpret_cast<const unsigned long long *>(p), reinterpret_cast<const long long *>(p + (size_t)w * 8), w};
+    return rp::BlockMap{reinterpret_cast<const unsigned long long *>(p), reinterpret_cast<const long long *>(p + (size_t)w * 8), w, shift};
 }
 }  // namespace
 
-int rp_coverage_map_bytes(int64_t dense_len, size_t *bytes)
+int rp_coverage_map_bytes(int64_t dense_len, int32_t block_positions, size_t *bytes)
 {
     if (!bytes) return fail(RP_ERR_NULL, "bytes is null");
     if (dense_len < 0) return fail(RP_ERR_SIZE, "negative size");
-    *bytes = rp::map_bytes(dense_len);
+    if (!rp::map_block_ok(block_positions)) return fail(RP_ERR_ARG, "block_positions must be a power of two from 1 to 64, got %d", (int)block_positions);
+    *bytes = rp::map_bytes(dense_len, rp::map_shift(block_positions));
     return RP_OK;
 }
 
 int rp_coverage_map_create_dev(int device, int64_t *d_iv_start, const int32_t *d_iv_len, int64_t n_intervals, int64_t dense_len,
-                               void *d_map_mem, size_t map_bytes, void *hip_stream, int64_t *compact_len)
+                               int32_t block_positions, void *d_map_mem, size_t map_bytes, void *hip_stream, int64_t *compact_len)
 {
     if (!compact_len) return fail(RP_ERR_NULL, "compact_len is null");
     *compact_len = 0;
     if (n_intervals < 0 || dense_len < 0) return fail(RP_ERR_SIZE, "negative size");
+    if (!rp::map_block_ok(block_positions)) return fail(RP_ERR_ARG, "block_positions must be a power of two from 1 to 64, got %d", (int)block_positions);
+    const int shift = rp::map_shift(block_positions);
     if (!d_map_mem || (n_intervals > 0 && (!d_iv_start || !d_iv_len))) return fail(RP_ERR_NULL, "interval table and map memory must be non-null");
-    if (map_bytes < rp::map_bytes(dense_len)) return fail(RP_ERR_WORKSPACE, "block map memory of %zu bytes required, got %zu", rp::map_bytes(dense_len), map_bytes);
+    if (map_bytes < rp::map_bytes(dense_len, shift)) return fail(RP_ERR_WORKSPACE, "block map memory of %zu bytes required, got %zu", rp::map_bytes(dense_len, shift), map_bytes);
     if ((reinterpret_cast<uintptr_t>(d_map_mem) & 7u) != 0) return fail(RP_ERR_WORKSPACE, "map memory must be 8-byte aligned");
     RP_ON_DEVICE(device);
     hipStream_t stream = (hipStream_t)hip_stream;
-    const long long w = rp::map_words(dense_len);
+    const long long w = rp::map_words(dense_len, shift);
     const long long chunks = rp::map_chunks(w);
     char *p = static_cast<char *>(d_map_mem);
     unsigned long long *bits = reinterpret_cast<unsigned long long *>(p);
     long long *rank = reinterpret_cast<long long *>(p + (size_t)w * 8);
     long long *partial = reinterpret_cast<long long *>(p + (size_t)w * 8 + (size_t)(w + 1) * 8);
     int *d_err = reinterpret_cast<int *>(partial + chunks + 1);  // (the 256 spare bytes behind the chunk sums)
-    RP_HIP(hipMemsetAsync(d_map_mem, 0, rp::map_bytes(dense_len), stream));
+    RP_HIP(hipMemsetAsync(d_map_mem, 0, rp::map_bytes(dense_len, shift), stream));
     if (n_intervals > 0) {
         hipLaunchKernelGGL(rp::k_map_mark, dim3((unsigned)((n_intervals + 255) / 256)), dim3(256), 0, stream, d_iv_start, d_iv_len,
-                           (long long)n_intervals, (long long)dense_len, bits, d_err);
+                           (long long)n_intervals, (long long)dense_len, shift, bits, d_err);
         RP_HIP(hipGetLastError());
     }
     if (w > 0) {
@@ -880,10 +883,10 @@ int rp_coverage_map_create_dev(int device, int64_t *d_iv_start, const int32_t *d
     if (h_err) return fail(RP_ERR_INTERVALS, "an interval is empty or reaches outside the dense layout: not mappable");
     if (n_intervals > 0) {
         hipLaunchKernelGGL(rp::k_map_remap, dim3((unsigned)((n_intervals + 255) / 256)), dim3(256), 0, stream, d_iv_start,
-                           (long long)n_intervals, rp::BlockMap{bits, rank, w});
+                           (long long)n_intervals, rp::BlockMap{bits, rank, w, shift});
         RP_HIP(hipGetLastError());
     }
-    *compact_len = (int64_t)kept * 64;
+    *compact_len = (int64_t)(kept << shift);
     return RP_OK;
 }
 
@@ -939,11 +942,12 @@ int rp_coverage_build_rows_dev(int device, const uint8_t *d_strand, const int32_
                                const int64_t *d_count, int64_t n_rows, const int32_t *d_lut, int32_t n_chroms,
                                const int64_t *d_group_start, const int64_t *d_group_lo, const int64_t *d_group_hi,
                                int32_t n_groups, int32_t *d_coverage, int64_t coverage_len, void *hip_stream,
-                               int32_t *big_counts, const void *d_block_map, int64_t dense_len)
+                               int32_t *big_counts, const void *d_block_map, int64_t dense_len, int32_t block_positions)
 {
     if (big_counts) *big_counts = 0;
     if (n_rows < 0 || coverage_len < 0 || n_groups < 0 || n_chroms < 0) return fail(RP_ERR_SIZE, "negative size");
-    if (d_block_map && dense_len <= 0) return fail(RP_ERR_ARG, "a block map needs the length of the dense layout it was built for");
+    if (d_block_map && (dense_len <= 0 || !rp::map_block_ok(block_positions)))
+        return fail(RP_ERR_ARG, "a block map needs the length of the dense layout and the block size it was built for");
     if (n_rows > 0 && (!d_strand || !d_chrom || !d_pos || !d_count || !d_lut || !d_group_start || !d_group_lo || !d_group_hi))
         return fail(RP_ERR_NULL, "row columns, lookup table and group tables must be non-null");
     if (coverage_len > 0 && !d_coverage) return fail(RP_ERR_NULL, "d_coverage is null");
@@ -959,7 +963,8 @@ int rp_coverage_build_rows_dev(int device, const uint8_t *d_strand, const int32_
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(rp::k_coverage_build_rows, dim3((unsigned)blocks), dim3(256), 0, stream, d_strand, d_chrom, d_pos, d_count,
                            (long long)n_rows, d_lut, (int)n_chroms, d_group_start, d_group_lo, d_group_hi, (int)n_groups, d_coverage,
-                           (long long)coverage_len, d_err, block_map_of(d_block_map, dense_len));
+                           (long long)coverage_len, d_err,
+                           block_map_of(d_block_map, dense_len, d_block_map ? rp::map_shift(block_positions) : 0));
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, stream);

@@ -20,42 +20,49 @@ namespace rp {
 // ---------------------------------------------------------------------------
 // Compact coverage (round 4).  The dense layout gives every position of every (strand, chromosome) extent a slot --
 // 25 GB for a human index, 85 GB for the 11 M-ORF synthetic one -- although only positions under an exon are ever
-// read (the reference looks nothing else up: detect_orfs.py:176-187).  A BLOCK MAP keeps the 64-position blocks that
-// an exon interval touches and packs them in order: one bit per block, and per 64-bit word (4 096 positions) the number
+// read (the reference looks nothing else up: detect_orfs.py:176-187).  A BLOCK MAP keeps the blocks of 2^shift
+// positions that an exon interval touches and packs them in order: one bit per block, and per 64-bit word the number
 // of kept blocks in front of it.  position -> slot is a shift, a popcount and an add; an interval stays contiguous
-// (the blocks it covers are all kept, and consecutive kept blocks are consecutive slots).  The coverage shrinks to the
-// exonic part (+ at most 126 positions per interval): 85 GB -> 9 GB, and with it the allocation, the memset and the
-// address range the scoring kernels wander over.
+// (the blocks it covers are all kept, and consecutive kept blocks are consecutive slots).  With 64-position blocks
+// the coverage shrinks to the exonic part + at most 126 positions per interval (85 GB -> 9 GB), and with it the
+// allocation, the memset and the address range the scoring kernels wander over.  With ONE-position blocks (shift 0)
+// nothing but exonic positions is left: exons that were neighbours across an intron become neighbours in memory, the
+// pieces of a spliced ORF merge into one run of the gather plan, and the cache lines at both ends of a piece are
+// shared with the next piece instead of being fetched for a few counts each (what the fused kernel paid 1.28x the
+// algorithmic traffic for on gapped layouts); the map then takes dense_len / 4 bytes instead of dense_len / 256.
 // ---------------------------------------------------------------------------
 struct BlockMap {
-    const unsigned long long *bits;  // [n_words]      bit b of word w: block 64 w + b (positions 64 (64 w + b) ...) is kept
+    const unsigned long long *bits;  // [n_words]      bit b of word w: block 64 w + b (positions (64 w + b) << shift ...) is kept
     const long long *rank;           // [n_words + 1]  kept blocks in words < w; rank[n_words] = all of them
     long long n_words;
+    int shift;                       // log2 of the block size in positions: 0 ... 6
 };
 constexpr int kMapChunk = 1024;  // words per scan chunk
 
-inline long long map_words(long long dense_len) { return (dense_len + 4095) / 4096; }
+inline bool map_block_ok(int block_positions) { return block_positions >= 1 && block_positions <= 64 && (block_positions & (block_positions - 1)) == 0; }
+inline int map_shift(int block_positions) { return __builtin_ctz((unsigned)block_positions); }
+inline long long map_words(long long dense_len, int shift) { return (dense_len + (64ll << shift) - 1) >> (6 + shift); }
 inline long long map_chunks(long long n_words) { return (n_words + kMapChunk - 1) / kMapChunk; }
-inline size_t map_bytes(long long dense_len)
+inline size_t map_bytes(long long dense_len, int shift)
 {
-    const long long w = map_words(dense_len);
+    const long long w = map_words(dense_len, shift);
     return (size_t)w * 8 + (size_t)(w + 1) * 8 + (size_t)(map_chunks(w) + 1) * 8 + 256;
 }
 
 // slot of dense position idx, or -1 when its block is not kept (no exon interval touches it)
 __device__ __forceinline__ long long map_position(const BlockMap &m, long long idx)
 {
-    const long long block = idx >> 6, w = block >> 6;
+    const long long block = idx >> m.shift, w = block >> 6;
     if (idx < 0 || w >= m.n_words) return -1;
     const unsigned long long word = m.bits[w];
     const int b = (int)(block & 63);
     if (!((word >> b) & 1ull)) return -1;
     const long long kept = m.rank[w] + __builtin_popcountll(word & ((1ull << b) - 1ull));
-    return (kept << 6) | (idx & 63);
+    return (kept << m.shift) | (idx & ((1ll << m.shift) - 1));
 }
 
 __global__ void k_map_mark(const int64_t *__restrict__ iv_start, const int32_t *__restrict__ iv_len, long long n_iv,
-                           long long dense_len, unsigned long long *__restrict__ bits, int *__restrict__ err)
+                           long long dense_len, int shift, unsigned long long *__restrict__ bits, int *__restrict__ err)
 {
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_iv) return;
@@ -64,9 +71,12 @@ __global__ void k_map_mark(const int64_t *__restrict__ iv_start, const int32_t *
         atomicOr(err, 1);
         return;
     }
-    for (long long b = s >> 6; b <= (s + n - 1) >> 6; ++b) {
-        const unsigned long long bit = 1ull << (b & 63);
-        if (!(bits[b >> 6] & bit)) atomicOr(&bits[b >> 6], bit);
+    const long long b0 = s >> shift, b1 = (s + n - 1) >> shift;  // blocks b0 .. b1, a word's worth at a time
+    for (long long w = b0 >> 6; w <= b1 >> 6; ++w) {
+        const int lo = w == (b0 >> 6) ? (int)(b0 & 63) : 0;
+        const int hi = w == (b1 >> 6) ? (int)(b1 & 63) : 63;
+        const unsigned long long mask = (hi == 63 ? ~0ull : (1ull << (hi + 1)) - 1ull) & ~((1ull << lo) - 1ull);
+        if ((bits[w] & mask) != mask) atomicOr(&bits[w], mask);  // (nested candidate ORFs mark the same exons over and over)
     }
 }
 

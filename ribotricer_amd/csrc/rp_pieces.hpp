@@ -177,12 +177,44 @@ __device__ __forceinline__ chunk_desc_t make_chunk(const Clipped &c, long long t
 // with more than kMaxChunks chunks (or pieces > 4 GiB apart) is marked kTileSlow.
 constexpr int kRowBlock = 256;
 
+// Pieces that CONTINUE their predecessor -- the same base and direction: consecutive profile positions read consecutive
+// coverage elements, which is what a compact coverage with one-position blocks makes of exons that face each other
+// across an intron, and of consecutive ORFs on gapless layouts -- are staged as one RUN: the thread of the run's first
+// piece leaves with the whole run, the threads of the others with nothing.  Fewer, fuller chunks (a chunk never spans
+// two runs), and no partial cache line where two pieces meet.  Workgroup-uniform call; a run ends at the end of a batch
+// of kRowBlock pieces.
+// (Round 4 also built 16-byte-per-lane chunks for forward runs of >= 64 positions -- global_load_lds_dwordx4 does take a
+// source and an LDS address that are only 4-byte aligned, scripts/probes/dma16_probe.hip -- with a second row region and
+// a second issue loop: a fifth fewer requests, bit-identical results, and the fused kernel 10 % SLOWER on both bench
+// layouts, whether the quad part started with the run, at a 16-byte aligned source or at a 16-byte aligned LDS address
+// (profiles/r04_ab_quad_chunks.txt).  Source and destination alignments differ piece by piece, so one of the two is
+// always off; the dword chunks stay.)
+__device__ __forceinline__ Clipped merge_runs(Clipped c, long long base, long long *s_base, int *s_n, int *s_cont, int t)
+{
+    __syncthreads();  // (the arrays of the previous batch are consumed)
+    s_base[t] = base;
+    s_n[t] = c.neg ? -c.n : c.n;
+    __syncthreads();
+    const bool cont = t > 0 && c.n > 0 && s_n[t - 1] != 0 && (s_n[t - 1] < 0) == c.neg && s_base[t - 1] == base;
+    s_cont[t] = cont ? 1 : 0;
+    __syncthreads();
+    if (cont) {
+        c.n = 0;
+        return c;
+    }
+    if (c.n > 0)
+        for (int k = t + 1; k < kRowBlock && s_cont[k]; ++k) c.n += s_n[k] < 0 ? -s_n[k] : s_n[k];
+    return c;
+}
+
 template <int TILE, int HALO>
 __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, long long n_pieces, long long total_nt)
 {
     __shared__ long long s_j0, s_lo, s_hi;
     __shared__ int s_total, s_base, s_full, s_wide;
     __shared__ int s_wave[kRowBlock / 64];
+    __shared__ long long s_run_base[kRowBlock];
+    __shared__ int s_run_n[kRowBlock], s_run_cont[kRowBlock];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const long long b = blockIdx.x;
     const long long t0 = b * (long long)TILE;
@@ -219,7 +251,9 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
     for (long long j0 = s_j0;; j0 += kRowBlock) {  // workgroup-uniform
         const long long j = j0 + t;
         Clipped c{0, 0, 0, false};
-        if (j < n_pieces) c = clip_piece(plan.start[j], plan.start[j + 1], plan.base[j], t0, t_end);
+        const long long base = j < n_pieces ? plan.base[j] : 0;
+        if (j < n_pieces) c = clip_piece(plan.start[j], plan.start[j + 1], base, t0, t_end);
+        c = merge_runs(c, base, s_run_base, s_run_n, s_run_cont, t);
         if (c.n > 0) {
             atomicMin(&s_lo, c.neg ? c.src - (c.n - 1) : c.src);
             atomicMax(&s_hi, c.neg ? c.src : c.src + c.n - 1);
@@ -244,7 +278,9 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
     for (long long j0 = s_j0;; j0 += kRowBlock) {
         const long long j = j0 + t;
         Clipped c{0, 0, 0, false};
-        if (j < n_pieces) c = clip_piece(plan.start[j], plan.start[j + 1], plan.base[j], t0, t_end);
+        const long long base = j < n_pieces ? plan.base[j] : 0;
+        if (j < n_pieces) c = clip_piece(plan.start[j], plan.start[j + 1], base, t0, t_end);
+        c = merge_runs(c, base, s_run_base, s_run_n, s_run_cont, t);
         const int nch = (c.n + 63) >> 6;
         int incl = nch;
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);

@@ -166,26 +166,42 @@ def interval_table_from_index(index, base) -> IntervalTable:
     return IntervalTable(iv_start, iv_len, arrays[2].copy(), np.ascontiguousarray(index.reverse, dtype=np.uint8).copy(), offsets)
 
 
-class CoverageMap:
-    """Block map of a COMPACT coverage (``rp_coverage_map_create_dev``): of the dense layout only the 64-position blocks
-    under an exon interval get a slot -- the reference never looks anything else up (detect_orfs.py:176-187) -- so the
-    coverage of a human-sized index takes a tenth of the dense array's memory, allocation time and memset.  Built once per
-    index (it depends on the interval table only); ``table`` is the interval table in COMPACT coordinates (an interval
-    stays contiguous), ``compact_len`` the coverage length, ``dense_len`` what the alignment rows' layout spans.  Owns its
-    device memory."""
+COVERAGE_BLOCK = 1  # positions per block of a compact coverage (RIBOTRICER_AMD_COVERAGE_BLOCK: a power of two, 1 ... 64)
 
-    def __init__(self, dense_table: IntervalTable, dense_len: int, device=None):
+
+def coverage_block() -> int:
+    import os
+
+    block = int(os.environ.get("RIBOTRICER_AMD_COVERAGE_BLOCK", COVERAGE_BLOCK))
+    if block < 1 or block > 64 or block & (block - 1):
+        raise ValueError(f"RIBOTRICER_AMD_COVERAGE_BLOCK must be a power of two from 1 to 64, got {block}")
+    return block
+
+
+class CoverageMap:
+    """Block map of a COMPACT coverage (``rp_coverage_map_create_dev``): of the dense layout only the blocks of
+    ``block_positions`` positions under an exon interval get a slot -- the reference never looks anything else up
+    (detect_orfs.py:176-187) -- so the coverage of a human-sized index takes a tenth of the dense array's memory,
+    allocation time and memset.  With one-position blocks (the default) the coverage holds exonic positions only: exons
+    that face each other across an intron become neighbours, a spliced ORF's pieces merge into one run of the gather
+    plan, and the fused kernel stops paying for the cache lines at both ends of every exon.  Built once per index (it
+    depends on the interval table only); ``table`` is the interval table in COMPACT coordinates (an interval stays
+    contiguous), ``compact_len`` the coverage length, ``dense_len`` what the alignment rows' layout spans.  Owns its
+    device memory (dense_len / 4 bytes for one-position blocks, dense_len / 256 for 64-position ones)."""
+
+    def __init__(self, dense_table: IntervalTable, dense_len: int, device=None, block_positions: int | None = None):
         dev = get_engine(device).device
         self.device = dev
         self.dense_len = int(dense_len)
+        self.block_positions = int(block_positions) if block_positions is not None else coverage_block()
         nbytes = ctypes.c_size_t(0)
-        _lib.check(_lib.load().rp_coverage_map_bytes(self.dense_len, ctypes.byref(nbytes)))
+        _lib.check(_lib.load().rp_coverage_map_bytes(self.dense_len, self.block_positions, ctypes.byref(nbytes)))
         self._mem = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
         iv_start = _as_device(dense_table.iv_start, torch.int64, dev).clone()  # (rewritten in place: dense -> compact)
         iv_len = _as_device(dense_table.iv_len, torch.int32, dev)
         compact = ctypes.c_int64(0)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(_lib.load().rp_coverage_map_create_dev(dev.index, _ptr(iv_start), _ptr(iv_len), iv_start.numel(), self.dense_len,
+        _lib.check(_lib.load().rp_coverage_map_create_dev(dev.index, _ptr(iv_start), _ptr(iv_len), iv_start.numel(), self.dense_len, self.block_positions,
                                                          _ptr(self._mem), self._mem.numel(), stream, ctypes.byref(compact)))
         self.compact_len = int(compact.value)
         self.table = IntervalTable(iv_start.cpu().numpy(), dense_table.iv_len, dense_table.orf_iv, dense_table.reverse, dense_table.offsets)
@@ -270,7 +286,7 @@ class GatherPlan:
 
     def stats(self) -> dict:
         """Diagnostics (scripts): how the tiles of this plan are staged -- chunk rows per tile (<= 64
-        positions of one exon each; 352 fit a row, more take the scalar slow path), read back from the plan memory
+        positions of one run each; 352 fit a row, more take the scalar slow path), read back from the plan memory
         (layout: csrc/rp_pieces.hpp ``carve_piece_plan`` behind the 128-byte header)."""
         tile = _lib.tile_positions(self.n_orfs, self.total_nt)
         n_tiles = max(1, -(-self.total_nt // tile))

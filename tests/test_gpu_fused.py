@@ -88,11 +88,12 @@ def test_gather_selected_equals_the_sub_table_gather():
         assert torch.equal(sub, counts)
 
 
-def test_compact_coverage_map():
-    """gather.CoverageMap: only the 64-position blocks under an exon interval keep a slot.  The table in compact
+@pytest.mark.parametrize("block", [1, 8, 64])
+def test_compact_coverage_map(block):
+    """gather.CoverageMap: only the blocks of `block` positions under an exon interval keep a slot.  The table in compact
     coordinates reads out of the compact coverage exactly what the dense table reads out of the dense one (per-ORF gather,
-    tile gather, fused scores bit for bit), the compact length is the number of kept blocks x 64, and positions under no
-    exon have no slot."""
+    tile gather, fused scores bit for bit), the compact length is the number of kept blocks x block, and positions under
+    no exon have no slot.  With one-position blocks the plan stages merged runs: fewer chunks than pieces need alone."""
     import torch
 
     from ribotricer_amd.engine import get_engine, make_filter
@@ -102,26 +103,64 @@ def test_compact_coverage_map():
     dense_len = 3_000_000
     cov = rng.poisson(0.5, size=dense_len).astype(np.int32)
     t = random_table(rng, 5000, dense_len, max_exons=5, exon_len=(1, 500))
-    cmap = CoverageMap(t, dense_len)
-    blocks = np.zeros((dense_len + 63) // 64, bool)
+    cmap = CoverageMap(t, dense_len, block_positions=block)
+    assert cmap.block_positions == block
+    blocks = np.zeros((dense_len + block - 1) // block, bool)
     for s0, n in zip(t.iv_start, t.iv_len):
-        blocks[s0 // 64 : (s0 + n - 1) // 64 + 1] = True
-    assert cmap.compact_len == 64 * int(blocks.sum()) < dense_len
+        blocks[s0 // block : (s0 + n - 1) // block + 1] = True
+    assert cmap.compact_len == block * int(blocks.sum()) < dense_len
     slot_of_block = np.cumsum(blocks) - 1
-    want_start = slot_of_block[t.iv_start // 64] * 64 + t.iv_start % 64
+    want_start = slot_of_block[t.iv_start // block] * block + t.iv_start % block
     assert np.array_equal(cmap.table.iv_start, want_start)
-    compact = np.zeros(cmap.compact_len, np.int32)
-    kept = np.flatnonzero(blocks)
-    for k, b in enumerate(kept):  # the compact coverage as the build kernel would fill it
-        seg = cov[64 * b : 64 * b + 64]
-        compact[64 * k : 64 * k + seg.size] = seg
+    padded = np.zeros(blocks.size * block, np.int32)
+    padded[:dense_len] = cov
+    compact = padded.reshape(-1, block)[blocks].reshape(-1)  # the compact coverage as the build kernel would fill it
+    assert compact.size == cmap.compact_len
     dense_counts, _ = gather_profiles_device(cov, t)
     compact_counts, _ = gather_profiles_device(compact, cmap.table)
     assert torch.equal(dense_counts, compact_counts)
     eng = get_engine("cuda:0")
-    a = eng.score_coverage(cov, GatherPlan(t, dense_len), thresholds=make_filter()).cpu_numpy()
-    b = eng.score_coverage(compact, GatherPlan(cmap.table, cmap.compact_len), thresholds=make_filter()).cpu_numpy()
+    dense_plan, compact_plan = GatherPlan(t, dense_len), GatherPlan(cmap.table, cmap.compact_len)
+    a = eng.score_coverage(cov, dense_plan, thresholds=make_filter()).cpu_numpy()
+    b = eng.score_coverage(compact, compact_plan, thresholds=make_filter()).cpu_numpy()
     assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert compact_plan.stats()["slow_tiles"] == 0
+
+
+def test_contiguous_pieces_are_staged_as_runs():
+    """Exons that face each other across an intron are neighbours in a compact coverage with one-position blocks: the plan
+    stages them as one run (chunks of 64 positions that span the exon boundaries), so a layout without reuse needs about
+    tile / 64 chunks per tile whatever its exon structure -- and reads the same counts."""
+    import torch
+
+    from ribotricer_amd.engine import get_engine, make_filter
+    from ribotricer_amd.gather import CoverageMap, GatherPlan, IntervalTable, gather_profiles_device
+    from ribotricer_amd.synth import orf_lengths, synth_exon_layout
+
+    lengths = orf_lengths(40_000, 5, "cfg3")
+    iv_start, iv_len, orf_iv, reverse, offsets, dense_len = synth_exon_layout(lengths, 5)
+    t = IntervalTable(iv_start, iv_len, orf_iv, reverse, offsets)
+    rng = np.random.default_rng(9)
+    cov = rng.poisson(0.7, size=dense_len).astype(np.int32)
+    stats = {}
+    results = {}
+    for block in (64, 1):
+        cmap = CoverageMap(t, dense_len, block_positions=block)
+        padded = np.zeros(-(-dense_len // block) * block, np.int32)
+        padded[:dense_len] = cov
+        blocks = np.zeros(padded.size // block, bool)
+        for s0, n in zip(t.iv_start, t.iv_len):
+            blocks[s0 // block : (s0 + n - 1) // block + 1] = True
+        compact = padded.reshape(-1, block)[blocks].reshape(-1)
+        plan = GatherPlan(cmap.table, cmap.compact_len)
+        stats[block] = plan.stats()
+        results[block] = get_engine("cuda:0").score_coverage(compact, plan, thresholds=make_filter()).cpu_numpy()
+        counts, _ = gather_profiles_device(compact, cmap.table)
+        want, _ = gather_profiles_device(cov, t)
+        assert torch.equal(counts, want)
+    assert all(np.array_equal(results[1][k], results[64][k]) for k in results[1])
+    assert stats[1]["slow_tiles"] == stats[64]["slow_tiles"] == 0
+    assert stats[1]["chunks_per_tile_mean"] < 0.95 * stats[64]["chunks_per_tile_mean"]
 
 
 def test_unplannable_tables():
