@@ -160,15 +160,40 @@ __device__ __forceinline__ Clipped clip_piece(unsigned long long start_word, uns
 constexpr long long kMaxTileSpan = (1ll << 37) - 256;  // positions between a tile's lowest and highest source (7 + 32 bits of byte offset)
 constexpr unsigned kMaxChunkLow = 0xfffffe00u;         // a lane adds up to 252 to the low half in 32-bit arithmetic
 
-__device__ __forceinline__ chunk_desc_t make_chunk(const Clipped &c, long long tile_lo, int k, bool *low_half_full)
+// Where a run is cut into chunks: at multiples of 64 ELEMENTS OF THE COVERAGE (256-byte lines of the source: the
+// array is allocated on such a boundary), not at multiples of 64 positions of the run -- a chunk then asks the L1 for
+// two whole cache lines instead of three partial ones, and no line is asked for by two chunks of one run (the fused
+// kernel sent 1.8x the plain kernel's read requests to the L2: profiles/r04_fused_ta_tcp_counters.txt).  The price is
+// the run's first chunk: `head` positions up to the first boundary (0: the run starts on one).
+#ifndef RP_CHUNK_ALIGN
+#define RP_CHUNK_ALIGN 1
+#endif
+__device__ __forceinline__ int run_head(const Clipped &c)
+{
+#if RP_CHUNK_ALIGN
+    const int head = c.neg ? (int)((c.src + 1) & 63) : (int)((64 - (c.src & 63)) & 63);
+    return head < c.n ? head : 0;  // (a run that ends before the boundary is one chunk anyway)
+#else
+    return 0;
+#endif
+}
+__device__ __forceinline__ int run_chunks(const Clipped &c, int head) { return (head ? 1 : 0) + ((c.n - head + 63) >> 6); }
+
+__device__ __forceinline__ chunk_desc_t make_chunk(const Clipped &c, long long tile_lo, int k, int head, bool *low_half_full)
 {
     const unsigned long long rel = (unsigned long long)(c.src - tile_lo);  // >= 64, < 2^37 (checked by the caller)
-    const int left = c.n - 64 * k;
-    const unsigned cnt = left < 64 ? (unsigned)left : 64u;
-    const unsigned long long soff = (c.neg ? rel - 64ull * k - 63ull : rel + 64ull * k) * 4ull;
+    int p, cnt;  // positions [p, p + cnt) of the run
+    if (head && k == 0) {
+        p = 0;
+        cnt = head;
+    } else {
+        p = head + 64 * (k - (head ? 1 : 0));
+        cnt = c.n - p < 64 ? c.n - p : 64;
+    }
+    const unsigned long long soff = (c.neg ? rel - (unsigned long long)p - 63ull : rel + (unsigned long long)p) * 4ull;
     const unsigned lo = (unsigned)soff;
     if (lo > kMaxChunkLow) *low_half_full = true;  // (6e-8 of the chunks: the tile takes the slow path)
-    return (chunk_desc_t)lo | ((chunk_desc_t)(unsigned)(c.off + 64 * k) << 32) | ((chunk_desc_t)(64u - cnt) << 45) |
+    return (chunk_desc_t)lo | ((chunk_desc_t)(unsigned)(c.off + p) << 32) | ((chunk_desc_t)(64u - (unsigned)cnt) << 45) |
            ((chunk_desc_t)(c.neg ? 1u : 0u) << 51) | ((chunk_desc_t)(soff >> 32) << 52);
 }
 
@@ -257,7 +282,7 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
         if (c.n > 0) {
             atomicMin(&s_lo, c.neg ? c.src - (c.n - 1) : c.src);
             atomicMax(&s_hi, c.neg ? c.src : c.src + c.n - 1);
-            atomicAdd(&s_total, (c.n + 63) >> 6);
+            atomicAdd(&s_total, run_chunks(c, run_head(c)));
         }
         const long long last = j0 + kRowBlock;  // does the tile go on past this batch?
         if (!(last < n_pieces && (long long)(plan.start[last] & ~kPieceNeg) < t_end)) break;
@@ -281,7 +306,8 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
         const long long base = j < n_pieces ? plan.base[j] : 0;
         if (j < n_pieces) c = clip_piece(plan.start[j], plan.start[j + 1], base, t0, t_end);
         c = merge_runs(c, base, s_run_base, s_run_n, s_run_cont, t);
-        const int nch = (c.n + 63) >> 6;
+        const int head = c.n > 0 ? run_head(c) : 0;
+        const int nch = c.n > 0 ? run_chunks(c, head) : 0;
         int incl = nch;
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
@@ -296,7 +322,7 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
         for (int w = 0; w < wave; ++w) c0 += s_wave[w];
         bool full = false;
         for (int k = 0; k < nch; ++k) {
-            const chunk_desc_t cd = make_chunk(c, tile_lo, k, &full);
+            const chunk_desc_t cd = make_chunk(c, tile_lo, k, head, &full);
             row[c0 + k] = cd;
             if ((cd >> 52) != 0) s_wide = 1;  // (benign race: every writer stores 1)
         }
