@@ -84,6 +84,15 @@ def test_argument_errors_do_not_need_a_gpu():
     assert lib.rp_plan_create_dev(0, None, 10, 3000, 0, None, 0, None, ctypes.byref(handle)) == -1
     assert lib.rp_phase_score_csr_plan_dev(None, None, None, None, None, None, None, None, None, None, None, 0, None) == -1
     lib.rp_plan_free(None)
+    # the compact coverage's block map: blocks of 1 ... 64 positions, powers of two; one bit per block + 8 bytes per 64 blocks
+    assert lib.rp_coverage_map_bytes(1 << 20, 64, ctypes.byref(out)) == 0
+    coarse = out.value
+    assert lib.rp_coverage_map_bytes(1 << 20, 1, ctypes.byref(out)) == 0
+    assert 60 * coarse > out.value > 20 * coarse and out.value >= (1 << 20) // 4
+    for bad in (0, 3, 128, -1):
+        assert lib.rp_coverage_map_bytes(1 << 20, bad, ctypes.byref(out)) == -8 and b"power of two" in lib.rp_last_error()
+    assert lib.rp_coverage_map_bytes(-1, 1, ctypes.byref(out)) == -2
+    assert lib.rp_coverage_map_bytes(1 << 20, 1, None) == -1
 
 
 def test_no_cpu_fallback_without_gpu():
