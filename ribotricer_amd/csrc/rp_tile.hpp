@@ -1191,6 +1191,11 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score_probe(c
 // pass 3: one thread per ORF -- add the records of the tiles it spans, score, filter,
 // store.  Too-close-to-call ORFs (~0.4 %) are re-walked in float64 by the wave that found
 // them, one after the other: short ones on the spot, long ones queued for pass 4.
+// (Round 4 measured what the re-walks cost the pass -- 0.258 ms with them, 0.162 without at 11 M ORFs; 0.063 / 0.022 at
+// 1 M -- and rebuilt the queue with 64 lists in 64 cache lines and a wave-per-ORF drain kernel behind the pass: 0.297 /
+// 0.074 ms, slower again.  It is not the imbalance: 0.6 % of the ORFs are exact frame ties, each replay is a serial
+// float64 fold, and spread over the 172 000 waves of this pass that work hides better than in a kernel of its own;
+// profiles/r04_ab_finish_rewalk.txt, r04_ab_finish_rewalk_queue.patch.)
 // (Measured alternatives, both slower: a global queue filled with one atomicAdd per wave and
 // drained by a wave-per-ORF kernel -- 40 000 atomics on one word cost 0.46 ms at 11 M ORFs,
 // profiles/r03_ab_finish_split.txt; finishing one-tile ORFs inside the scoring kernel -- +12 %
@@ -1321,6 +1326,9 @@ __global__ __launch_bounds__(kFinishBlock, RP_FINISH_WAVES) void k_orf_finish(So
     // float64 walk from global memory (the integer results stand: they are exact), then -- on an
     // exact frame tie -- the replay of the reference's own arithmetic (rp_device.hpp).
     unsigned long long todo = __ballot(unsafe);
+#ifdef RP_EXPERIMENT_NO_REWALK  // timing experiment only (results wrong): what the in-wave re-walks cost the finish pass
+    todo = 0;
+#endif
     while (todo != 0) {
         const int l = __builtin_ctzll(todo);
         todo &= todo - 1;
