@@ -1175,21 +1175,61 @@ int rp_interval_table_host(const int64_t *iv_start, const int64_t *iv_end, const
     if (!out_offsets || !orf_iv || (n_orfs > 0 && (!group || !length || !group_start || !group_lo)) ||
         (n_intervals > 0 && (!iv_start || !iv_end || !out_iv_start || !out_iv_len)))
         return fail(RP_ERR_NULL, "index arrays and outputs must be non-null");
-    int64_t total = 0;
+    // ORF ranges side by side (22.8 M intervals: 85 ms on one core, most of it first-touch page faults of the outputs):
+    // every thread writes its intervals and the running length sums of ITS range, the ranges' totals are scanned, and a
+    // second sweep adds each range's base to its offsets
     out_offsets[0] = 0;
-    for (int64_t i = 0; i < n_orfs; ++i) {
-        const int32_t g = group[i];
-        const int64_t k0 = orf_iv[i], k1 = orf_iv[i + 1];
-        if (g < 0 || g >= n_groups || k0 < 0 || k1 < k0 || k1 > n_intervals)
-            return fail(RP_ERR_ARG, "ORF %lld: group %d / interval range [%lld, %lld) out of range", (long long)i, (int)g, (long long)k0, (long long)k1);
-        const int64_t shift = group_start[g] - group_lo[g];
-        for (int64_t k = k0; k < k1; ++k) {
-            out_iv_start[k] = iv_start[k] + shift;
-            out_iv_len[k] = (int32_t)(iv_end[k] - iv_start[k] + 1);
+    int threads = rphost::usable_threads();
+    if (threads > 32) threads = 32;
+    if (n_orfs < 200000) threads = 1;
+    struct Part {
+        int64_t total = 0, bad = -1;
+    };
+    std::vector<Part> parts((size_t)threads);
+    auto range = [&](int t) { return std::pair<int64_t, int64_t>{n_orfs * t / threads, n_orfs * (t + 1) / threads}; };
+    auto fill = [&](int t) {
+        const auto [a, b] = range(t);
+        int64_t total = 0;
+        for (int64_t i = a; i < b; ++i) {
+            const int32_t g = group[i];
+            const int64_t k0 = orf_iv[i], k1 = orf_iv[i + 1];
+            if (g < 0 || g >= n_groups || k0 < 0 || k1 < k0 || k1 > n_intervals) {
+                parts[(size_t)t].bad = i;
+                return;
+            }
+            const int64_t shift = group_start[g] - group_lo[g];
+            for (int64_t k = k0; k < k1; ++k) {
+                out_iv_start[k] = iv_start[k] + shift;
+                out_iv_len[k] = (int32_t)(iv_end[k] - iv_start[k] + 1);
+            }
+            total += length[i];
+            out_offsets[i + 1] = total;
         }
-        total += length[i];
-        out_offsets[i + 1] = total;
+        parts[(size_t)t].total = total;
+    };
+    auto rebase = [&](int t, int64_t base) {
+        const auto [a, b] = range(t);
+        for (int64_t i = a; i < b; ++i) out_offsets[i + 1] += base;
+    };
+    auto run = [&](auto &&fn) {
+        if (threads == 1) {
+            fn(0);
+            return;
+        }
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t) pool.emplace_back(fn, t);
+        for (auto &th : pool) th.join();
+    };
+    run(fill);
+    for (int t = 0; t < threads; ++t) {
+        const int64_t i = parts[(size_t)t].bad;
+        if (i >= 0)
+            return fail(RP_ERR_ARG, "ORF %lld: group %d / interval range [%lld, %lld) out of range", (long long)i, (int)group[i],
+                        (long long)orf_iv[i], (long long)orf_iv[i + 1]);
     }
+    std::vector<int64_t> base((size_t)threads, 0);
+    for (int t = 1; t < threads; ++t) base[(size_t)t] = base[(size_t)t - 1] + parts[(size_t)t - 1].total;
+    if (threads > 1) run([&](int t) { if (base[(size_t)t] != 0) rebase(t, base[(size_t)t]); });
     return RP_OK;
 }
 

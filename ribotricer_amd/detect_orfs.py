@@ -388,7 +388,7 @@ def _table_and_plan(index, base, coverage_len: int, device, table=None):
         cache.clear()  # (one layout per index: another one replaces it)
         extras: dict = {}
         plan_len = coverage_len
-        if _compact_coverage() and len(table.iv_start):
+        if _compact_coverage() and len(table.iv_len):
             from ._lib import ERR_INTERVALS, RibophaseError
 
             try:

@@ -224,6 +224,41 @@ def test_native_index_equals_python_parser(packed):
     assert np.array_equal(tb.offsets, offsets)
 
 
+def test_interval_table_pass_in_threads():
+    """rp_interval_table_host cuts an index of more than 200 000 ORFs into ORF ranges, one per thread (per-range
+    length sums, scanned, then re-based): the same table as numpy makes, and the first bad ORF is the one reported."""
+    import types
+
+    from ribotricer_amd import _lib
+    from ribotricer_amd.gather import interval_table_from_index
+
+    rng = np.random.default_rng(8)
+    n = 450_001
+    n_ex = rng.integers(1, 5, n)
+    orf_iv = np.zeros(n + 1, np.int64)
+    np.cumsum(n_ex, out=orf_iv[1:])
+    m = int(orf_iv[-1])
+    ex_len = rng.integers(1, 400, m).astype(np.int64)
+    gap = rng.integers(0, 50, m)
+    start = np.cumsum(gap + ex_len) - ex_len + 1000
+    group = np.repeat(rng.integers(0, 3, n).astype(np.int32), 1)
+    length = np.add.reduceat(ex_len, orf_iv[:-1])
+    keys = [("+", "a"), ("+", "b"), ("-", "a")]
+    base = {keys[0]: (0, 1000), keys[1]: (10**9, 7), keys[2]: (3 * 10**9, 123)}
+    index = types.SimpleNamespace(group_keys=keys, n_orfs=n, iv_start=start, iv_end=start + ex_len - 1, orf_iv=orf_iv, group=group, length=length,
+                                  reverse=np.zeros(n, np.uint8))
+    t = interval_table_from_index(index, base)
+    shift = np.array([base[k][0] - base[k][1] for k in keys], np.int64)
+    assert np.array_equal(t.iv_start, start + np.repeat(shift[group], n_ex))
+    assert np.array_equal(t.iv_len, ex_len.astype(np.int32))
+    assert np.array_equal(t.offsets, np.concatenate(([0], np.cumsum(length))))
+    index.group = group.copy()
+    index.group[[400_000, 123_456]] = 7
+    with pytest.raises(_lib.RibophaseError) as e:
+        interval_table_from_index(index, base)
+    assert "ORF 123456" in str(e.value)
+
+
 def test_native_index_line_semantics():
     from ribotricer_amd.index import NativeIndex
 
