@@ -171,8 +171,8 @@ constexpr unsigned kMaxChunkLow = 0xfffffe00u;         // a lane adds up to 252 
 __device__ __forceinline__ int run_head(const Clipped &c)
 {
 #if RP_CHUNK_ALIGN
-    const int head = c.neg ? (int)((c.src + 1) & 63) : (int)((64 - (c.src & 63)) & 63);
-    return head < c.n ? head : 0;  // (a run that ends before the boundary is one chunk anyway)
+    if (c.n < 64) return 0;  // (one chunk either way; cut in two it would only fill the rows of short-exon layouts sooner)
+    return c.neg ? (int)((c.src + 1) & 63) : (int)((64 - (c.src & 63)) & 63);
 #else
     return 0;
 #endif
@@ -354,6 +354,12 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
 // loop over pieces, with its decode and branch chain, was measured at ~1 000 cycles per piece
 // next to three other workgroups' lane runs: one instruction per ~10 cycles.)
 // Nothing is waited for here.
+// (Round 4: the scorer runs at 80 % VALU occupancy, the fused kernel at 87 %, and four MORE vector instructions per step
+// cost the fused kernel 9 % -- but taking the four it has OUT did not pay: chunks issued through the scalar unit
+// (descriptors by s_load_dwordx16, eight to a group, the next group in flight; direction-sorted groups; five scalar
+// instructions and the load per chunk, no vector instruction at all) came out at -1.5 % on the nested law and +2 % on
+// the exon layout, a first version with the direction branch per chunk at +7 % / +4 %: the scalar loads' latency takes
+// what the vector instructions gave.  profiles/r04_ab_scalar_issue.txt, r04_ab_scalar_issue_v1.patch, _v2.patch.)
 // ---------------------------------------------------------------------------------------
 #ifndef RP_CHUNK_POLICY
 #define RP_CHUNK_POLICY " nt"  // the coverage is read once per launch: tile gather -5 % on gapped / 60-nt layouts, else unchanged
