@@ -163,6 +163,64 @@ def test_contiguous_pieces_are_staged_as_runs():
     assert stats[1]["chunks_per_tile_mean"] < 0.95 * stats[64]["chunks_per_tile_mean"]
 
 
+def abutting_table(rng, n, cov_len):
+    """ORFs laid along the coverage with exons that often ABUT (gap 0: pieces that continue their predecessor, staged
+    as one run), lengths around the chunk size and starts around the 256-byte lines of the source -- the places where
+    the run merge and the source-aligned chunk cuts of k_chunk_rows decide something."""
+    from ribotricer_amd.gather import IntervalTable
+
+    lens_pool = np.array([1, 2, 3, 5, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 200, 640, 1000, 9000], np.int64)
+    n_iv = rng.integers(1, 7, size=n)
+    orf_iv = np.concatenate([[0], np.cumsum(n_iv)]).astype(np.int64)
+    m = int(orf_iv[-1])
+    iv_len = rng.choice(lens_pool, size=m)
+    gap = np.where(rng.random(m) < 0.55, 0, rng.integers(1, 200, size=m))
+    snap = rng.random(m) < 0.3  # some exons start exactly on / next to a 64-element boundary
+    iv_start = np.zeros(m, np.int64)
+    at = 70
+    for k in range(m):
+        s0 = at + int(gap[k])
+        if snap[k]:
+            s0 = (s0 + 63) // 64 * 64 + int(rng.integers(-1, 2))
+            s0 = max(s0, at)
+        iv_start[k] = s0
+        at = s0 + int(iv_len[k])
+    assert at < cov_len
+    reverse = (rng.random(n) < 0.5).astype(np.uint8)
+    reverse[: n // 4] = 0  # a stretch of forward ORFs in a row: runs that span ORFs
+    reverse[n // 4 : n // 2] = 1
+    lengths = np.add.reduceat(iv_len, orf_iv[:-1])
+    offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    return IntervalTable(iv_start, iv_len.astype(np.int32), orf_iv, reverse, offsets)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_abutting_exons_and_line_boundaries(seed):
+    """Run merge + source-aligned cuts: the tile gather equals numpy's orf_coverage, the fused scores equal
+    gather-then-score bit for bit, and no tile falls back to the slow path (that merging happens is
+    test_contiguous_pieces_are_staged_as_runs' business)."""
+    import torch
+
+    from ribotricer_amd.engine import get_engine, make_filter
+    from ribotricer_amd.gather import GatherPlan, gather_profiles_device
+
+    rng = np.random.default_rng(seed)
+    n = 3000
+    cov_len = 12_000_000
+    cov = rng.poisson(0.6, size=cov_len).astype(np.int32)
+    t = abutting_table(rng, n, cov_len)
+    plan = GatherPlan(t, cov_len)
+    st = plan.stats()
+    assert st["slow_tiles"] == 0
+    got, _ = gather_profiles_device(cov, t, plan=plan)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.cpu().numpy(), numpy_gather(cov, t))
+    eng = get_engine("cuda:0")
+    fused = eng.score_coverage(cov, plan, thresholds=make_filter()).cpu_numpy()
+    two_step = eng.score(got, torch.from_numpy(t.offsets).cuda(), thresholds=make_filter(), algo="tile").cpu_numpy()
+    assert all(np.array_equal(fused[k], two_step[k]) for k in fused)
+
+
 def test_unplannable_tables():
     from ribotricer_amd import _lib
     from ribotricer_amd.gather import GatherPlan, IntervalTable, make_gather_plan
