@@ -77,7 +77,15 @@ def _require_gpu() -> None:
 
 def _as_device(x, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
     if isinstance(x, np.ndarray):
-        x = torch.from_numpy(np.ascontiguousarray(x))
+        x = np.ascontiguousarray(x)
+        if x.flags.writeable:
+            x = torch.from_numpy(x)
+        else:  # (a read-only view of a parsed index: only ever copied FROM -- torch's "not writable" warning is not for this)
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", UserWarning)
+                x = torch.from_numpy(x)
     elif not isinstance(x, torch.Tensor):
         x = torch.as_tensor(x)
     if x.dtype != dtype:
