@@ -25,20 +25,25 @@ namespace rp {
 typedef unsigned long long chunk_desc_t;
 
 constexpr unsigned long long kPieceNeg = 1ull << 63;  // start word: the piece runs down the coverage array
-constexpr int kMaxChunks = 352;                    // chunks in a tile's fixed-stride row (2.75 KiB per 31 KiB tile)
+constexpr int kMaxChunks = 352;                    // slots of a tile's fixed-stride row (2.75 KiB per 31 KiB tile)
+constexpr int kFastSlots = 256;                    // the slots the fast path stages from: four waves x 64 lanes
 constexpr long long kTileSlow = INT64_MIN;         // tile_lo of a tile whose chunks do not fit its row
 
-// A chunk (8 bytes): <= 64 consecutive positions of one piece, inside one tile.
+// A chunk (8 bytes): <= 64 consecutive positions of one run, inside one tile -- every field one scalar instruction
+// away from where the issuing code needs it.
 //   bits  0-31  byte offset of the chunk's lowest-ADDRESS element from cov + tile_lo, low half
-//   bits 32-44  LDS index of its first position
-//   bits 45-50  64 - positions
-//   bit  51     the source index falls as the position rises ('-' strand piece)
-//   bits 52-58  the byte offset's high half (units of 4 GiB; round 4): the pieces of one tile may lie anywhere
+//   bits 32-37  64 - positions (the low six bits of the high word: a 64-bit shift takes its count from there)
+//   bit  38     the source index falls as the position rises ('-' strand piece)
+//   bits 39-45  the byte offset's high half (units of 4 GiB; round 4): the pieces of one tile may lie anywhere
 //               in a coverage of up to 512 GiB -- an index whose consecutive transcripts sit on different
 //               chromosomes (gigabytes apart in the dense coverage) sent 93 % of its tiles down the scalar slow
 //               path while the offset had 32 bits (profiles/r04_fused_nested_before.json)
-// Unused slots of a row repeat the row's chunk 0 (staging a chunk twice is harmless), so the
-// issuing code never has to ask how many there are.
+//   bits 48-63  LDS BYTE offset of its first position (the high word >> 16)
+// The first kFastSlots slots of a row are what the fast path stages from, thread (wave w, lane i) holding slot 4 i + w:
+// the FORWARD chunks fill them from slot 0 upwards, the '-' strand chunks from slot kFastSlots - 1 downwards, so that
+// every wave issues its forward chunks from lane 0 up and its reverse chunks from lane 63 down, each with its own
+// loop-invariant lane offsets.  Both regions are padded to whole blocks of four lanes with copies of a chunk of their
+// direction (staging a chunk twice is harmless): the issuing code tests for the end every four steps.
 
 struct PiecePlan {
     const unsigned long long *start;  // [n_pieces + 1] first profile position | kPieceNeg; sentinel total_nt
@@ -158,7 +163,6 @@ __device__ __forceinline__ Clipped clip_piece(unsigned long long start_word, uns
 }
 
 constexpr long long kMaxTileSpan = (1ll << 37) - 256;  // positions between a tile's lowest and highest source (7 + 32 bits of byte offset)
-constexpr unsigned kMaxChunkLow = 0xfffffe00u;         // a lane adds up to 252 to the low half in 32-bit arithmetic
 
 // Where a run is cut into chunks: at multiples of 64 ELEMENTS OF THE COVERAGE (256-byte lines of the source: the
 // array is allocated on such a boundary), not at multiples of 64 positions of the run -- a chunk then asks the L1 for
@@ -179,7 +183,7 @@ __device__ __forceinline__ int run_head(const Clipped &c)
 }
 __device__ __forceinline__ int run_chunks(const Clipped &c, int head) { return (head ? 1 : 0) + ((c.n - head + 63) >> 6); }
 
-__device__ __forceinline__ chunk_desc_t make_chunk(const Clipped &c, long long tile_lo, int k, int head, bool *low_half_full)
+__device__ __forceinline__ chunk_desc_t make_chunk(const Clipped &c, long long tile_lo, int k, int head)
 {
     const unsigned long long rel = (unsigned long long)(c.src - tile_lo);  // >= 64, < 2^37 (checked by the caller)
     int p, cnt;  // positions [p, p + cnt) of the run
@@ -190,12 +194,13 @@ __device__ __forceinline__ chunk_desc_t make_chunk(const Clipped &c, long long t
         p = head + 64 * (k - (head ? 1 : 0));
         cnt = c.n - p < 64 ? c.n - p : 64;
     }
+    // (the issuing code adds the offset to the tile's base in 64-bit scalar arithmetic and the lanes' own 0 ... 252 bytes
+    // in the address unit: no carry is lost, whatever the low half holds)
     const unsigned long long soff = (c.neg ? rel - (unsigned long long)p - 63ull : rel + (unsigned long long)p) * 4ull;
-    const unsigned lo = (unsigned)soff;
-    if (lo > kMaxChunkLow) *low_half_full = true;  // (6e-8 of the chunks: the tile takes the slow path)
-    return (chunk_desc_t)lo | ((chunk_desc_t)(unsigned)(c.off + p) << 32) | ((chunk_desc_t)(64u - (unsigned)cnt) << 45) |
-           ((chunk_desc_t)(c.neg ? 1u : 0u) << 51) | ((chunk_desc_t)(soff >> 32) << 52);
+    const unsigned hi = (64u - (unsigned)cnt) | ((c.neg ? 1u : 0u) << 6) | ((unsigned)(soff >> 32) << 7) | (((unsigned)(c.off + p) * 4u) << 16);
+    return (chunk_desc_t)(unsigned)soff | ((chunk_desc_t)hi << 32);
 }
+__device__ __forceinline__ bool chunk_is_wide(chunk_desc_t cd) { return ((cd >> 39) & 0x7full) != 0; }
 
 // One workgroup per tile: find the piece that holds the tile's first position, clip the
 // tile's pieces to [t0, t0 + TILE + HALO), number their chunks and write the row.  A tile
@@ -236,7 +241,7 @@ template <int TILE, int HALO>
 __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, long long n_pieces, long long total_nt)
 {
     __shared__ long long s_j0, s_lo, s_hi;
-    __shared__ int s_total, s_base, s_full, s_wide;
+    __shared__ int s_total, s_base, s_wide;
     __shared__ int s_wave[kRowBlock / 64];
     __shared__ long long s_run_base[kRowBlock];
     __shared__ int s_run_n[kRowBlock], s_run_cont[kRowBlock];
@@ -282,19 +287,21 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
         if (c.n > 0) {
             atomicMin(&s_lo, c.neg ? c.src - (c.n - 1) : c.src);
             atomicMax(&s_hi, c.neg ? c.src : c.src + c.n - 1);
-            atomicAdd(&s_total, run_chunks(c, run_head(c)));
+            atomicAdd(&s_total, run_chunks(c, run_head(c)) << (c.neg ? 16 : 0));  // forward | reverse << 16
         }
         const long long last = j0 + kRowBlock;  // does the tile go on past this batch?
         if (!(last < n_pieces && (long long)(plan.start[last] & ~kPieceNeg) < t_end)) break;
     }
     __syncthreads();
-    const bool fast = s_total > 0 && s_total <= kMaxChunks && s_hi - s_lo < kMaxTileSpan;
+    const int n_fwd = s_total & 0xffff, n_rev = s_total >> 16;  // (a tile owns < 8 000 positions: both fit 16 bits)
+    const int fwd_lanes = ((n_fwd + 3) / 4 + 3) / 4 * 4;  // lanes 0 ... of every wave that hold forward chunks or their padding
+    const int rev_lanes = ((n_rev + 3) / 4 + 3) / 4 * 4;  // lanes 63 ... downwards: the '-' strand ones
+    const bool fast = s_total > 0 && fwd_lanes + rev_lanes <= 64 && s_hi - s_lo < kMaxTileSpan;
     const long long tile_lo = fast ? s_lo - 64 : kTileSlow;
     if (t == 0) {
         plan.tile_lo[2 * b] = tile_lo;
-        plan.tile_lo[2 * b + 1] = s_total;
+        plan.tile_lo[2 * b + 1] = (long long)(unsigned)s_total;
         s_base = 0;
-        s_full = 0;
         s_wide = 0;
     }
     if (!fast) return;  // (the row stays unwritten: never read)
@@ -307,7 +314,8 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
         if (j < n_pieces) c = clip_piece(plan.start[j], plan.start[j + 1], base, t0, t_end);
         c = merge_runs(c, base, s_run_base, s_run_n, s_run_cont, t);
         const int head = c.n > 0 ? run_head(c) : 0;
-        const int nch = c.n > 0 ? run_chunks(c, head) : 0;
+        const int mine = c.n > 0 ? run_chunks(c, head) : 0;
+        const int nch = mine << (c.neg ? 16 : 0);  // (both prefix sums in one scan)
         int incl = nch;
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
@@ -318,92 +326,87 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
         __syncthreads();  // (s_wave / s_base of the previous batch are consumed)
         if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
-        int c0 = s_base + incl - nch;
-        for (int w = 0; w < wave; ++w) c0 += s_wave[w];
-        bool full = false;
-        for (int k = 0; k < nch; ++k) {
-            const chunk_desc_t cd = make_chunk(c, tile_lo, k, head, &full);
-            row[c0 + k] = cd;
-            if ((cd >> 52) != 0) s_wide = 1;  // (benign race: every writer stores 1)
+        int before = s_base + incl - nch;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        for (int k = 0; k < mine; ++k) {
+            const chunk_desc_t cd = make_chunk(c, tile_lo, k, head);
+            row[c.neg ? kFastSlots - 1 - ((before >> 16) + k) : (before & 0xffff) + k] = cd;
+            if (chunk_is_wide(cd)) s_wide = 1;  // (benign race: every writer stores 1)
         }
-        if (full) s_full = 1;
         __syncthreads();
         if (t == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         const long long last = j0 + kRowBlock;
         if (!(last < n_pieces && (long long)(plan.start[last] & ~kPieceNeg) < t_end)) break;
     }
     __syncthreads();
-    if (s_full) {  // a chunk's low offset half leaves no room for the lanes' own 252 bytes
-        if (t == 0) plan.tile_lo[2 * b] = kTileSlow;
-        return;
-    }
-    if (s_wide && t == 0) plan.tile_lo[2 * b + 1] = (long long)s_total | (1ll << 32);  // (kTileWide, defined below with its reader)
-    // pad: the slots past the last chunk repeat chunk 0 (written by the thread that owns position t0)
+    if (s_wide && t == 0) plan.tile_lo[2 * b + 1] = (long long)(unsigned)s_total | (1ll << 32);  // (kTileWide, defined below with its reader)
+    // pad: the slots up to the end of a direction's last block of four lanes repeat that direction's first chunk
     __threadfence_block();
-    const chunk_desc_t first = row[0];
-    for (int c = s_total + t; c < kMaxChunks; c += kRowBlock) row[c] = first;
+    if (n_fwd > 0) {
+        const chunk_desc_t first = row[0];
+        for (int c = n_fwd + t; c < 4 * fwd_lanes; c += kRowBlock) row[c] = first;
+    }
+    if (n_rev > 0) {
+        const chunk_desc_t first = row[kFastSlots - 1];
+        for (int c = n_rev + t; c < 4 * rev_lanes; c += kRowBlock) row[kFastSlots - 1 - c] = first;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
-// Staging a tile, the fast path.  Wave w, lane i takes chunk 4 i + w of the row (64 lanes x 4
-// waves = the first 256 chunks; a second round takes the rest) and keeps
-//   w0 = the chunk's byte offset, w1 = LDS address | (64 - positions) << 16 | dir << 24
-// in two registers; then 64 unrolled steps -- two lane reads, M0, the EXEC mask of the ragged
-// end, two VALU for the lane's byte offset ((lane or 63 - lane) * 4 + chunk offset), one
-// global_load_lds with a scalar base -- no branches but an exit test every 8 steps.  (A scalar
-// loop over pieces, with its decode and branch chain, was measured at ~1 000 cycles per piece
-// next to three other workgroups' lane runs: one instruction per ~10 cycles.)
+// Staging a tile, the fast path.  Thread (wave w, lane i) holds slot 4 i + w of the row in two registers (loaded with
+// the head row: loads that depend on blockIdx only); the wave then issues its FORWARD chunks from lane 0 upwards and
+// its '-' strand chunks from lane 63 downwards, straight-line code with an exit test every four steps.  A step is two
+// lane reads, EXEC from the high word's low six bits (the ragged end), M0 from its high half (the LDS address), a
+// 64-bit scalar add of the chunk's offset to the tile's base, and one global_load_lds whose vector operand is
+// loop-invariant: lane * 4 going up, (63 - lane) * 4 for a '-' strand chunk.  Two vector instructions per chunk, where
+// rounds 2-4 spent four (the lane's offset computed per step): the scorer runs at 80 % VALU occupancy and the fused
+// kernel at 87 %, and four MORE per step cost it 9 % (profiles/r04_ab_scalar_issue.txt; issuing through the scalar unit
+// alone -- descriptors by s_load_dwordx16 -- lost what it gained to the scalar loads' latency, which cannot be overlapped
+// beyond one group: scalar loads return out of order, the only wait is for all of them).  (A scalar loop over pieces,
+// with its decode and branch chain, was measured at ~1 000 cycles per piece next to three other workgroups' lane runs.)
 // Nothing is waited for here.
-// (Round 4: the scorer runs at 80 % VALU occupancy, the fused kernel at 87 %, and four MORE vector instructions per step
-// cost the fused kernel 9 % -- but taking the four it has OUT did not pay: chunks issued through the scalar unit
-// (descriptors by s_load_dwordx16, eight to a group, the next group in flight; direction-sorted groups; five scalar
-// instructions and the load per chunk, no vector instruction at all) came out at -1.5 % on the nested law and +2 % on
-// the exon layout, a first version with the direction branch per chunk at +7 % / +4 %: the scalar loads' latency takes
-// what the vector instructions gave.  profiles/r04_ab_scalar_issue.txt, r04_ab_scalar_issue_v1.patch, _v2.patch.)
 // ---------------------------------------------------------------------------------------
 #ifndef RP_CHUNK_POLICY
 #define RP_CHUNK_POLICY " nt"  // the coverage is read once per launch: tile gather -5 % on gapped / 60-nt layouts, else unchanged
 #endif
-// w1 = LDS address | (64 - positions) << 16 | dir << 24 | (byte offset >> 32) << 25.
-// NARROW step (all chunks of the tile within 4 GiB of its lowest source: every chromosome-sorted index): the scalar
-// base is the tile's own.  WIDE step (pieces of one tile anywhere in 512 GiB: two more scalar instructions): the base of
-// a step is s[20:21] = {base low, base high + the chunk's high offset half} (named registers: an asm operand cannot be
-// addressed by halves; both are on the clobber list).
+// NARROW step (all chunks of the tile within 4 GiB of its lowest source: every chromosome-sorted index); WIDE step
+// (pieces of one tile anywhere in 512 GiB): the high offset half joins the carry.  The base of a step is s[20:21]
+// (named registers: an asm operand cannot be addressed by halves; both are on the clobber list).
 #define RP_DMA_STEP_NARROW(I)                                   \
     "v_readlane_b32 %[so], %[w0], " #I "\n\t"                   \
     "v_readlane_b32 %[s1], %[w1], " #I "\n\t"                   \
-    "s_and_b32 m0, %[s1], 0xffff\n\t"                           \
-    "s_lshr_b32 %[st], %[s1], 16\n\t"                           \
-    "s_lshr_b64 exec, -1, %[st]\n\t"                            \
-    "s_lshr_b32 %[sd], %[st], 8\n\t"                            \
-    "v_mad_i32_i24 %[vt], %[sd], %[vdelta], %[vup]\n\t"         \
-    "v_add_u32 %[vt], %[so], %[vt]\n\t"                         \
-    "global_load_lds_dword %[vt], s[20:21]" RP_CHUNK_POLICY "\n\t"
+    "s_lshr_b64 exec, -1, %[s1]\n\t"                            \
+    "s_lshr_b32 m0, %[s1], 16\n\t"                              \
+    "s_add_u32 s20, %[blo], %[so]\n\t"                          \
+    "s_addc_u32 s21, %[bhi], 0\n\t"                             \
+    "global_load_lds_dword %[voff], s[20:21]" RP_CHUNK_POLICY "\n\t"
 #define RP_DMA_STEP_WIDE(I)                                     \
     "v_readlane_b32 %[so], %[w0], " #I "\n\t"                   \
     "v_readlane_b32 %[s1], %[w1], " #I "\n\t"                   \
-    "s_and_b32 m0, %[s1], 0xffff\n\t"                           \
-    "s_lshr_b32 %[st], %[s1], 16\n\t"                           \
-    "s_lshr_b64 exec, -1, %[st]\n\t"                            \
-    "s_bfe_u32 %[sd], %[s1], 0x10018\n\t"                       \
-    "s_lshr_b32 %[st], %[s1], 25\n\t"                           \
-    "s_add_u32 s21, %[bhi], %[st]\n\t"                          \
-    "v_mad_i32_i24 %[vt], %[sd], %[vdelta], %[vup]\n\t"         \
-    "v_add_u32 %[vt], %[so], %[vt]\n\t"                         \
-    "global_load_lds_dword %[vt], s[20:21]" RP_CHUNK_POLICY "\n\t"
-#define RP_DMA_STEP8(S, A, B, C, D, E, F, G, H, LIM)            \
-    S(A) S(B) S(C) S(D) S(E) S(F) S(G) S(H)                     \
+    "s_lshr_b64 exec, -1, %[s1]\n\t"                            \
+    "s_lshr_b32 m0, %[s1], 16\n\t"                              \
+    "s_bfe_u32 %[st], %[s1], 0x70007\n\t"                       \
+    "s_add_u32 s20, %[blo], %[so]\n\t"                          \
+    "s_addc_u32 s21, %[bhi], %[st]\n\t"                         \
+    "global_load_lds_dword %[voff], s[20:21]" RP_CHUNK_POLICY "\n\t"
+#define RP_DMA_STEP4(S, A, B, C, D, LIM)                        \
+    S(A) S(B) S(C) S(D)                                         \
     "s_cmp_le_u32 %[steps], " #LIM "\n\t"                       \
     "s_cbranch_scc1 1f\n\t"
-#define RP_DMA_STEPS64(S)                                       \
-    RP_DMA_STEP8(S, 0, 1, 2, 3, 4, 5, 6, 7, 8)                  \
-    RP_DMA_STEP8(S, 8, 9, 10, 11, 12, 13, 14, 15, 16)           \
-    RP_DMA_STEP8(S, 16, 17, 18, 19, 20, 21, 22, 23, 24)         \
-    RP_DMA_STEP8(S, 24, 25, 26, 27, 28, 29, 30, 31, 32)         \
-    RP_DMA_STEP8(S, 32, 33, 34, 35, 36, 37, 38, 39, 40)         \
-    RP_DMA_STEP8(S, 40, 41, 42, 43, 44, 45, 46, 47, 48)         \
-    RP_DMA_STEP8(S, 48, 49, 50, 51, 52, 53, 54, 55, 56)         \
-    RP_DMA_STEP8(S, 56, 57, 58, 59, 60, 61, 62, 63, 64)
+#define RP_DMA_STEPS_UP(S)                                                                                      \
+    RP_DMA_STEP4(S, 0, 1, 2, 3, 4) RP_DMA_STEP4(S, 4, 5, 6, 7, 8) RP_DMA_STEP4(S, 8, 9, 10, 11, 12)             \
+    RP_DMA_STEP4(S, 12, 13, 14, 15, 16) RP_DMA_STEP4(S, 16, 17, 18, 19, 20) RP_DMA_STEP4(S, 20, 21, 22, 23, 24) \
+    RP_DMA_STEP4(S, 24, 25, 26, 27, 28) RP_DMA_STEP4(S, 28, 29, 30, 31, 32) RP_DMA_STEP4(S, 32, 33, 34, 35, 36) \
+    RP_DMA_STEP4(S, 36, 37, 38, 39, 40) RP_DMA_STEP4(S, 40, 41, 42, 43, 44) RP_DMA_STEP4(S, 44, 45, 46, 47, 48) \
+    RP_DMA_STEP4(S, 48, 49, 50, 51, 52) RP_DMA_STEP4(S, 52, 53, 54, 55, 56) RP_DMA_STEP4(S, 56, 57, 58, 59, 60) \
+    RP_DMA_STEP4(S, 60, 61, 62, 63, 64)
+#define RP_DMA_STEPS_DOWN(S)                                                                                    \
+    RP_DMA_STEP4(S, 63, 62, 61, 60, 4) RP_DMA_STEP4(S, 59, 58, 57, 56, 8) RP_DMA_STEP4(S, 55, 54, 53, 52, 12)   \
+    RP_DMA_STEP4(S, 51, 50, 49, 48, 16) RP_DMA_STEP4(S, 47, 46, 45, 44, 20) RP_DMA_STEP4(S, 43, 42, 41, 40, 24) \
+    RP_DMA_STEP4(S, 39, 38, 37, 36, 28) RP_DMA_STEP4(S, 35, 34, 33, 32, 32) RP_DMA_STEP4(S, 31, 30, 29, 28, 36) \
+    RP_DMA_STEP4(S, 27, 26, 25, 24, 40) RP_DMA_STEP4(S, 23, 22, 21, 20, 44) RP_DMA_STEP4(S, 19, 18, 17, 16, 48) \
+    RP_DMA_STEP4(S, 15, 14, 13, 12, 52) RP_DMA_STEP4(S, 11, 10, 9, 8, 56) RP_DMA_STEP4(S, 7, 6, 5, 4, 60)       \
+    RP_DMA_STEP4(S, 3, 2, 1, 0, 64)
 
 // Call sites must be wave-uniform with all 64 lanes active: the block overwrites EXEC and leaves
 // it all-ones (stage_tile_chunks is reached through workgroup-uniform branches only).  M0 and EXEC
@@ -412,39 +415,30 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
 // are reserved registers, which is the point.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-template <bool WIDE>
-__device__ __forceinline__ void issue_chunks(const int32_t *base, unsigned w0, unsigned w1, int steps, int lane)
+// UP: the wave's first `steps` lanes, with lane offsets voff = lane * 4; !UP: its last `steps` lanes, voff = (63 - lane) * 4
+template <bool WIDE, bool UP>
+__device__ __forceinline__ void issue_chunks(unsigned blo, unsigned bhi, unsigned w0, unsigned w1, int steps, int voff)
 {
-    const int vup = lane * 4, vdelta = (63 - 2 * lane) * 4;  // vup + vdelta = (63 - lane) * 4
-    unsigned so, s1, st, sd;
-    int vt;
-    const unsigned long long u = (unsigned long long)base;
-    const unsigned blo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
-    const unsigned bhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
-    if constexpr (WIDE) {
-        asm volatile(
-            "s_mov_b32 s20, %[blo]\n\t"
-            RP_DMA_STEPS64(RP_DMA_STEP_WIDE)
-            "1:\n\t"
-            "s_mov_b64 exec, -1"
-            : [so] "=&s"(so), [s1] "=&s"(s1), [st] "=&s"(st), [sd] "=&s"(sd), [vt] "=&v"(vt)
-            : [w0] "v"(w0), [w1] "v"(w1), [vdelta] "v"(vdelta), [vup] "v"(vup), [blo] "s"(blo), [bhi] "s"(bhi), [steps] "s"(steps)
-            : "memory", "scc", "m0", "exec", "s20", "s21");  // every step rewrites M0 and EXEC (EXEC is left all-ones, as it came in)
-    } else {
-        asm volatile(
-            "s_mov_b32 s20, %[blo]\n\t"
-            "s_mov_b32 s21, %[bhi]\n\t"
-            RP_DMA_STEPS64(RP_DMA_STEP_NARROW)
-            "1:\n\t"
-            "s_mov_b64 exec, -1"
-            : [so] "=&s"(so), [s1] "=&s"(s1), [st] "=&s"(st), [sd] "=&s"(sd), [vt] "=&v"(vt)
-            : [w0] "v"(w0), [w1] "v"(w1), [vdelta] "v"(vdelta), [vup] "v"(vup), [blo] "s"(blo), [bhi] "s"(bhi), [steps] "s"(steps)
-            : "memory", "scc", "m0", "exec", "s20", "s21");
-    }
+    unsigned so, s1, st;
+#define RP_ISSUE(STEPS, STEP)                                                                                                  \
+    asm volatile(STEPS(STEP) "1:\n\ts_mov_b64 exec, -1"                                                                       \
+                 : [so] "=&s"(so), [s1] "=&s"(s1), [st] "=&s"(st)                                                              \
+                 : [w0] "v"(w0), [w1] "v"(w1), [voff] "v"(voff), [blo] "s"(blo), [bhi] "s"(bhi), [steps] "s"(steps)            \
+                 : "memory", "scc", "m0", "exec", "s20", "s21")  // every step rewrites M0 and EXEC (EXEC is left all-ones, as it came in)
+    if constexpr (WIDE && UP)
+        RP_ISSUE(RP_DMA_STEPS_UP, RP_DMA_STEP_WIDE);
+    else if constexpr (WIDE)
+        RP_ISSUE(RP_DMA_STEPS_DOWN, RP_DMA_STEP_WIDE);
+    else if constexpr (UP)
+        RP_ISSUE(RP_DMA_STEPS_UP, RP_DMA_STEP_NARROW);
+    else
+        RP_ISSUE(RP_DMA_STEPS_DOWN, RP_DMA_STEP_NARROW);
+#undef RP_ISSUE
 }
 #pragma clang diagnostic pop
-#undef RP_DMA_STEPS64
-#undef RP_DMA_STEP8
+#undef RP_DMA_STEPS_DOWN
+#undef RP_DMA_STEPS_UP
+#undef RP_DMA_STEP4
 #undef RP_DMA_STEP_NARROW
 #undef RP_DMA_STEP_WIDE
 
@@ -462,40 +456,39 @@ __device__ __forceinline__ unsigned lds_address(const int *p)
     return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const int *)p;
 }
 
-// the row slot of round 0 that this thread keeps: chunk 4 * lane + wave
+// the row slot that this thread keeps: chunk 4 * lane + wave
 __device__ __forceinline__ const chunk_desc_t *chunk_slot(const PiecePlan &pp, long long b, int lane, int wave)
 {
     return pp.rows + b * kMaxChunks + 4 * lane + wave;
 }
 
-// `e`: the thread's round-0 chunk (already loaded); total: the tile's chunk count
-// `total`: the tile's chunk count, with kTileWide set when a chunk's offset does not fit 32 bits
+// `e`: the thread's slot (already loaded); total_word = tile_lo[2 b + 1]: forward chunks | '-' strand chunks << 16,
+// with kTileWide set when a chunk's offset does not fit 32 bits
 constexpr long long kTileWide = 1ll << 32;
 
 __device__ __forceinline__ void stage_tile_chunks(const int32_t *__restrict__ cov, const PiecePlan &pp, long long b,
                                                   long long tile_lo, long long total_word, chunk_desc_t e, int *s_counts, int lane, int wave)
 {
-    const int total = (int)(unsigned)total_word;
+    const int n_fwd = (int)(total_word & 0xffff), n_rev = (int)((total_word >> 16) & 0xffff);
     const bool wide = (total_word & kTileWide) != 0;  // workgroup-uniform
-    const unsigned lds0 = lds_address(s_counts);
-    const int32_t *base = scalar_ptr(cov + tile_lo);
-    for (int r0 = 0;; r0 += 256) {  // workgroup-uniform; one round unless the tile has > 256 chunks
-        const unsigned hi = (unsigned)(e >> 32);
-        const unsigned w1 = (lds0 + (hi & 0x1fffu) * 4u) | (((hi >> 13) & 0x3fu) << 16) | (((hi >> 19) & 1u) << 24) | (((hi >> 20) & 0x7fu) << 25);
-        int steps = (total - r0 - wave + 3) >> 2;  // chunks r0 + wave, r0 + wave + 4, ... < total
-        steps = __builtin_amdgcn_readfirstlane(steps > 64 ? 64 : steps);
-#ifdef RP_EXPERIMENT_CHUNK_DIV  // timing experiment only (results wrong): issue 1 / RP_EXPERIMENT_CHUNK_DIV of the chunks
-        steps = (steps + RP_EXPERIMENT_CHUNK_DIV - 1) / RP_EXPERIMENT_CHUNK_DIV;
-#endif
-        if (steps > 0) {
-            if (wide)
-                issue_chunks<true>(base, (unsigned)e, w1, steps, lane);
-            else
-                issue_chunks<false>(base, (unsigned)e, w1, steps, lane);
-        }
-        if (r0 + 256 >= total) break;
-        const int c = r0 + 256 + 4 * lane + wave;
-        e = pp.rows[b * kMaxChunks + (c < kMaxChunks ? c : 0)];
+    const unsigned long long base0 = (unsigned long long)scalar_ptr(cov + tile_lo);
+    const unsigned blo = (unsigned)base0, bhi = (unsigned)(base0 >> 32);
+    const unsigned w0 = (unsigned)e;
+    const unsigned w1 = (unsigned)(e >> 32) + (lds_address(s_counts) << 16);  // (the LDS byte offset becomes the LDS address)
+    // forward chunks wave, wave + 4, ... < n_fwd in lanes 0 ...; reverse chunk j in slot 255 - j: wave 3 - j % 4, lane 63 - j / 4
+    const int fsteps = __builtin_amdgcn_readfirstlane((n_fwd - wave + 3) >> 2);
+    const int rsteps = __builtin_amdgcn_readfirstlane((n_rev + wave) >> 2);
+    if (fsteps > 0) {
+        if (wide)
+            issue_chunks<true, true>(blo, bhi, w0, w1, fsteps, lane * 4);
+        else
+            issue_chunks<false, true>(blo, bhi, w0, w1, fsteps, lane * 4);
+    }
+    if (rsteps > 0) {
+        if (wide)
+            issue_chunks<true, false>(blo, bhi, w0, w1, rsteps, (63 - lane) * 4);
+        else
+            issue_chunks<false, false>(blo, bhi, w0, w1, rsteps, (63 - lane) * 4);
     }
 }
 

@@ -306,7 +306,8 @@ class GatherPlan:
 
     def stats(self) -> dict:
         """Diagnostics (scripts): how the tiles of this plan are staged -- chunk rows per tile (<= 64
-        positions of one run each; 352 fit a row, more take the scalar slow path), read back from the plan memory
+        positions of one run each; 256 fit a row -- less the padding of the two directions' regions to blocks of 16 --,
+        more take the scalar slow path), read back from the plan memory
         (layout: csrc/rp_pieces.hpp ``carve_piece_plan`` behind the 128-byte header)."""
         tile = _lib.tile_positions(self.n_orfs, self.total_nt)
         n_tiles = max(1, -(-self.total_nt // tile))
@@ -314,8 +315,8 @@ class GatherPlan:
         at = 128 + 2 * up((self.n_intervals + 1) * 8) + up((self.n_orfs + 1) * 8) + up(n_tiles * 8)
         torch.cuda.synchronize(self.device)
         words = self._mem[at : at + 16 * n_tiles].cpu().numpy().view(np.int64).reshape(n_tiles, 2)
-        lo, chunks = words[:, 0], words[:, 1] & 0xFFFFFFFF
-        wide = (words[:, 1] >> 32) != 0  # a chunk of the tile lies > 4 GiB from the tile's lowest source: the two-instructions-longer issue loop
+        lo, chunks = words[:, 0], (words[:, 1] & 0xFFFF) + ((words[:, 1] >> 16) & 0xFFFF)  # forward + '-' strand chunks
+        wide = ((words[:, 1] >> 32) & 1) != 0  # a chunk of the tile lies > 4 GiB from the tile's lowest source: one more instruction per chunk
         slow = lo == np.iinfo(np.int64).min
         q = np.percentile(chunks, [50, 90, 99]) if n_tiles else [0, 0, 0]
         return {"tile_positions": tile, "tiles": int(n_tiles), "slow_tiles": int(slow.sum()), "chunks_per_tile_mean": float(chunks.mean()),
