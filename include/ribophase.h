@@ -504,6 +504,20 @@ int rp_interval_table_host(const int64_t *iv_start, const int64_t *iv_end, const
                            int64_t *out_offsets);
 
 /*
+ * The part of a coverage array that a set of intervals touches, as a few WINDOWS (what a GPU that scores one slice of
+ * the index needs of the whole coverage: engine.CoverageShards; replaces nothing in the reference -- its loop runs on
+ * one process).  Intervals that lie closer than 2^gap_shift positions share a window; windows ascend, start and length
+ * rounded to 16 positions; win_base[k] = where window k sits in the compacted array of *total positions.  With
+ * out_iv_start non-NULL the interval starts are also re-based onto the compacted array (start - win_start[k] +
+ * win_base[k]).  One pass over the intervals, no sort (a block of 2^gap_shift positions can only hold one window).
+ * RP_ERR_SIZE when more than `capacity` windows exist (*n_windows says how many), RP_ERR_INTERVALS for an empty or
+ * negative interval.
+ */
+int rp_coverage_windows_host(const int64_t *iv_start, const int32_t *iv_len, int64_t n_intervals, int32_t gap_shift,
+                             int64_t *win_start, int64_t *win_len, int64_t *win_base, int64_t capacity, int64_t *n_windows,
+                             int64_t *total, int64_t *out_iv_start);
+
+/*
  * ---- host side: BAM front end ----------------------------------
  *
  * rp_bam_split_host replaces split_bam (bam.py:33-153) without pysam: the BGZF file is read

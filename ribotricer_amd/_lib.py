@@ -28,6 +28,7 @@ FLAG_BIGCOUNT = 0x20
 MIN_CODON_COV_EMPTY = 2147483647
 MAX_COUNT = 16777215
 ERR_INTERVALS = -12
+ERR_SIZE = -2
 
 
 class RibophaseError(RuntimeError):
@@ -99,6 +100,7 @@ SYMBOLS = {
     "rp_index_view_host": (_int, [_vp, _vp]),
     "rp_index_free": (None, [_vp]),
     "rp_interval_table_host": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "rp_coverage_windows_host": (_int, [_vp, _vp, _i64, ctypes.c_int32, _vp, _vp, _vp, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64), _vp]),
     "rp_bam_split_host": (_int, [ctypes.c_char_p, _int, _vp, ctypes.c_int32, ctypes.POINTER(_vp)]),
     "rp_bam_view_host": (_int, [_vp, _vp]),
     "rp_bam_free": (None, [_vp]),

@@ -1233,6 +1233,75 @@ int rp_interval_table_host(const int64_t *iv_start, const int64_t *iv_end, const
     return RP_OK;
 }
 
+int rp_coverage_windows_host(const int64_t *iv_start, const int32_t *iv_len, int64_t n_intervals, int32_t gap_shift,
+                             int64_t *win_start, int64_t *win_len, int64_t *win_base, int64_t capacity, int64_t *n_windows,
+                             int64_t *total, int64_t *out_iv_start)
+{
+    if (!n_windows || !total) return fail(RP_ERR_NULL, "n_windows and total must be non-null");
+    *n_windows = 0;
+    *total = 0;
+    if (n_intervals < 0 || capacity < 0) return fail(RP_ERR_SIZE, "negative size");
+    if (gap_shift < 4 || gap_shift > 40) return fail(RP_ERR_ARG, "gap_shift must lie in [4, 40], got %d", (int)gap_shift);
+    if (n_intervals == 0) return RP_OK;
+    if (!iv_start || !iv_len || (capacity > 0 && (!win_start || !win_len || !win_base))) return fail(RP_ERR_NULL, "intervals and window arrays must be non-null");
+    // pass 1: the extent (and the sanity of every interval)
+    int64_t lo = INT64_MAX, hi = INT64_MIN;
+    for (int64_t k = 0; k < n_intervals; ++k) {
+        const int64_t s = iv_start[k], n = iv_len[k];
+        if (n <= 0 || s < 0) return fail(RP_ERR_INTERVALS, "interval %lld is empty or starts below 0", (long long)k);
+        if (s < lo) lo = s;
+        if (s + n > hi) hi = s + n;
+    }
+    // pass 2: per block of 2^gap_shift positions, the lowest start and the highest end of the intervals that START in it.
+    // Two intervals of one block start less than the gap apart: one window.  Blocks are then walked in order.
+    const int64_t b0 = lo >> gap_shift;
+    const int64_t n_blocks = ((hi - 1) >> gap_shift) - b0 + 1;
+    std::vector<int64_t> first((size_t)n_blocks, INT64_MAX), last((size_t)n_blocks, INT64_MIN);
+    for (int64_t k = 0; k < n_intervals; ++k) {
+        const int64_t s = iv_start[k], e = s + iv_len[k];
+        const size_t b = (size_t)((s >> gap_shift) - b0);
+        if (s < first[b]) first[b] = s;
+        if (e > last[b]) last[b] = e;
+    }
+    const int64_t gap = (int64_t)1 << gap_shift;
+    std::vector<int64_t> block_window((size_t)n_blocks, -1);
+    int64_t w = -1, reach = INT64_MIN, base = 0;
+    auto close = [&]() {  // window w ends at `reach`
+        if (w < 0) return;
+        if (w < capacity) {
+            win_len[w] = (reach - win_start[w] + 15) / 16 * 16;
+            win_base[w] = base;
+            base += win_len[w];
+        }
+    };
+    int64_t start_w = 0;
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        if (first[(size_t)b] == INT64_MAX) continue;
+        if (w < 0 || first[(size_t)b] > reach + gap) {  // (sharding.coverage_windows: s > reach + gap opens a window)
+            close();
+            ++w;
+            start_w = first[(size_t)b] / 16 * 16;
+            if (w < capacity) win_start[w] = start_w;
+            reach = last[(size_t)b];
+        } else if (last[(size_t)b] > reach) {
+            reach = last[(size_t)b];
+        }
+        block_window[(size_t)b] = w;
+    }
+    close();
+    *n_windows = w + 1;
+    if (w + 1 > capacity) return fail(RP_ERR_SIZE, "%lld windows, room for %lld", (long long)(w + 1), (long long)capacity);
+    *total = base;
+    if (out_iv_start) {
+        for (int64_t k = 0; k < n_intervals; ++k) {
+            const int64_t s = iv_start[k];
+            const int64_t win = block_window[(size_t)((s >> gap_shift) - b0)];
+            out_iv_start[k] = s - win_start[win] + win_base[win];
+        }
+    }
+    return RP_OK;
+}
+
 int rp_format_double_repr(double value, char *buf) { return buf ? rpfmt::double_repr(value, buf) : 0; }
 
 size_t rp_format_int_list(const int32_t *values, int64_t n, char *out)

@@ -764,8 +764,8 @@ class CoverageShards:
     uploads its windows and launches; nothing is planned again (the one-GPU path: detect_orfs._table_and_plan)."""
 
     def __init__(self, table, devices: Sequence, coverage_len: int):
-        from .gather import IntervalTable, select_orfs
-        from .sharding import coverage_windows, remap_to_windows, slice_bounds
+        from .gather import IntervalTable, slice_orfs
+        from .sharding import coverage_windows_native, slice_bounds
 
         self.devices = _devices(devices)
         self.coverage_len = int(coverage_len)
@@ -774,12 +774,12 @@ class CoverageShards:
         self.parts: list = []
         for k in range(len(self.devices)):
             lo, hi = int(self.bounds[k]), int(self.bounds[k + 1])
-            sub = select_orfs(table, np.arange(lo, hi, dtype=np.int64))
+            sub = slice_orfs(table, lo, hi)  # (views: the slices of an 11 M-ORF index are not copied)
             windows = None
             if len(self.devices) > 1:  # only what this slice reads crosses to the device
-                w_start, w_len, w_base, w_total = coverage_windows(sub.iv_start, sub.iv_len)
+                w_start, w_len, w_base, w_total, rebased = coverage_windows_native(sub.iv_start, sub.iv_len)
                 windows = (w_start, w_len, w_base, max(w_total, 16))
-                sub = IntervalTable(remap_to_windows(sub.iv_start, w_start, w_base), sub.iv_len, sub.orf_iv, sub.reverse, sub.offsets)
+                sub = IntervalTable(rebased, sub.iv_len, sub.orf_iv, sub.reverse, sub.offsets)
             self.parts.append({"table": sub, "windows": windows, "plan": None, "tile_plan": None, "stream": None})
         self.plans_built = 0
 

@@ -358,6 +358,15 @@ def select_orfs(table: IntervalTable, orf_ids: np.ndarray) -> IntervalTable:
     return IntervalTable(table.iv_start[pick], table.iv_len[pick], orf_iv, table.reverse[orf_ids], offsets)
 
 
+def slice_orfs(table, lo: int, hi: int) -> IntervalTable:
+    """The interval table of ORFs [lo, hi): views of the table's arrays (no copy of the intervals), offsets and interval
+    ranges re-based -- what :func:`select_orfs` returns for ``np.arange(lo, hi)`` without its fancy indexing."""
+    orf_iv = np.asarray(table.orf_iv, np.int64)
+    offsets = np.asarray(table.offsets, np.int64)
+    k0, k1 = int(orf_iv[lo]), int(orf_iv[hi])
+    return IntervalTable(table.iv_start[k0:k1], table.iv_len[k0:k1], orf_iv[lo : hi + 1] - k0, table.reverse[lo:hi], offsets[lo : hi + 1] - offsets[lo])
+
+
 def orfs_touching(table: IntervalTable, positions: np.ndarray) -> np.ndarray:
     """Sorted ids of the ORFs with an exon interval that contains one of ``positions`` (coverage indices):
     who holds the saturated positions ``alignments.build_coverage_device`` reported.  Two binary searches per

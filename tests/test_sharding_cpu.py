@@ -5,6 +5,7 @@ there is no GPU -- the GPU twin of this test is test_gpu_parity.test_full_size_p
 import os
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -74,6 +75,43 @@ def test_two_rank_gloo_gather():
     ok = mp.get_context("spawn").Value("i", 0)
     mp.spawn(_worker, args=(world, 29531 + os.getpid() % 200, ok), nprocs=world, join=True)
     assert ok.value == 1
+
+
+def test_native_coverage_windows_equal_the_numpy_ones():
+    """rp_coverage_windows_host (one pass, no sort) against sharding.coverage_windows + remap_to_windows (argsort +
+    searchsorted): the same windows and the same re-based starts -- islands megabases apart, intervals that straddle
+    block boundaries, nested and abutting intervals, one interval, none; and gather.slice_orfs == select_orfs(arange)."""
+    from ribotricer_amd import _lib
+    from ribotricer_amd.gather import IntervalTable, select_orfs, slice_orfs
+    from ribotricer_amd.sharding import coverage_windows, coverage_windows_native, remap_to_windows
+
+    rng = np.random.default_rng(77)
+    for trial in range(30):
+        n = int(rng.integers(1, 4000))
+        islands = np.sort(rng.integers(0, 1 << 34, size=int(rng.integers(1, 12))))
+        s = (islands[rng.integers(0, islands.size, n)] + rng.integers(0, 1 << int(rng.integers(4, 23)), n)).astype(np.int64)
+        ln = rng.integers(1, 100_000 if trial % 3 else 40, n).astype(np.int32)
+        for shift in (20, 12):
+            a = coverage_windows(s, ln, gap=1 << shift)
+            b = coverage_windows_native(s, ln, gap_shift=shift)
+            for x, y in zip(a[:3], b[:3]):
+                assert np.array_equal(x, y), (trial, shift)
+            assert a[3] == b[3]
+            assert np.array_equal(remap_to_windows(s, a[0], a[2]), b[4])
+    z = coverage_windows_native(np.zeros(0, np.int64), np.zeros(0, np.int32))
+    assert z[3] == 0 and z[0].size == 0 and z[4].size == 0
+    with pytest.raises(_lib.RibophaseError):
+        coverage_windows_native(np.array([5], np.int64), np.array([0], np.int32))
+    # slices as views
+    n_iv = rng.integers(1, 5, 300)
+    orf_iv = np.concatenate([[0], np.cumsum(n_iv)]).astype(np.int64)
+    m = int(orf_iv[-1])
+    t = IntervalTable(rng.integers(0, 10**6, m).astype(np.int64), rng.integers(1, 90, m).astype(np.int32), orf_iv,
+                      rng.integers(0, 2, 300).astype(np.uint8), np.concatenate([[0], np.cumsum(rng.integers(1, 400, 300))]).astype(np.int64))
+    for lo, hi in ((0, 300), (0, 1), (17, 123), (299, 300), (40, 40)):
+        x, y = slice_orfs(t, lo, hi), select_orfs(t, np.arange(lo, hi, dtype=np.int64))
+        for u, v in zip(x, y):
+            assert np.array_equal(u, v), (lo, hi)
 
 
 def test_coverage_windows_carry_exactly_what_a_slice_reads():
