@@ -574,6 +574,26 @@ size_t rp_format_int_list(const int32_t *values, int64_t n, char *out);
 size_t rp_format_wig_rows_host(const int64_t *pos, const int64_t *count, int64_t n, char *out);
 
 /*
+ * export_wig's ordering work (detect_orfs.py:327-345: the reference sorts the Counter's (chrom, pos) keys in Python)
+ * for the rows of ONE strand of the merged P-site columns, in two native passes around a plain value sort:
+ *   rp_wig_pack_host    (rank of the row's chromosome name, position, count) of every row with strand == strand_code
+ *                       into one 64-bit word each (10 + 32 + 22 bits: the sort order of the words is the file's order);
+ *                       in threads.  RP_ERR_ARG when a row does not fit (position outside [0, 2^32), count outside
+ *                       [0, 2^22), >= 1024 chromosomes, a chromosome code outside the table): the caller sorts by columns.
+ *   rp_wig_render_host  words [lo, hi) of the SORTED array (lo and hi on position boundaries) to text: the rows of one
+ *                       position are added up (several read lengths can land on one P-site), "{pos}\t{count}\n" per
+ *                       position, and "variableStep chrom={name}\n" (detect_orfs.py:343-351) in front of the first position
+ *                       of every chromosome that STARTS in the range (names: the chromosome names in rank order,
+ *                       concatenated; name_off[r] .. name_off[r + 1] is rank r's).  out must hold 42 * (hi - lo) bytes +
+ *                       24 + the name's length for every rank; returns the bytes written.  Ranges are independent: the
+ *                       caller renders them in threads and writes them in order.
+ */
+int rp_wig_pack_host(const uint8_t *strand, const int32_t *chrom, const int64_t *pos, const int64_t *count, int64_t n_rows,
+                     int32_t strand_code, const int32_t *rank_of_chrom, int32_t n_chroms, uint64_t *packed, int64_t *n_packed);
+size_t rp_wig_render_host(const uint64_t *sorted_words, int64_t lo, int64_t hi, const char *names, const int64_t *name_off,
+                          char *out);
+
+/*
  * Same as rp_phase_score_csr_dev (plan == NULL) or rp_phase_score_csr_plan_dev (plan given)
  * but brackets each internal launch with HIP events on `hip_stream`, synchronises, and
  * reports milliseconds: ms[0] tile-index pass (0 with a plan), ms[1] main scoring kernel,

@@ -107,6 +107,8 @@ SYMBOLS = {
     "rp_format_double_repr": (_int, [ctypes.c_double, _vp]),
     "rp_format_int_list": (ctypes.c_size_t, [_vp, _i64, _vp]),
     "rp_format_wig_rows_host": (ctypes.c_size_t, [_vp, _vp, _i64, _vp]),
+    "rp_wig_pack_host": (_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_int32, _vp, ctypes.c_int32, _vp, ctypes.POINTER(_i64)]),
+    "rp_wig_render_host": (ctypes.c_size_t, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "rp_measurement_tag": (ctypes.c_int, [ctypes.c_int]),
 }
 

@@ -1309,6 +1309,87 @@ size_t rp_format_int_list(const int32_t *values, int64_t n, char *out)
     return (out && (values || n <= 0)) ? rpfmt::int_list_str(values, n, out) : 0;
 }
 
+int rp_wig_pack_host(const uint8_t *strand, const int32_t *chrom, const int64_t *pos, const int64_t *count, int64_t n_rows,
+                     int32_t strand_code, const int32_t *rank_of_chrom, int32_t n_chroms, uint64_t *packed, int64_t *n_packed)
+{
+    if (!n_packed) return fail(RP_ERR_NULL, "n_packed is null");
+    *n_packed = 0;
+    if (n_rows < 0 || n_chroms < 0) return fail(RP_ERR_SIZE, "negative size");
+    if (n_rows > 0 && (!strand || !chrom || !pos || !count || !rank_of_chrom || !packed)) return fail(RP_ERR_NULL, "columns, ranks and output must be non-null");
+    if (n_chroms >= 1024) return fail(RP_ERR_ARG, "%d chromosome names do not fit the 10 rank bits of a packed WIG key", (int)n_chroms);
+    int threads = rphost::usable_threads();
+    if (threads > 32) threads = 32;
+    if (n_rows < 1000000) threads = 1;
+    std::vector<int64_t> kept((size_t)threads + 1, 0);
+    std::vector<int> bad((size_t)threads, 0);
+    auto range = [&](int t) { return std::pair<int64_t, int64_t>{n_rows * t / threads, n_rows * (t + 1) / threads}; };
+    auto run = [&](auto &&fn) {
+        if (threads == 1) {
+            fn(0);
+            return;
+        }
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t) pool.emplace_back(fn, t);
+        for (auto &th : pool) th.join();
+    };
+    run([&](int t) {  // how many rows of its range every thread keeps
+        const auto [a, b] = range(t);
+        int64_t k = 0;
+        for (int64_t i = a; i < b; ++i) k += strand[i] == strand_code;
+        kept[(size_t)t + 1] = k;
+    });
+    for (int t = 0; t < threads; ++t) kept[(size_t)t + 1] += kept[(size_t)t];
+    run([&](int t) {
+        const auto [a, b] = range(t);
+        uint64_t *out = packed + kept[(size_t)t];
+        for (int64_t i = a; i < b; ++i) {
+            if (strand[i] != strand_code) continue;
+            const int32_t c = chrom[i];
+            const int64_t p = pos[i], v = count[i];
+            if (c < 0 || c >= n_chroms || p < 0 || p >= (1ll << 32) || v < 0 || v >= (1ll << 22)) {
+                bad[(size_t)t] = 1;
+                return;
+            }
+            *out++ = ((uint64_t)(uint32_t)rank_of_chrom[c] << 54) | ((uint64_t)p << 22) | (uint64_t)v;
+        }
+    });
+    for (int t = 0; t < threads; ++t)
+        if (bad[(size_t)t]) return fail(RP_ERR_ARG, "a row does not fit a packed WIG key (position outside [0, 2^32), count outside [0, 2^22) or an unknown chromosome code)");
+    *n_packed = kept[(size_t)threads];
+    return RP_OK;
+}
+
+size_t rp_wig_render_host(const uint64_t *sorted_words, int64_t lo, int64_t hi, const char *names, const int64_t *name_off, char *out)
+{
+    if (!sorted_words || !names || !name_off || !out || lo < 0 || hi <= lo) return 0;
+    char *o = out;
+    // a chromosome's header goes in front of its first position: the range's first word opens one only at the very
+    // start of the array or when the word before it belongs to another chromosome
+    long long prev_rank = lo > 0 ? (long long)(sorted_words[lo - 1] >> 54) : -1;
+    int64_t i = lo;
+    while (i < hi) {
+        const uint64_t key = sorted_words[i] >> 22;
+        int64_t total = 0;
+        for (; i < hi && (sorted_words[i] >> 22) == key; ++i) total += (int64_t)(sorted_words[i] & 0x3fffffull);
+        const long long rank = (long long)(key >> 32);
+        if (rank != prev_rank) {
+            static const char head[] = "variableStep chrom=";
+            std::memcpy(o, head, sizeof(head) - 1);
+            o += sizeof(head) - 1;
+            const int64_t a = name_off[rank], b = name_off[rank + 1];
+            std::memcpy(o, names + a, (size_t)(b - a));
+            o += b - a;
+            *o++ = '\n';
+            prev_rank = rank;
+        }
+        o += rpfmt::int_str((int64_t)(key & 0xffffffffull), o);
+        *o++ = '\t';
+        o += rpfmt::int_str(total, o);
+        *o++ = '\n';
+    }
+    return (size_t)(o - out);
+}
+
 int rp_measurement_tag(int on)
 {
     return g_measurement_tag.exchange(on ? 1 : 0, std::memory_order_relaxed);
