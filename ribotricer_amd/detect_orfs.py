@@ -582,7 +582,6 @@ def export_wig(merged_alignments, prefix: str) -> None:
     from .alignments import STRANDS, MergedColumns
 
     import ctypes
-    import threading
 
     from . import _lib
 
@@ -626,16 +625,13 @@ def export_wig(merged_alignments, prefix: str) -> None:
             np.cumsum([len(x) for x in by_rank], out=name_off[1:])
             name_buf = ctypes.create_string_buffer(b"".join(by_rank) + b"\0")
             room = 42 * (step + 64) + sum(24 + len(x) for x in by_rank)
-            local = threading.local()
 
             def render(k: int):
                 lo, hi = cuts[k], cuts[k + 1]
                 need = room if hi - lo <= step + 64 else 42 * (hi - lo) + room
-                buf = getattr(local, "buf", None)  # (one buffer per thread: its first touch is the costly part)
-                if buf is None or len(buf) < need:
-                    buf = local.buf = ctypes.create_string_buffer(need)
-                n = lib.rp_wig_render_host(ptr(packed), lo, hi, name_buf, ptr(name_off), buf)
-                return ctypes.string_at(buf, n)
+                buf = np.empty(need, np.uint8)  # (filled by the C call, written as it is: no copy under the GIL)
+                n = lib.rp_wig_render_host(ptr(packed), lo, hi, name_buf, ptr(name_off), ptr(buf))
+                return memoryview(buf)[:n]
 
             from concurrent.futures import ThreadPoolExecutor
 
