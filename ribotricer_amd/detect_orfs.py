@@ -318,7 +318,7 @@ def export_orf_coverages(
             if mapped:
                 at += tsv.write_rows_native(output.fileno(), at, *args)
             else:  # render threads hand their chunks, in order, to this one writer
-                for chunk in tsv.format_rows_native(*args):
+                for chunk in tsv.format_rows_native(*args, recycle=True):  # (written before the next one is asked for)
                     output.write(chunk)
     if timings is not None:
         timings["profiles_d2h_tsv_render_write"] = time.perf_counter() - t0

@@ -55,6 +55,28 @@ def record_tables(records):
     return head, head_off, tail, tail_off
 
 
+_SPARE: list = []  # chunk buffers handed back by a consumer that has written them (format_rows_native(recycle=True))
+_SPARE_LOCK = threading.Lock()
+_SPARE_MAX = 96
+
+
+def _take_buffer(cap: int) -> np.ndarray:
+    with _SPARE_LOCK:
+        while _SPARE:
+            buf = _SPARE.pop()
+            if buf.size == cap:
+                return buf  # (its pages are mapped already: a fresh 4 MB buffer costs a thousand page faults)
+    return np.empty(cap, np.uint8)
+
+
+def _give_back(chunk) -> None:
+    buf = getattr(chunk, "obj", None)
+    if isinstance(buf, np.ndarray):
+        with _SPARE_LOCK:
+            if len(_SPARE) < _SPARE_MAX:
+                _SPARE.append(buf)
+
+
 def _format_range(arrays, tables_c, report_all, first, last, chunk_bytes) -> list:
     """Rows of ORFs [first, last) as a list of byte chunks (one C call per chunk)."""
     lib = _lib.load()
@@ -65,7 +87,7 @@ def _format_range(arrays, tables_c, report_all, first, last, chunk_bytes) -> lis
     # no copy of the text is made while the GIL is held.  (Until round 4's last day a reusable buffer was copied out
     # with `out.raw[:n]` -- two copies of every chunk under the GIL, which the one writer thread also needs: 12.8 GB of
     # report_all text took 2.43 s that way, 1.9 s with one copy, and less with none.)
-    out = np.empty(cap, np.uint8)
+    out = _take_buffer(cap)
     nxt = ctypes.c_int64(first)
     ln = ctypes.c_size_t(0)
     cur = first
@@ -86,7 +108,7 @@ def _format_range(arrays, tables_c, report_all, first, last, chunk_bytes) -> lis
         if ln.value:
             chunks.append(memoryview(out)[: ln.value])  # (a view: it keeps its buffer alive until it is written)
             if nxt.value < last:
-                out = np.empty(cap, np.uint8)
+                out = _take_buffer(cap)
         cur = nxt.value
     return chunks
 
@@ -104,12 +126,15 @@ def format_rows_native(
     last: int | None = None,
     chunk_bytes: int = 64 << 20,
     threads: int | None = None,
+    recycle: bool = False,
 ) -> Iterator[bytes]:
     """Yield the TSV body of ORFs [first, last), in order, in chunks of at most
     ``chunk_bytes`` (a single longer row gets a buffer of its own).
 
     ``threads`` > 1 renders disjoint ORF ranges concurrently (the C call holds no shared
-    state and ctypes drops the GIL); default: the usable cores (at most 32), one for small batches."""
+    state and ctypes drops the GIL); default: the usable cores (at most 32), one for small batches.
+    A chunk is a view of a buffer of its own.  ``recycle``: the caller is done with a chunk when it asks for the next
+    one (it wrote it out): the buffer goes back to a pool and later chunks reuse it -- not for callers that keep them."""
     counts = np.ascontiguousarray(counts, dtype=np.int32)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     phase = np.ascontiguousarray(phase, dtype=np.float64)
@@ -132,8 +157,14 @@ def format_rows_native(
     total_nt = int(offsets[last] - offsets[first]) if last > first else 0
     if threads is None:
         threads = min(32, _lib.usable_cores()) if total_nt > (4 << 20) else 1
+    def hand_out(chunks):
+        for chunk in chunks:
+            yield chunk
+            if recycle:
+                _give_back(chunk)
+
     if threads <= 1 or last - first < 2:
-        yield from _format_range(arrays, tables_c, report_all, first, last, chunk_bytes)
+        yield from hand_out(_format_range(arrays, tables_c, report_all, first, last, chunk_bytes))
         return
     # ranges of about chunk_bytes / 4 nucleotides (a row is ~3.2 bytes of text per nt), cut on
     # the prefix sum of lengths; a sliding window of futures keeps the output ordered and bounded
@@ -149,9 +180,9 @@ def format_rows_native(
         for a, b in zip(bounds[:-1], bounds[1:]):
             window.append(pool.submit(_format_range, arrays, tables_c, report_all, int(a), int(b), chunk_bytes))
             if len(window) >= 2 * threads:
-                yield from window.popleft().result()
+                yield from hand_out(window.popleft().result())
         while window:
-            yield from window.popleft().result()
+            yield from hand_out(window.popleft().result())
 
 
 class _OrderedOffsets:
