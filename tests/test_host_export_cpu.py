@@ -339,6 +339,27 @@ def test_native_rows_threaded_equal_serial(packed, threads):
     assert part == b"".join(tsv.format_rows_native(*args, False, first=17, last=140, threads=1))
 
 
+def test_recycled_chunk_buffers_carry_the_same_rows(packed):
+    """format_rows_native(recycle=True): a chunk's buffer goes back to the render threads once the consumer asks for the
+    next chunk (the export writes a chunk before it does).  A consumer that copies each chunk at once sees the same
+    bytes as without recycling, over many passes that reuse the pooled buffers; chunks are views, not copies."""
+    from ribotricer_amd import tsv
+
+    records, counts, offsets = packed
+    res = oracle_results(counts, offsets)
+    tables = tsv.record_tables(records)
+    args = (counts, offsets, res["phase"], res["valid"], res["read_count"], res["status"], tables)
+    want = b"".join(tsv.format_rows_native(*args, True, threads=1))
+    for threads in (1, 3):
+        for _ in range(4):
+            got = []
+            for chunk in tsv.format_rows_native(*args, True, threads=threads, chunk_bytes=1 << 20, recycle=True):
+                assert isinstance(chunk, memoryview)
+                got.append(bytes(chunk))  # (consumed before the next one is asked for)
+            assert b"".join(got) == want
+    assert len(tsv._SPARE) <= tsv._SPARE_MAX
+
+
 def test_native_index_threaded_equals_sequential(monkeypatch):
     """rp_index_parse_host cuts a large text into runs of whole lines, one per thread: same arrays,
     same (strand, chrom) numbering by first appearance, same first malformed line."""
