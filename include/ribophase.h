@@ -504,6 +504,16 @@ int rp_interval_table_host(const int64_t *iv_start, const int64_t *iv_end, const
                            int64_t *out_offsets);
 
 /*
+ * Default-mode bookkeeping of export_orf_coverages (detect_orfs.py:301-303 prints the translating ORFs only): from the
+ * per-ORF `keep` flags and profile lengths, in one pass -- the ids of the kept ORFs (chosen[k]), where each one's profile
+ * starts in the packed array of kept profiles (chosen_off[k], k <= n_chosen), and CSR offsets over ALL ORFs in which
+ * every other ORF has an empty range (offsets[n_orfs + 1]: what the row formatter takes).  chosen / chosen_off need
+ * room for n_orfs (+ 1) entries.
+ */
+int rp_select_profiles_host(const uint8_t *keep, const int64_t *lengths, int64_t n_orfs, int64_t *chosen, int64_t *chosen_off,
+                            int64_t *offsets, int64_t *n_chosen);
+
+/*
  * The part of a coverage array that a set of intervals touches, as a few WINDOWS (what a GPU that scores one slice of
  * the index needs of the whole coverage: engine.CoverageShards; replaces nothing in the reference -- its loop runs on
  * one process).  Intervals that lie closer than 2^gap_shift positions share a window; windows ascend, start and length

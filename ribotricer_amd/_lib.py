@@ -100,6 +100,7 @@ SYMBOLS = {
     "rp_index_view_host": (_int, [_vp, _vp]),
     "rp_index_free": (None, [_vp]),
     "rp_interval_table_host": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "rp_select_profiles_host": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
     "rp_coverage_windows_host": (_int, [_vp, _vp, _i64, ctypes.c_int32, _vp, _vp, _vp, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64), _vp]),
     "rp_bam_split_host": (_int, [ctypes.c_char_p, _int, _vp, ctypes.c_int32, ctypes.POINTER(_vp)]),
     "rp_bam_view_host": (_int, [_vp, _vp]),

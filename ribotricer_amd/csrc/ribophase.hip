@@ -1233,6 +1233,29 @@ int rp_interval_table_host(const int64_t *iv_start, const int64_t *iv_end, const
     return RP_OK;
 }
 
+int rp_select_profiles_host(const uint8_t *keep, const int64_t *lengths, int64_t n_orfs, int64_t *chosen, int64_t *chosen_off,
+                            int64_t *offsets, int64_t *n_chosen)
+{
+    if (!n_chosen || !offsets || !chosen_off) return fail(RP_ERR_NULL, "n_chosen, offsets and chosen_off must be non-null");
+    *n_chosen = 0;
+    if (n_orfs < 0) return fail(RP_ERR_SIZE, "negative size");
+    if (n_orfs > 0 && (!keep || !lengths || !chosen)) return fail(RP_ERR_NULL, "keep, lengths and chosen must be non-null");
+    int64_t k = 0, at = 0;
+    offsets[0] = 0;
+    chosen_off[0] = 0;
+    for (int64_t i = 0; i < n_orfs; ++i) {
+        if (keep[i]) {
+            if (lengths[i] < 0) return fail(RP_ERR_ARG, "ORF %lld has a negative length", (long long)i);
+            chosen[k] = i;
+            at += lengths[i];
+            chosen_off[++k] = at;
+        }
+        offsets[i + 1] = at;
+    }
+    *n_chosen = k;
+    return RP_OK;
+}
+
 int rp_coverage_windows_host(const int64_t *iv_start, const int32_t *iv_len, int64_t n_intervals, int32_t gap_shift,
                              int64_t *win_start, int64_t *win_len, int64_t *win_base, int64_t capacity, int64_t *n_windows,
                              int64_t *total, int64_t *out_iv_start)

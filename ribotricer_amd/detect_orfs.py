@@ -174,7 +174,7 @@ def _devices_from_env():
 
 
 def score_profiles(counts, offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
-                   min_valid_codons_ratio, min_density_over_orf, device=None, devices=None, shards=None) -> dict:
+                   min_valid_codons_ratio, min_density_over_orf, device=None, devices=None, shards=None, pinned=None) -> dict:
     """One launch for the whole batch; host numpy arrays back (24 B + 2 B per ORF).  With
     ``devices`` (several GPUs of this node): nt-balanced ORF-index slices, one per GPU, host
     concat (``engine.score_sharded``).  Exact frame ties carry the reference's bits throughout
@@ -188,7 +188,7 @@ def score_profiles(counts, offsets, phase_score_cutoff, min_valid_codons, min_re
 
         return score_sharded(counts, offsets, devices, thresholds=thresholds, shards=shards)
     eng = get_engine(device if devices is None or not len(devices) else devices[0])
-    return eng.score_host(counts, offsets, thresholds=thresholds)
+    return eng.score_host(counts, offsets, thresholds=thresholds, pinned=pinned)
 
 
 def format_rows(records, counts, offsets, res, report_all: bool):
@@ -297,6 +297,7 @@ def export_orf_coverages(
     counts, offsets, res = score_index(
         index, merged_alignments, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
         min_valid_codons_ratio, min_density_over_orf, report_all, devices, timings=timings, profiles_on_device=True,
+        reuse_result_buffers=True,  # (the results are written out before this function returns)
     )
     t0 = time.perf_counter()
     tables = index.tables_native
@@ -465,7 +466,7 @@ def _profile_slices(counts, offsets, slice_nt: int = 64 << 20):
 
 def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
                 min_valid_codons_ratio, min_density_over_orf, report_all: bool, devices=None, timings=None,
-                profiles_on_device: bool = False):
+                profiles_on_device: bool = False, reuse_result_buffers: bool = False):
     """Gather + score for a natively parsed index: ``(counts, offsets, results)`` as host arrays,
     ready for the row formatter (``profiles_on_device``: ``counts`` stays a device tensor, for
     ``_profile_slices``).
@@ -533,6 +534,7 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
         res = score_profiles(
             d_counts, d_offsets, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
             min_valid_codons_ratio, min_density_over_orf, device=device, devices=devices, shards=shards,
+            pinned=extras.setdefault("pinned_results", {}) if reuse_result_buffers and not sharded else None,
         )
         # (counts beyond 2^24 - 1: score_profiles scans the gathered CSR counts itself -- engine.fix_big_counts_csr)
         t = lap("gather_score_results_d2h", t)
@@ -552,15 +554,18 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     else:
         eng = get_engine(device)
         res = eng.score_coverage(coverage, plan, thresholds=thresholds)
+        # (reuse_result_buffers: pinned staging tensors kept with the index's layout, overwritten by its next sample)
+        res = res.cpu_numpy(extras.setdefault("pinned_results", {}) if reuse_result_buffers else None)
         torch.cuda.synchronize(eng.device)
-        res = res.cpu_numpy()
         resolve_big_ties(res, coverage_profiles_of(coverage, table, device), thresholds)
     if big["positions"].size:
         rescore_big_count_orfs(res, orfs_touching(table, big["positions"]), coverage_profiles_of(coverage, table, device), thresholds, device)
     t = lap("fused_score_results_d2h", t)
     keep = res["status"] != 0
     if plan is not None and not sharded:  # through the plan's pieces: ids and prefix sums on the device (GatherPlan.gather_selected)
-        d_counts, offsets = plan.gather_selected(coverage, keep, lengths=np.diff(table.offsets))
+        if "orf_lengths" not in extras:
+            extras["orf_lengths"] = np.diff(table.offsets)  # (11 M subtractions: once per index, not per sample)
+        d_counts, offsets = plan.gather_selected(coverage, keep, lengths=extras["orf_lengths"], reuse_arrays=reuse_result_buffers)
     else:
         chosen = np.flatnonzero(keep)
         d_counts, _ = gather_profiles_device(coverage, select_orfs(table, chosen), device)

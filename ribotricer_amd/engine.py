@@ -41,8 +41,28 @@ class PhaseScores(NamedTuple):
     flags: torch.Tensor  # uint8    FLAG_TIE | FLAG_RECHECK64 | FLAG_SPLIT
     status: Optional[torch.Tensor]  # uint8    1 = translating (None when no thresholds given)
 
-    def cpu_numpy(self) -> dict:
-        return {k: (None if v is None else v.cpu().numpy()) for k, v in self._asdict().items()}
+    def cpu_numpy(self, pinned: Optional[dict] = None) -> dict:
+        """Host numpy arrays.  ``pinned``: a dict the caller keeps (one per index): the arrays are then views of pinned
+        staging tensors kept in it -- the copies run at PCIe speed instead of through pageable memory (290 MB for 11 M
+        ORFs: 6 ms instead of 29) -- and the NEXT call with the same dict overwrites them: for a caller that is done with
+        one sample's results before it scores the next (export_orf_coverages)."""
+        if pinned is None:
+            return {k: (None if v is None else v.cpu().numpy()) for k, v in self._asdict().items()}
+        out = {}
+        dev = None
+        for k, v in self._asdict().items():
+            if v is None:
+                out[k] = None
+                continue
+            dev = v.device
+            host = pinned.get(k)
+            if host is None or host.numel() != v.numel() or host.dtype != v.dtype:
+                host = pinned[k] = torch.empty(v.numel(), dtype=v.dtype, pin_memory=True)
+            host.copy_(v.reshape(-1), non_blocking=True)
+            out[k] = host.numpy().reshape(tuple(v.shape))
+        if dev is not None and dev.type == "cuda":
+            torch.cuda.current_stream(dev).synchronize()
+        return out
 
 
 class FrameDiagnostics(NamedTuple):
@@ -474,7 +494,8 @@ class PhaseScoreEngine:
         return phase, valid, flags
 
 
-    def score_host(self, counts, offsets, thresholds: Optional[FilterParams] = None, algo: str = "auto", plan="auto") -> dict:
+    def score_host(self, counts, offsets, thresholds: Optional[FilterParams] = None, algo: str = "auto", plan="auto",
+                   pinned: Optional[dict] = None) -> dict:
         """:meth:`score`, waited for and brought to the host as a dict of numpy arrays, with the
         exact frame ties the device could not finish resolved (:func:`resolve_big_ties`): every
         ``phase`` / ``valid`` then carries the reference's bits wherever a tie is flagged.  ORFs that hold a
@@ -482,8 +503,8 @@ class PhaseScoreEngine:
         ``RP_FLAG_BIGCOUNT``): no count the int32 array can hold is refused."""
         d_counts = _as_device(counts, torch.int32, self.device)
         res = self.score(d_counts, offsets, thresholds=thresholds, algo=algo, plan=plan)
+        host = res.cpu_numpy(pinned)  # (``pinned``: PhaseScores.cpu_numpy -- staging tensors the caller keeps and lets the next call overwrite)
         torch.cuda.synchronize(self.device)
-        host = res.cpu_numpy()
         resolve_big_ties(host, csr_profiles_of(counts, offsets), thresholds)
         fix_big_counts_csr(host, d_counts, offsets, thresholds)  # counts beyond 2^24 - 1: those ORFs again, in float64 / int64
         return host

@@ -277,32 +277,41 @@ class GatherPlan:
         _lib.check(_lib.load().rp_gather_profiles_plan_dev(self.handle, _ptr(cov), cov.numel(), _ptr(counts), stream))
         return counts
 
-    def gather_selected(self, coverage, keep: np.ndarray, lengths: np.ndarray = None):
+    def gather_selected(self, coverage, keep: np.ndarray, lengths: np.ndarray = None, reuse_arrays: bool = False):
         """Profiles of the ORFs with ``keep[i]`` true (host bool array of n_orfs), packed one after the other on the
         device: ``(counts int32 device tensor, offsets int64 host array [n_orfs + 1])`` where every other ORF has an
         empty range -- what the TSV writer takes in default mode (only translating ORFs are printed,
-        detect_orfs.py:301-303).  One wave per chosen ORF copies its pieces (``rp_gather_selected_plan_dev``); the ids and
-        the two prefix sums are three numpy passes on the host (torch ops would do them in a millisecond, but each op's
-        first use in a process costs ~0.1 s of code loading on ROCm: a single-sample run is the common case).
-        ``lengths``: profile lengths of all ORFs (default: from this plan's offsets, one device read-back)."""
+        detect_orfs.py:301-303).  One wave per chosen ORF copies its pieces (``rp_gather_selected_plan_dev``); the ids, the
+        packed starts and the all-ORF offsets come from one native pass on the host (``rp_select_profiles_host``; torch ops would
+        do them in a millisecond, but each op's first use in a process costs ~0.1 s of code loading on ROCm, and a
+        single-sample run is the common case).
+        ``lengths``: profile lengths of all ORFs (default: from this plan's offsets, one device read-back).
+        ``reuse_arrays``: the returned ``offsets`` is this plan's scratch array, overwritten by its next call (the export
+        is done with one sample's offsets before it scores the next); default: a copy."""
         cov = _as_device(coverage, torch.int32, self.device)
         keep = np.ascontiguousarray(keep, dtype=np.bool_)
         if lengths is None:
             lengths = np.diff(self.offsets.cpu().numpy())
-        chosen = np.flatnonzero(keep)
-        sel_len = np.asarray(lengths, np.int64)[chosen]
-        out_off = np.zeros(chosen.size + 1, np.int64)
-        np.cumsum(sel_len, out=out_off[1:])
-        offsets = np.zeros(self.n_orfs + 1, np.int64)
-        offsets[chosen + 1] = sel_len
-        np.cumsum(offsets, out=offsets)
+        lengths = np.ascontiguousarray(lengths, dtype=np.int64)
+        # ids, packed starts and the all-ORF offsets in one native pass (rp_select_profiles_host); the three arrays are kept
+        # for the next sample of this plan (88 MB each for 11 M ORFs: a fresh one costs more in page faults than the pass)
+        scratch = self.__dict__.setdefault("_select_scratch", {})
+        if scratch.get("n") != self.n_orfs:
+            scratch.update(n=self.n_orfs, chosen=np.empty(self.n_orfs, np.int64), chosen_off=np.empty(self.n_orfs + 1, np.int64),
+                           offsets=np.empty(self.n_orfs + 1, np.int64))
+        n_chosen = ctypes.c_int64(0)
+        ptr = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
+        _lib.check(_lib.load().rp_select_profiles_host(ptr(keep.view(np.uint8)), ptr(lengths), self.n_orfs, ptr(scratch["chosen"]),
+                                                      ptr(scratch["chosen_off"]), ptr(scratch["offsets"]), ctypes.byref(n_chosen)))
+        k = int(n_chosen.value)
+        chosen, out_off, offsets = scratch["chosen"][:k], scratch["chosen_off"][: k + 1], scratch["offsets"]
         counts = torch.empty(int(out_off[-1]), dtype=torch.int32, device=self.device)
         d_chosen = torch.from_numpy(chosen).to(self.device, non_blocking=True)
         d_off = torch.from_numpy(out_off[:-1].copy()).to(self.device, non_blocking=True)
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(_lib.load().rp_gather_selected_plan_dev(self.handle, _ptr(cov), cov.numel(), _ptr(d_chosen), d_chosen.numel(),
                                                           _ptr(d_off), _ptr(counts), stream))
-        return counts, offsets
+        return counts, (offsets if reuse_arrays else offsets.copy())
 
     def stats(self) -> dict:
         """Diagnostics (scripts): how the tiles of this plan are staged -- chunk rows per tile (<= 64
