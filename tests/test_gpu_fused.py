@@ -88,6 +88,40 @@ def test_gather_selected_equals_the_sub_table_gather():
         assert torch.equal(sub, counts)
 
 
+def test_reused_host_arrays_of_the_export_path():
+    """What export_orf_coverages reuses from sample to sample: PhaseScores.cpu_numpy(pinned) returns views of pinned
+    staging tensors kept in the caller's dict (equal to the plain copies; the next call overwrites them), and
+    GatherPlan.gather_selected(reuse_arrays=True) returns the plan's scratch offsets (a copy by default)."""
+    import torch
+
+    from ribotricer_amd.engine import get_engine, make_filter
+    from ribotricer_amd.gather import GatherPlan
+
+    rng = np.random.default_rng(21)
+    cov = rng.poisson(0.8, size=600_000).astype(np.int32)
+    t = random_table(rng, 3000, cov.size, max_exons=4, exon_len=(30, 300))
+    plan = GatherPlan(t, cov.size)
+    eng = get_engine("cuda:0")
+    res = eng.score_coverage(cov, plan, thresholds=make_filter())
+    plain = res.cpu_numpy()
+    keep_dict: dict = {}
+    pinned = res.cpu_numpy(keep_dict)
+    assert all(np.array_equal(plain[k], pinned[k]) for k in plain)
+    assert all(keep_dict[k].is_pinned() for k in keep_dict)
+    first_phase = pinned["phase"]
+    res2 = eng.score_coverage(np.zeros_like(cov), plan, thresholds=make_filter())
+    again = res2.cpu_numpy(keep_dict)
+    assert again["phase"] is not first_phase and np.shares_memory(again["phase"], first_phase)  # (same staging memory)
+    assert not again["phase"].any() and not first_phase.any()  # ... which the second call overwrote
+    keep = plain["status"] != 0
+    lengths = np.diff(t.offsets)
+    c1, o1 = plan.gather_selected(cov, keep, lengths=lengths)
+    c2, o2 = plan.gather_selected(cov, keep, lengths=lengths, reuse_arrays=True)
+    assert torch.equal(c1, c2) and np.array_equal(o1, o2)
+    _, o3 = plan.gather_selected(cov, np.zeros_like(keep), lengths=lengths, reuse_arrays=True)
+    assert np.shares_memory(o2, o3) and not o3.any() and o1.any()  # (the default's copy is untouched)
+
+
 @pytest.mark.parametrize("block", [1, 8, 64])
 def test_compact_coverage_map(block):
     """gather.CoverageMap: only the blocks of `block` positions under an exon interval keep a slot.  The table in compact
