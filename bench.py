@@ -485,7 +485,7 @@ def main():
 
     n_dev = torch.cuda.device_count()
     if n_dev == 0:
-        sys.exit("bench.py needs a HIP device (ribotricer_amd has no CPU path)")
+        sys.exit("bench.py measures the hip backend: it needs a HIP device")
     local_dev = local_rank % n_dev  # one rank per GPU on the driver's node; wraps only in 1-GPU self-tests
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)

@@ -22,8 +22,10 @@
  *   - counts must satisfy 0 <= counts[k] <= RP_MAX_COUNT.
  *   - an entry point taking `device` makes it current for the duration of the call and
  *     restores the calling thread's previous HIP device before it returns.
- *   - there is no CPU fallback: without a usable HIP device every compute entry
- *     point fails with RP_ERR_DEVICE / RP_ERR_HIP.
+ *   - the *_dev entry points never fall back to the CPU: without a usable HIP device they fail with
+ *     RP_ERR_DEVICE / RP_ERR_HIP.  The *_host entry points (no GPU involved) restate the reference's own float64
+ *     arithmetic in C++; the Python layer routes through them ONLY when asked to (RIBOTRICER_AMD_BACKEND=cpu, or
+ *     "auto" on a machine where no HIP device is visible) -- never behind a failing device call.
  */
 #ifndef RIBOPHASE_H
 #define RIBOPHASE_H
@@ -240,9 +242,9 @@ int rp_tie_replay_f64_host(const double *values, const int64_t *offsets, int64_t
  * as rp_phase_score_csr_dev's (host pointers): phase and valid_codons carry the reference's bits on
  * EVERY ORF, read_count / min_codon_cov are the integer results, flags = 0, status (may be NULL)
  * the predicate of `filter` (may be NULL: no status).  n_threads <= 0: all hardware threads.
- * NOT a fallback: nothing in the ribotricer_amd package routes scoring through it (there is no CPU
- * path in the product); it serves callers that want the reference's bits without a GPU and the
- * GPU-free cross-checks in tests/.  ~1 microsecond per codon and thread.
+ * The scoring step of the GPU-less backend (RIBOTRICER_AMD_BACKEND=cpu: export_orf_coverages / phasescore on a
+ * machine without a HIP device -- BASELINE configs[0], "CPU path, plumbing"); never used while the hip backend is
+ * selected, and never as a fallback behind a failing device call.  ~1 microsecond per codon and thread.
  */
 int rp_phase_score_csr_host(const int32_t *counts, const int64_t *offsets, int64_t n_orfs, double *phase,
                             int32_t *valid, int64_t *read_count, int32_t *min_codon_cov, uint8_t *flags,
@@ -414,6 +416,10 @@ int rp_coverage_big_positions_dev(int device, const int32_t *d_coverage, int64_t
 int rp_metagene_dev(int device, const int32_t *d_counts, const int64_t *d_offsets, int64_t n_orfs,
                     int32_t max_positions, double *d_mean, double *d_sum, int32_t *d_seen, void *hip_stream);
 
+/* rp_metagene_dev on the HOST (the GPU-less backend): the same float64 operations in the same order, same outputs. */
+int rp_metagene_host(const int32_t *counts, const int64_t *offsets, int64_t n_orfs, int32_t max_positions, double *mean,
+                     double *sum, int32_t *seen);
+
 /*
  * Synchronous input check (one pass over offsets and counts on the device, then a
  * host sync): RP_ERR_OFFSETS / RP_ERR_COUNTS as documented above.
@@ -502,6 +508,23 @@ int rp_interval_table_host(const int64_t *iv_start, const int64_t *iv_end, const
                            const int64_t *length, int64_t n_orfs, int64_t n_intervals, const int64_t *group_start,
                            const int64_t *group_lo, int64_t n_groups, int64_t *out_iv_start, int32_t *out_iv_len,
                            int64_t *out_offsets);
+
+/*
+ * orf_coverage for every ORF of a parsed index ON THE HOST (detect_orfs.py:134-203; the gather of the GPU-less backend,
+ * RIBOTRICER_AMD_BACKEND=cpu -- the device paths are rp_gather_profiles_dev / the gather plan): the merged P-site counts
+ * (merge_read_lengths, detect_orfs.py:54-83) come as a sorted table instead of a dict,
+ *   keys  int64[n_keys]  (group << 40) | position, ascending and unique: group = the (strand, chrom) group of the index
+ *                        (rp_index_view.group numbering), position 1-based and already shifted by the P-site offset
+ *   vals  int64[n_keys]  reads at that position (rows of one position added up by the caller)
+ * and every position of every exon interval (rp_index_view: iv_start / iv_end 1-based closed, orf_iv, group, reverse) is
+ * looked up in it: absent = 0 (the missing-key case of detect_orfs.py:176-187), '-' strand profiles reversed (:201-202).
+ *   offsets int64[n_orfs + 1]  prefix sums of the ORF lengths;  counts int32[offsets[n_orfs]]  output (CSR).
+ * RP_ERR_COUNTS for a count that is negative or passes 2^31 - 1 (the CSR array is int32), RP_ERR_OFFSETS when an ORF's
+ * intervals do not add up to its length.  n_threads <= 0: all usable cores.
+ */
+int rp_gather_profiles_host(const int64_t *keys, const int64_t *vals, int64_t n_keys, const int64_t *iv_start,
+                            const int64_t *iv_end, const int64_t *orf_iv, const int32_t *group, const uint8_t *reverse,
+                            const int64_t *offsets, int64_t n_orfs, int32_t *counts, int n_threads);
 
 /*
  * Default-mode bookkeeping of export_orf_coverages (detect_orfs.py:301-303 prints the translating ORFs only): from the

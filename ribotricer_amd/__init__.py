@@ -9,8 +9,10 @@ host-side mirror of the reference interface for that path:
     ribotricer_amd.detect_orfs.export_orf_coverages <- ribotricer.detect_orfs.export_orf_coverages
     ribotricer_amd.engine.phase_score_csr           (batch seam the GPU path sits behind)
 
-No CPU fallback: the HIP library must be built (``make -C ribotricer_amd/csrc``)
-and a GPU must be present for any compute call.
+The HIP library must be built (``make -C ribotricer_amd/csrc``).  ``RIBOTRICER_AMD_BACKEND`` = ``hip`` | ``cpu`` |
+``auto`` (default: hip when a HIP device is visible, else cpu -- decided from what is visible before any work, never
+behind a failing device call; ``backend.py``).  The cpu backend runs export_orf_coverages / phasescore / detect_orfs
+through the library's ``*_host`` entry points: the reference's own float64 arithmetic in C++.
 """
 
 

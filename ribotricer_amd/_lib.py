@@ -1,9 +1,9 @@
 """ctypes binding of libribophase.so (C ABI: include/ribophase.h).
 
-The shared library is the product: there is no Python or CPU stand-in for it.
-Importing this module without a built library raises immediately with the build
-command; calling a compute entry point without a usable HIP device raises
-``RibophaseError`` carrying the library's own message.
+The shared library is the product: there is no Python stand-in for it (the GPU-less backend,
+``backend.py``, is the library's own ``*_host`` entry points).  Importing this module without a built
+library raises immediately with the build command; calling a ``*_dev`` entry point without a usable HIP
+device raises ``RibophaseError`` carrying the library's own message.
 """
 
 from __future__ import annotations
@@ -87,6 +87,7 @@ SYMBOLS = {
                                            _vp, ctypes.c_size_t, _vp, _vp, _vp, ctypes.POINTER(ctypes.c_float * 4)]),
     "rp_validate_csr_dev": (_int, [_int, _vp, _vp, _i64, _i64, _vp]),
     "rp_metagene_dev": (_int, [_int, _vp, _vp, _i64, ctypes.c_int32, _vp, _vp, _vp, _vp]),
+    "rp_metagene_host": (_int, [_vp, _vp, _i64, ctypes.c_int32, _vp, _vp, _vp]),
     "rp_coverage_build_dev": (_int, [_int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp, ctypes.POINTER(ctypes.c_int32)]),
     "rp_coverage_build_rows_dev": (_int, [_int, _vp, _vp, _vp, _vp, _i64, _vp, ctypes.c_int32, _vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp,
                                           ctypes.POINTER(ctypes.c_int32), _vp, _i64, ctypes.c_int32]),
@@ -100,6 +101,7 @@ SYMBOLS = {
     "rp_index_view_host": (_int, [_vp, _vp]),
     "rp_index_free": (None, [_vp]),
     "rp_interval_table_host": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "rp_gather_profiles_host": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _int]),
     "rp_select_profiles_host": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, ctypes.POINTER(_i64)]),
     "rp_coverage_windows_host": (_int, [_vp, _vp, _i64, ctypes.c_int32, _vp, _vp, _vp, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64), _vp]),
     "rp_bam_split_host": (_int, [ctypes.c_char_p, _int, _vp, ctypes.c_int32, ctypes.POINTER(_vp)]),
@@ -125,7 +127,7 @@ def load() -> ctypes.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing. Build the HIP extension first: "
             "`make -C ribotricer_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
-            "ribotricer_amd has no CPU fallback."
+            "Both backends (hip and cpu) live in that library."
         )
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SYMBOLS.items():
@@ -217,9 +219,9 @@ def usable_cores() -> int:
 
 def phase_score_csr_host(counts, offsets, thresholds=None, n_threads: int = 0) -> dict:
     """``rp_phase_score_csr_host``: the per-ORF loop body on the HOST in the reference's own float64
-    arithmetic (SURVEY.md 8(b) lists a host entry point beside the device one).  NOT a fallback --
-    nothing in this package scores through it; for callers without a GPU who want the reference's
-    bits, and for GPU-free cross-checks.  Returns a dict of numpy arrays like ``PhaseScores.cpu_numpy()``."""
+    arithmetic (SURVEY.md 8(b) lists a host entry point beside the device one): the scoring step of the
+    GPU-less backend (``backend.py``, RIBOTRICER_AMD_BACKEND=cpu) and of GPU-free cross-checks; never a
+    fallback behind a failing device call.  Returns a dict of numpy arrays like ``PhaseScores.cpu_numpy()``."""
     import numpy as np
 
     counts = np.ascontiguousarray(counts, dtype=np.int32)

@@ -1025,6 +1025,36 @@ int rp_metagene_dev(int device, const int32_t *d_counts, const int64_t *d_offset
     return RP_OK;
 }
 
+int rp_metagene_host(const int32_t *counts, const int64_t *offsets, int64_t n_orfs, int32_t max_positions, double *mean,
+                     double *sum, int32_t *seen)
+{
+    if (n_orfs < 0 || max_positions < 0) return fail(RP_ERR_SIZE, "negative size");
+    if ((n_orfs > 0 && (!offsets || !mean)) || (max_positions > 0 && (!sum || !seen))) return fail(RP_ERR_NULL, "offsets / outputs must be non-null");
+    for (int32_t t = 0; t < 2 * max_positions; ++t) {
+        sum[t] = 0.0;
+        seen[t] = 0;
+    }
+    // ORFs in index order; per slot the same float64 operations in the same order as rp::k_metagene_sums (and as pandas:
+    // Series / mean, then Series.add(fill_value=0) ORF after ORF, metagene.py:213-228)
+    for (int64_t i = 0; i < n_orfs; ++i) {
+        const int64_t beg = offsets[i], len = offsets[i + 1] - beg;
+        if (len < 0 || (len > 0 && !counts)) return fail(RP_ERR_OFFSETS, "profile %lld: bad offsets or null counts", (long long)i);
+        int64_t s = 0;
+        for (int64_t k = 0; k < len; ++k) s += counts[beg + k];
+        const double m = len > 0 ? (double)s / (double)len : 0.0;
+        mean[i] = m;
+        if (!(m > 0.0)) continue;
+        const int64_t n = len < max_positions ? len : max_positions;
+        for (int64_t slot = 0; slot < n; ++slot) {
+            sum[slot] = sum[slot] + (double)counts[beg + slot] / m;
+            ++seen[slot];
+            sum[max_positions + slot] = sum[max_positions + slot] + (double)counts[beg + len - 1 - slot] / m;
+            ++seen[max_positions + slot];
+        }
+    }
+    return RP_OK;
+}
+
 int rp_format_rows_host(const int32_t *counts, const int64_t *offsets, int64_t n_orfs,
                         const double *phase, const int32_t *valid, const int64_t *read_count,
                         const uint8_t *status, const char *head, const int64_t *head_off,
@@ -1230,6 +1260,78 @@ int rp_interval_table_host(const int64_t *iv_start, const int64_t *iv_end, const
     std::vector<int64_t> base((size_t)threads, 0);
     for (int t = 1; t < threads; ++t) base[(size_t)t] = base[(size_t)t - 1] + parts[(size_t)t - 1].total;
     if (threads > 1) run([&](int t) { if (base[(size_t)t] != 0) rebase(t, base[(size_t)t]); });
+    return RP_OK;
+}
+
+int rp_gather_profiles_host(const int64_t *keys, const int64_t *vals, int64_t n_keys, const int64_t *iv_start,
+                            const int64_t *iv_end, const int64_t *orf_iv, const int32_t *group, const uint8_t *reverse,
+                            const int64_t *offsets, int64_t n_orfs, int32_t *counts, int n_threads)
+{
+    if (n_orfs < 0 || n_keys < 0) return fail(RP_ERR_SIZE, "negative size");
+    if (n_orfs == 0) return RP_OK;
+    if (!orf_iv || !group || !reverse || !offsets) return fail(RP_ERR_NULL, "index arrays and offsets must be non-null");
+    if (n_keys > 0 && (!keys || !vals)) return fail(RP_ERR_NULL, "keys / vals is null");
+    if (offsets[n_orfs] > 0 && (!counts || !iv_start || !iv_end)) return fail(RP_ERR_NULL, "counts / intervals is null");
+    int threads = n_threads > 0 ? n_threads : rphost::usable_threads();
+    if (threads > 64) threads = 64;
+    if (n_orfs < 4096 || threads < 1) threads = 1;
+    std::vector<int64_t> bad((size_t)threads, -1);
+    std::vector<int> why((size_t)threads, 0);
+    auto work = [&](int t) {
+        const int64_t a = n_orfs * t / threads, b = n_orfs * (t + 1) / threads;
+        for (int64_t i = a; i < b; ++i) {
+            const int64_t beg = offsets[i], len = offsets[i + 1] - beg;
+            const int64_t k0 = orf_iv[i], k1 = orf_iv[i + 1];
+            const int64_t g = group[i];
+            int64_t total = 0;
+            for (int64_t k = k0; k < k1; ++k) total += iv_end[k] - iv_start[k] + 1;
+            if (len < 0 || g < 0 || k1 < k0 || total != len) {
+                bad[(size_t)t] = i;
+                why[(size_t)t] = RP_ERR_OFFSETS;
+                return;
+            }
+            int32_t *dst = counts + beg;
+            std::memset(dst, 0, (size_t)len * sizeof(int32_t));  // a position that is not a key counts 0 (detect_orfs.py:176-187)
+            const bool rev = reverse[i] != 0;
+            int64_t asc = 0;  // ascending position inside the ORF of the interval's first nucleotide
+            for (int64_t k = k0; k < k1; ++k) {
+                const int64_t s = iv_start[k], e = iv_end[k];
+                // (a leader that reaches below position 1, metagene.py:128-143, or a position past 2^40 is never a key:
+                // the caller's keys hold 40 bits of position)
+                const int64_t s_key = s < 0 ? 0 : s, e_key = e >= ((int64_t)1 << 40) ? ((int64_t)1 << 40) - 1 : e;
+                if (s_key > e_key) {
+                    asc += e - s + 1;
+                    continue;
+                }
+                const int64_t lo_key = (g << 40) | s_key, hi_key = (g << 40) | e_key;
+                const int64_t *p = std::lower_bound(keys, keys + n_keys, lo_key);
+                for (; p < keys + n_keys && *p <= hi_key; ++p) {
+                    const int64_t v = vals[p - keys];
+                    if (v < 0 || v > INT32_MAX) {
+                        bad[(size_t)t] = i;
+                        why[(size_t)t] = RP_ERR_COUNTS;
+                        return;
+                    }
+                    const int64_t at = asc + ((*p & (((int64_t)1 << 40) - 1)) - s);
+                    dst[rev ? len - 1 - at : at] = (int32_t)v;  // '-' strand: the profile runs 5'->3' (detect_orfs.py:201-202)
+                }
+                asc += e - s + 1;
+            }
+        }
+    };
+    if (threads == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t) pool.emplace_back(work, t);
+        for (auto &th : pool) th.join();
+    }
+    for (int t = 0; t < threads; ++t)
+        if (bad[(size_t)t] >= 0) {
+            if (why[(size_t)t] == RP_ERR_COUNTS)
+                return fail(RP_ERR_COUNTS, "ORF %lld: a P-site count is negative or passes 2^31 - 1", (long long)bad[(size_t)t]);
+            return fail(RP_ERR_OFFSETS, "ORF %lld: its intervals do not add up to its profile length", (long long)bad[(size_t)t]);
+        }
     return RP_OK;
 }
 

@@ -268,12 +268,36 @@ def export_orf_coverages(
 
     index text -> ``rp_index_parse_host`` (f3) -> interval table + gather plan -> (f1, fused:
     :func:`score_index`) ``rp_phase_score_coverage_dev`` -> ``rp_format_rows_host`` (f2): no
-    per-ORF Python."""
+    per-ORF Python.  ``RIBOTRICER_AMD_BACKEND=cpu`` (or ``auto`` without a visible HIP device): the same
+    pipeline on the host through the library's ``*_host`` entry points (``backend.py``) -- the reference's
+    bits in every column."""
     from . import tsv
     from .index import NativeIndex
 
     import time
 
+    from . import backend
+
+    if backend.selected() == "cpu":
+        # the GPU-less backend (backend.py): parser -> host gather -> rp_phase_score_csr_host -> the same row formatter.
+        # Chosen from what is visible BEFORE any work; a failing device call below is never retried here.
+        t0 = time.perf_counter()
+        index = _index_of(ribotricer_index)
+        if timings is not None:
+            timings["index_parse"] = time.perf_counter() - t0
+        counts, offsets, res = backend.score_index_host(
+            index, merged_alignments, make_filter(phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio,
+                                                  min_density_over_orf), timings=timings)
+        t0 = time.perf_counter()
+        with open(f"{prefix}_translating_ORFs.tsv", "wb") as output:
+            output.write(("\t".join(COLUMNS) + "\n").encode("utf-8"))
+            for chunk in tsv.format_rows_native(counts, offsets, res["phase"], res["valid"], res["read_count"], res["status"],
+                                                index.tables_native, report_all, recycle=True):
+                output.write(chunk)
+        if timings is not None:
+            timings["tsv_render_write"] = time.perf_counter() - t0
+            timings["backend"] = "cpu"
+        return
     if devices is None:
         devices = _devices_from_env()
     t0 = time.perf_counter()

@@ -1,8 +1,9 @@
 """Batch phase scoring on one MI355X through the C ABI (include/ribophase.h).
 
 PyTorch is plumbing here: it owns device memory and the HIP stream; every number
-is produced by the hand-written gfx950 kernels in ``csrc/``.  There is no CPU
-path -- without a GPU (or without the built library) the calls raise.
+is produced by the hand-written gfx950 kernels in ``csrc/``.  Nothing here ever
+falls back to the CPU -- without a GPU (or without the built library) the calls raise
+(the GPU-less backend of the drop-in functions is a separate, explicitly selected path: backend.py).
 
 The batch call replaces the per-ORF body of the reference's hot loop
 (ribotricer/detect_orfs.py:274-299): ``sum(cov)``, ``phasescore(cov)``
@@ -90,9 +91,10 @@ def make_filter(
 
 def _require_gpu() -> None:
     if not torch.cuda.is_available():
-        # let the library produce its own diagnostic; it has no CPU path either
+        # let the library produce its own diagnostic
         _lib.device_count()
-        raise RibophaseError(-6, "no HIP device visible to PyTorch; ribotricer_amd has no CPU fallback")
+        raise RibophaseError(-6, "no HIP device visible to PyTorch; the hip backend never falls back to the CPU "
+                                 "(RIBOTRICER_AMD_BACKEND=cpu selects the host backend of export_orf_coverages / phasescore)")
 
 
 def _as_device(x, dtype: torch.dtype, device: torch.device) -> torch.Tensor:

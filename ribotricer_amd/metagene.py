@@ -40,6 +40,8 @@ class _CdsLayout:
                 ext[key] = (lo, hi)
         self.extents = ext
         self.group_keys = sorted(ext)
+        self.group_lo = np.array([ext[k][0] for k in self.group_keys], np.int64)
+        self.group_hi = np.array([ext[k][1] for k in self.group_keys], np.int64)
 
 
 def _profile_intervals(records, base, max_positions: int, offset_5p: int, offset_3p: int):
@@ -134,11 +136,9 @@ def metagene_coverage(cds, alignments, read_lengths, prefix, max_positions=600, 
     phase_3p, valid_3p)}`` with pandas Series profiles and writes the two
     ``{prefix}_metagene_profiles_{5p,3p}.tsv`` files."""
     import pandas as pd
-    import torch
 
-    from .alignments import AlignmentColumns, build_coverage_device
-    from .engine import _ptr, get_engine
-    from .gather import coverage_layout, gather_profiles_device
+    from . import backend
+    from .alignments import AlignmentColumns
     from .statistics import phasescore_batch
 
     for length, reads in list(read_lengths.items()):  # metagene.py:196-199
@@ -146,32 +146,58 @@ def metagene_coverage(cds, alignments, read_lengths, prefix, max_positions=600, 
             del read_lengths[length]
     cols = alignments if isinstance(alignments, AlignmentColumns) else AlignmentColumns.from_nested(alignments)
     records = _as_records(cds)
-    eng = get_engine(device)
-    dev = eng.device
     layout = _CdsLayout(records, max(offset_5p, offset_3p))
-    base, _ = coverage_layout(layout.extents)
-    table = _profile_intervals(records, base, max_positions, offset_5p, offset_3p)
     lib = _lib.load()
+    on_host = backend.selected() == "cpu"
+    if on_host:  # the GPU-less backend: the same profiles through rp_gather_profiles_host / rp_metagene_host
+        table = _profile_intervals(records, {k: (0, 0) for k in layout.group_keys}, max_positions, offset_5p, offset_3p)  # genomic coordinates
+        group_of = {k: g for g, k in enumerate(layout.group_keys)}
+        h_group = np.array([group_of[(r.strand, r.chrom)] for r in records], np.int32)
+        h_start = np.ascontiguousarray(table.iv_start, np.int64)
+        h_end = h_start + np.asarray(table.iv_len, np.int64) - 1
+        ptr = backend._ptr
+    else:
+        import torch
+
+        from .alignments import build_coverage_device
+        from .engine import _ptr, get_engine
+        from .gather import coverage_layout, gather_profiles_device
+
+        eng = get_engine(device)
+        dev = eng.device
+        base, _ = coverage_layout(layout.extents)
+        table = _profile_intervals(records, base, max_positions, offset_5p, offset_3p)
     metagenes = {}
     for length in read_lengths:
-        # (big={}: counts beyond 2^24 - 1 are fine here -- the metagene kernels add in int64 / float64)
-        coverage, _ = build_coverage_device(cols.of_length(int(length)), layout, dev, big={})
-        counts, offsets = gather_profiles_device(coverage, table, dev)
-        n = offsets.numel() - 1
-        mean = torch.empty(max(n, 1), dtype=torch.float64, device=dev)
-        sums = torch.empty(2 * max_positions, dtype=torch.float64, device=dev)
-        seen = torch.empty(2 * max_positions, dtype=torch.int32, device=dev)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _lib.check(lib.rp_metagene_dev(dev.index, _ptr(counts), _ptr(offsets), n, max_positions, _ptr(mean), _ptr(sums), _ptr(seen), stream))
-        torch.cuda.synchronize(dev)
-        sums_h, seen_h = sums.cpu().numpy(), seen.cpu().numpy()
+        if on_host:
+            keys, vals = backend.merged_keys(cols.of_length(int(length)), layout)
+            n = len(records)
+            h_counts = np.empty(int(table.offsets[-1]), np.int32)
+            _lib.check(lib.rp_gather_profiles_host(ptr(keys), ptr(vals), keys.size, ptr(h_start), ptr(h_end), ptr(table.orf_iv), ptr(h_group),
+                                                   ptr(table.reverse), ptr(table.offsets), n, ptr(h_counts), 0))
+            h_mean = np.empty(max(n, 1), np.float64)
+            sums_h = np.empty(2 * max_positions, np.float64)
+            seen_h = np.empty(2 * max_positions, np.int32)
+            _lib.check(lib.rp_metagene_host(ptr(h_counts), ptr(table.offsets), n, max_positions, ptr(h_mean), ptr(sums_h), ptr(seen_h)))
+        else:
+            # (big={}: counts beyond 2^24 - 1 are fine here -- the metagene kernels add in int64 / float64)
+            coverage, _ = build_coverage_device(cols.of_length(int(length)), layout, dev, big={})
+            counts, offsets = gather_profiles_device(coverage, table, dev)
+            n = offsets.numel() - 1
+            mean = torch.empty(max(n, 1), dtype=torch.float64, device=dev)
+            sums = torch.empty(2 * max_positions, dtype=torch.float64, device=dev)
+            seen = torch.empty(2 * max_positions, dtype=torch.int32, device=dev)
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.rp_metagene_dev(dev.index, _ptr(counts), _ptr(offsets), n, max_positions, _ptr(mean), _ptr(sums), _ptr(seen), stream))
+            torch.cuda.synchronize(dev)
+            sums_h, seen_h = sums.cpu().numpy(), seen.cpu().numpy()
         n_start = int((seen_h[:max_positions] > 0).sum())
         n_stop = int((seen_h[max_positions:] > 0).sum())
         start_vals = sums_h[:n_start] / seen_h[:n_start]  # metagene.py:236-238
         stop_vals = (sums_h[max_positions : max_positions + n_stop] / seen_h[max_positions : max_positions + n_stop])[::-1]
         from_start = pd.Series(start_vals, index=np.arange(-offset_5p, n_start - offset_5p))
         from_stop = pd.Series(stop_vals, index=np.arange(offset_3p - n_stop + 1, offset_3p + 1))
-        phase, valid, _ = phasescore_batch([start_vals, stop_vals], device=dev)
+        phase, valid, _ = phasescore_batch([start_vals, stop_vals], device=None if on_host else dev)
         metagenes[length] = (from_start, from_stop, np.float64(phase[0]), int(valid[0]), np.float64(phase[1]), int(valid[1]))
     to_write_5p = "fragment_length\toffset_5p\tprofile\tphase_score\tvalid_codons\n"
     to_write_3p = "fragment_length\toffset_3p\tprofile\tphase_score\tvalid_codons\n"

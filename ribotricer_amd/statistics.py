@@ -4,7 +4,9 @@
 (ribotricer/statistics.py:48-115: ``(np.float64 phase_score, int valid_codons)``)
 but every number comes from the gfx950 kernels behind libribophase.so.  Callers in
 the reference: detect_orfs.py:280 (int profiles), metagene.py:243-244 (float
-profiles), utils.py:227-229.  No CPU fallback.
+profiles), utils.py:227-229.  ``RIBOTRICER_AMD_BACKEND=cpu`` (or ``auto`` on a machine
+without a HIP device) takes the library's host entry points instead -- the reference's own
+float64 operation sequence in C++ (``backend.py``); a failing device call is never retried there.
 """
 
 from __future__ import annotations
@@ -13,7 +15,7 @@ from collections.abc import Sequence
 
 import numpy as np
 
-from . import _lib
+from . import _lib, backend
 from .engine import get_engine
 
 
@@ -31,6 +33,8 @@ def phasescore_batch(profiles: Sequence[Sequence[float]], device=None):
 
     arrays = [np.asarray(list(p) if not isinstance(p, np.ndarray) else p) for p in profiles]
     arrays = [a.astype(np.float64) if a.size == 0 else a for a in arrays]
+    if backend.selected() == "cpu":
+        return backend.phasescore_batch_host(arrays)
     lengths = np.array([a.size for a in arrays], np.int64)
     offsets = np.zeros(len(arrays) + 1, np.int64)
     np.cumsum(lengths, out=offsets[1:])

@@ -25,6 +25,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X GPU (HIP path through the C ABI)")
 
 
+@pytest.fixture(autouse=True)
+def _gpu_tests_insist_on_the_hip_backend(request, monkeypatch):
+    """A test marked gpu must run the HIP path or fail: never the host backend that ``auto`` would pick on a box whose
+    GPU is not visible."""
+    if request.node.get_closest_marker("gpu") is not None:
+        monkeypatch.setenv("RIBOTRICER_AMD_BACKEND", "hip")
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

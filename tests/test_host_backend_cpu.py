@@ -1,0 +1,182 @@
+"""The GPU-less backend (RIBOTRICER_AMD_BACKEND=cpu; ribotricer_amd/backend.py): export_orf_coverages and phasescore
+entirely through the library's *_host entry points -- BASELINE configs[0], "CPU path, plumbing" -- against outputs of
+the reference itself.  It is the reference's own float64 operation sequence, so the bar here is BYTES: every column of
+the G6 / G10 TSVs (phase score included, where the GPU path is held to 1e-6) and every bit of the G1 / G5 vectors.
+Nothing from oracle/ is involved."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from test_host_export_cpu import load_alignments
+
+
+@pytest.fixture()
+def cpu_backend(monkeypatch):
+    monkeypatch.setenv("RIBOTRICER_AMD_BACKEND", "cpu")
+    monkeypatch.setenv("RIBOTRICER_AMD_INDEX_CACHE", "0")
+
+
+def load_g10_alignments():
+    from collections import Counter, defaultdict
+
+    align = defaultdict(Counter)
+    with open(os.path.join(GOLDEN, "g10_alignments.tsv")) as fh:
+        fh.readline()
+        for line in fh:
+            strand, chrom, pos, count = line.rstrip("\n").split("\t")
+            align[strand][(chrom, int(pos))] = int(count)
+    return align
+
+
+@pytest.mark.parametrize("fixture", ["g6", "g10"])
+@pytest.mark.parametrize("name", ["default", "report_all", "strict"])
+def test_cpu_backend_writes_the_reference_bytes(tmp_path, cpu_backend, fixture, name):
+    from ribotricer_amd.detect_orfs import export_orf_coverages
+
+    params = json.load(open(os.path.join(GOLDEN, "g6_params.json")))["param_sets"][name]
+    prefix = str(tmp_path / "out")
+    merged = load_alignments() if fixture == "g6" else load_g10_alignments()
+    timings = {}
+    export_orf_coverages(os.path.join(GOLDEN, "g6_index.tsv"), merged, prefix, timings=timings, **params)
+    assert timings["backend"] == "cpu"
+    with open(prefix + "_translating_ORFs.tsv", "rb") as fh:
+        got = fh.read()
+    with open(os.path.join(GOLDEN, f"{fixture}_expected_{name}.tsv"), "rb") as fh:
+        assert got == fh.read()
+
+
+def test_cpu_backend_takes_columns_as_well(tmp_path, cpu_backend):
+    """The package's own hand-over format (alignments.MergedColumns) with rows of several read lengths on one position."""
+    from ribotricer_amd.alignments import MergedColumns
+    from ribotricer_amd.detect_orfs import export_orf_coverages
+
+    cols = MergedColumns.from_counters(load_alignments())
+    half = cols.count // 2  # every position twice: the halves add up again
+    doubled = MergedColumns(np.concatenate([cols.strand, cols.strand]), np.concatenate([cols.chrom, cols.chrom]),
+                            np.concatenate([cols.pos, cols.pos]), np.concatenate([half, cols.count - half]), cols.chroms)
+    prefix = str(tmp_path / "out")
+    export_orf_coverages(os.path.join(GOLDEN, "g6_index.tsv"), doubled, prefix, report_all=True)
+    with open(prefix + "_translating_ORFs.tsv", "rb") as a, open(os.path.join(GOLDEN, "g6_expected_report_all.tsv"), "rb") as b:
+        assert a.read() == b.read()
+
+
+def test_host_gather_equals_the_python_loop(cpu_backend):
+    """rp_gather_profiles_host against the per-nucleotide dict lookups of orf_coverage (detect_orfs.py:134-203 as
+    restated in ribotricer_amd.detect_orfs.orf_coverage), both strands, spliced ORFs."""
+    from ribotricer_amd import backend
+    from ribotricer_amd import detect_orfs as d
+    from ribotricer_amd.index import NativeIndex
+
+    path = os.path.join(GOLDEN, "g6_index.tsv")
+    merged = load_alignments()
+    counts, offsets = backend.gather_profiles_host(NativeIndex.from_file(path), merged, n_threads=3)
+    want_counts, want_offsets = d.pack_profiles(d.read_index(path), merged)
+    assert np.array_equal(offsets, want_offsets)
+    assert np.array_equal(counts, want_counts)
+
+
+def test_cpu_backend_phasescore_known_answers(cpu_backend, g1, g5, g8f):
+    from ribotricer_amd.statistics import phasescore
+
+    for v in g1:
+        phase, valid = phasescore(v["input"])
+        assert isinstance(phase, np.float64) and isinstance(valid, int)
+        want = v["phase"]
+        assert (np.isnan(phase) and want is None) or phase == np.float64(want), v
+        assert valid == v["valid"], v
+    for v in list(g5) + list(g8f):  # float profiles (metagene.py:243-244): the reference's bits
+        phase, valid = phasescore(v["input"])
+        assert phase == np.float64(v["phase"]) and valid == v["valid"], v
+
+
+def test_cpu_backend_rejects_counts_beyond_int32(cpu_backend, tmp_path):
+    from collections import Counter
+
+    from ribotricer_amd._lib import RibophaseError
+    from ribotricer_amd.detect_orfs import export_orf_coverages
+
+    merged = load_alignments()
+    strand = next(iter(merged))
+    table = Counter(merged[strand])
+    key = next(iter(table))
+    table[key] = 1 << 31
+    merged = dict(merged)
+    merged[strand] = table
+    with pytest.raises(RibophaseError) as e:
+        export_orf_coverages(os.path.join(GOLDEN, "g6_index.tsv"), merged, str(tmp_path / "x"), report_all=True)
+    assert e.value.status == -7
+
+
+def test_backend_selection(monkeypatch):
+    from ribotricer_amd import backend
+
+    monkeypatch.setenv("RIBOTRICER_AMD_BACKEND", "hip")
+    assert backend.selected() == "hip"
+    monkeypatch.setenv("RIBOTRICER_AMD_BACKEND", "cpu")
+    assert backend.selected() == "cpu"
+    monkeypatch.setenv("RIBOTRICER_AMD_BACKEND", "cuda")
+    with pytest.raises(ValueError):
+        backend.selected()
+    monkeypatch.setenv("RIBOTRICER_AMD_BACKEND", "auto")
+    import torch
+
+    assert backend.selected() == ("hip" if torch.cuda.device_count() > 0 else "cpu")
+
+
+def test_hip_backend_never_falls_back(monkeypatch, tmp_path):
+    """With the hip backend insisted on and no device around, the export fails loudly -- it does not quietly take the
+    host path."""
+    import torch
+
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    from ribotricer_amd._lib import RibophaseError
+    from ribotricer_amd.detect_orfs import export_orf_coverages
+
+    monkeypatch.setenv("RIBOTRICER_AMD_BACKEND", "hip")
+    with pytest.raises(RibophaseError):
+        export_orf_coverages(os.path.join(GOLDEN, "g6_index.tsv"), load_alignments(), str(tmp_path / "x"))
+    assert not os.path.exists(str(tmp_path / "x") + "_translating_ORFs.tsv")
+
+
+def test_cpu_backend_whole_pipeline_from_a_bam(tmp_path, cpu_backend, capsys):
+    """BASELINE configs[0] in miniature, no GPU: BAM -> columns -> metagene (rp_gather_profiles_host + rp_metagene_host)
+    -> offsets -> merge -> WIG -> TSV on a BAM holding the G7 reads.  Every output file equals the reference's, BYTE FOR
+    BYTE -- the metagene phase scores and the TSV's phase_score column included (the hip backend is held to 1e-9 /
+    1e-6 there)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    from bamwriter import write_bam
+    from test_host_frontend_cpu import g7_params, load_g7_alignments
+
+    INDEX = os.path.join(GOLDEN, "g6_index.tsv")
+
+    from ribotricer_amd.detect_orfs import detect_orfs
+
+    nested = load_g7_alignments()
+    refs = [("chrI", 400000), ("chrII", 400000), ("chrM", 400000)]
+    reads = []
+    for length in sorted(nested):
+        for strand in nested[length]:
+            for (chrom, pos), count in nested[length][strand].items():
+                for _ in range(count):  # forward protocol: '+' reads start at pos, '-' reads END at pos
+                    start0 = pos - 1 if strand == "+" else pos - length
+                    reads.append(dict(name="r", chrom=chrom, pos=start0, flag=0 if strand == "+" else 16, mapq=255, cigar=[("M", length)]))
+    lead = []  # lengths are met in the order the reference's generator met them (its dict order decides the offsets report)
+    for length in [int(k) for k in g7_params()["psite_offsets"]]:
+        k = next(i for i, r in enumerate(reads) if r["cigar"][0][1] == length)
+        lead.append(reads.pop(k))
+    bam = str(tmp_path / "g7.bam")
+    write_bam(bam, refs, lead + reads)
+    prefix = str(tmp_path / "out" / "g7")
+    params = g7_params()
+    detect_orfs(bam, INDEX, prefix, "forward", None, None, report_all=True, meta_min_reads=params["meta_min_reads"])
+    capsys.readouterr()
+    for name in ("psite_offsets.txt", "pos.wig", "neg.wig", "metagene_profiles_5p.tsv", "metagene_profiles_3p.tsv", "translating_ORFs.tsv"):
+        with open(f"{prefix}_{name}", "rb") as a, open(os.path.join(GOLDEN, f"g7_expected_{name}"), "rb") as b:
+            assert a.read() == b.read(), name
