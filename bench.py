@@ -84,6 +84,7 @@ def parse_args():
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of head / middle / tail slices (N = 1) and the concat == whole check (N > 1)")
     ap.add_argument("--no-tune-workspace", action="store_true", help="keep the record workspace where the first allocation put it (engine.tune_workspace off)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-stream many-samples section (N = 1)")
+    ap.add_argument("--no-slice-projection", action="store_true", help="skip timing rank 0's slice of the 2 / 4 / 8-GPU runs on this one GPU (N = 1)")
     ap.add_argument("--no-fused", action="store_true", help="skip the fused gather + score section (N = 1)")
     ap.add_argument("--no-fused-nested", action="store_true", help="skip the nested-index fused section (N = 1)")
     ap.add_argument("--no-fused-exons", action="store_true", help="skip the fused section on the run's own length law (N = 1; counter passes that want the nested launches alone)")
@@ -347,14 +348,21 @@ def self_launch(args) -> int:
     import subprocess
     import threading
 
+    import tempfile
+
     n = args.gpus
+    # The ranks meet through a FILE store in a directory of this launch's own (torch.distributed's file:// rendezvous):
+    # no port is picked here and handed on, so two bench runs on one box -- or anybody else's listener -- cannot take
+    # it in between.  (MASTER_ADDR / MASTER_PORT are still exported for libraries that read them; the port is a free
+    # one at this moment, nothing of ours depends on it staying free.)
+    rdzv_dir = tempfile.mkdtemp(prefix="rp_bench_rdzv_")
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     base_env = dict(os.environ)
     base_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
     base_env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                    RP_BENCH_SELF_LAUNCHED="1")
+                    RP_BENCH_SELF_LAUNCHED="1", RP_BENCH_RDZV_FILE=os.path.join(rdzv_dir, "store"))
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs = []
     for r in range(n):
@@ -398,10 +406,27 @@ def self_launch(args) -> int:
         time.sleep(0.05)
     for t in threads:
         t.join(timeout=5.0)
+    import shutil
+
+    shutil.rmtree(rdzv_dir, ignore_errors=True)
     if status[0] != 0:
         return status[0] if status[0] > 0 else 1
     bad = [s for s in status if s != 0]
     return (bad[0] if bad[0] > 0 else 1) if bad else 0
+
+
+def init_gloo(dist, rank: int, world: int):
+    """The process group proper (gloo).  Self-launched ranks (and a one-rank RP_BENCH_FORCE_DIST run) meet through a file
+    store -- no port to lose to somebody else --, ranks under a launcher through the launcher's env:// rendezvous.  A
+    rendezvous that cannot complete fails after 5 minutes, not 30."""
+    import datetime
+
+    timeout = datetime.timedelta(minutes=5)
+    path = os.environ.get("RP_BENCH_RDZV_FILE")
+    if path:
+        dist.init_process_group(backend="gloo", init_method="file://" + path, rank=rank, world_size=world, timeout=timeout)
+    else:
+        dist.init_process_group(backend="gloo", timeout=timeout)
 
 
 def launch_only(rank: int, world: int) -> None:
@@ -418,7 +443,7 @@ def launch_only(rank: int, world: int) -> None:
     args = parse_args()
     if os.environ.get("RP_BENCH_LAUNCH_ONLY_SLEEP"):  # (the launcher's clean-up, under test: ranks that are still busy when the parent is stopped)
         time.sleep(float(os.environ["RP_BENCH_LAUNCH_ONLY_SLEEP"]))
-    dist.init_process_group(backend="gloo")
+    init_gloo(dist, rank, world)
     n_set = args.orfs if args.orfs > 0 else DEFAULT_ORFS[args.cfg]
     offsets_set = offsets_from_lengths(orf_lengths(n_set, args.seed, args.cfg))
     bounds = slice_bounds(offsets_set, world)
@@ -437,6 +462,12 @@ def launch_only(rank: int, world: int) -> None:
     dist.destroy_process_group()
     if os.environ.get("RP_BENCH_LAUNCH_ONLY_FAIL_RANK") == str(rank):  # (the launcher's status relay, under test)
         sys.exit(7)
+
+
+def ctypes_stream(torch, dev):
+    import ctypes
+
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 _json_out = None
@@ -491,6 +522,7 @@ def main():
     dev = torch.device("cuda", local_dev)
     dist = None
     backend = None
+    forced_dir = None
     rccl = None  # the RCCL group (barriers around the timed region, max over ranks) when it came up
     side = None  # (objects and result hand-over use the default group: gloo)
     if world > 1 or os.environ.get("RP_BENCH_FORCE_DIST") == "1":
@@ -506,12 +538,14 @@ def main():
         # Fewer GPUs than ranks (the one-GPU test box): ranks share GPUs round-robin, two ranks on one device cannot form
         # an RCCL communicator -> gloo only (config.ranks_share_gpus); RP_BENCH_BACKEND overrides.
         want = os.environ.get("RP_BENCH_BACKEND", "nccl" if n_dev >= world else "gloo")
-        if world == 1:  # RP_BENCH_FORCE_DIST: the N-rank control flow with one rank (RCCL init / barrier / all_reduce on one GPU)
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(minutes=30))
+        if world == 1 and "RP_BENCH_RDZV_FILE" not in os.environ and "MASTER_PORT" not in os.environ:
+            # RP_BENCH_FORCE_DIST: the N-rank control flow with one rank (RCCL init / barrier / all_reduce on one GPU);
+            # a file store of its own instead of a guessed port
+            import tempfile
+
+            forced_dir = tempfile.mkdtemp(prefix="rp_bench_rdzv_")
+            os.environ["RP_BENCH_RDZV_FILE"] = os.path.join(forced_dir, "store")
+        init_gloo(dist, rank, world)
         backend = "gloo"
         if want == "nccl":
             ok, why = 1, ""
@@ -650,6 +684,61 @@ def main():
     k_index = sum(t[0] for t in timings) / len(timings)
     k_main = sum(t[1] for t in timings) / len(timings)
     k_fin = sum(t[2] for t in timings) / len(timings)
+    # The 1 -> 8 GPU curve (BASELINE configs[3]) PROJECTED from the one GPU at hand: for G in {2, 4, 8}, rank 0's
+    # nt-balanced slice of the SAME set (sharding.slice_bounds -- exactly what `--gpus G` gives rank 0: views of the
+    # resident counts / offsets, a tile plan of its own) timed with the headline protocol.  There is no collective and
+    # no shared state on the data path (detect_orfs.py:274-324: independent iterations), so G GPUs run G such steps
+    # side by side: projected_value = n_set / step_ms(G), projected_efficiency = step_ms(1) / (G * step_ms(G)).  What
+    # the projection cannot see is anything the ranks share on a real node (host launch threads, power); the driver's
+    # --gpus N runs measure that.
+    projection = None
+    if world == 1 and strong and plan is not None and not args.no_slice_projection and n_orfs >= 64:
+        from ribotricer_amd.engine import TilePlan
+
+        step1_ms = 1e3 * elapsed / max(1, args.steps)
+        rows = []
+        n_proj = max(5, min(args.steps, 50))
+        for g in (2, 4, 8):
+            b = slice_bounds(offsets_set, g)
+            hi_g = int(b[1])
+            nt_g = int(offsets_set[hi_g])
+            c_g, o_g = counts[:nt_g], offsets[: hi_g + 1]
+            resolved_g = ("tile" if nt_g >= (2 << 20) else "wave") if algo == "auto" else algo
+            plan_g = None
+            if resolved_g == "tile":
+                plan_g = TilePlan(dev, o_g, nt_g, (c_g.data_ptr() // 4) % 4, ctypes_stream(torch, dev))
+
+            def step_g():
+                return eng.score(c_g, o_g, thresholds=thresholds, algo=algo, reuse_outputs=True, plan=plan_g if plan_g is not None else "auto")
+
+            for _ in range(max(3, min(args.warmup, 10))):
+                out_g = step_g()
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n_proj):
+                out_g = step_g()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms_g = e0.elapsed_time(e1) / n_proj
+            tm_g: list = []
+            for _ in range(5):
+                eng.score(c_g, o_g, thresholds=thresholds, algo=algo, plan=plan_g if plan_g is not None else "auto", timings=tm_g)
+            km, kf = sum(t[1] for t in tm_g) / len(tm_g), sum(t[2] for t in tm_g) / len(tm_g)
+            bytes_g = 4 * nt_g + 8 * (hi_g + 1) + 24 * hi_g
+            same = all(bool(torch.equal(getattr(out_g, k_), getattr(out, k_)[:hi_g])) for k_ in ("valid", "read_count", "min_codon_cov", "status"))
+            dphase = float((out_g.phase - out.phase[:hi_g]).abs().max()) if hi_g else 0.0
+            rows.append({"gpus": g, "orfs": hi_g, "nt": nt_g, "step_ms": ms_g, "kernel_ms": km, "finish_ms": kf, "steps": n_proj,
+                         "kernel_frac": bytes_g / (km * 1e-3) / 1e9 / HBM_PEAK_GBS if km > 0 else None,
+                         "step_frac": bytes_g / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "projected_value": n_job / (ms_g * 1e-3),
+                         "projected_efficiency": step1_ms / (g * ms_g),
+                         "integers_equal_headline": same, "max_abs_dphase_vs_headline": dphase})
+            del plan_g, out_g
+        projection = {"step_ms_1gpu": step1_ms, "slices": rows,
+                      "what": "rank 0's nt-balanced slice of the same set for G = 2, 4, 8 (what `--gpus G` hands rank 0), timed on this one GPU "
+                              "with the headline protocol; projected_value = ORFs of the whole set / step_ms(G); projected_efficiency = "
+                              "step_ms(1) / (G x step_ms(G)); a projection (the ranks share nothing on the data path), not a measurement of G GPUs"}
     # A single-sample `detect-orfs` run uses its index ONCE: the plan is then part of the job.
     # Timed separately (same K-step protocol, fewer steps): the tile index, descriptors and head
     # rows rebuilt inside every step (rp_phase_score_csr_dev without a plan).
@@ -890,6 +979,8 @@ def main():
             result["value_first_allocation"] = (n_job / (first_alloc_ms * 1e-3)) if world == 1 else None
             result["first_allocation"] = {"ms_per_step": first_alloc_ms, "steps": max(3, min(args.steps, 20)),
                                           "what": "the same step before engine.tune_workspace: the record workspace where the first allocation put it (rank 0's slice)"}
+        if projection is not None:
+            result["slice_projection"] = projection
         if pipelined is not None:
             result["value_pipelined"] = n_job / (pipelined["ms_per_step"] * 1e-3)
             result["pipelined"] = pipelined
@@ -918,6 +1009,10 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        if forced_dir is not None:
+            import shutil
+
+            shutil.rmtree(forced_dir, ignore_errors=True)
 
 
 if __name__ == "__main__":

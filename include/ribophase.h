@@ -388,6 +388,10 @@ int rp_coverage_build_rows_dev(int device, const uint8_t *d_strand, const int32_
 int rp_coverage_map_bytes(int64_t dense_len, int32_t block_positions, size_t *bytes);
 int rp_coverage_map_create_dev(int device, int64_t *d_iv_start, const int32_t *d_iv_len, int64_t n_intervals, int64_t dense_len,
                                int32_t block_positions, void *d_map_mem, size_t map_bytes, void *hip_stream, int64_t *compact_len);
+/* Positions of the dense layout that lie under an exon (e.g. interval starts) -> their slots in the compact coverage, in
+ * place, through a map that rp_coverage_map_create_dev built (same dense_len and block_positions).  Asynchronous. */
+int rp_coverage_map_remap_dev(int device, int64_t *d_positions, int64_t n_positions, const void *d_map_mem, int64_t dense_len,
+                              int32_t block_positions, void *hip_stream);
 
 /*
  * The positions of a dense coverage whose count passes RP_MAX_COUNT (after a coverage build reported

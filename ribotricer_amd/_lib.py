@@ -93,6 +93,7 @@ SYMBOLS = {
                                           ctypes.POINTER(ctypes.c_int32), _vp, _i64, ctypes.c_int32]),
     "rp_coverage_map_bytes": (_int, [_i64, ctypes.c_int32, ctypes.POINTER(ctypes.c_size_t)]),
     "rp_coverage_map_create_dev": (_int, [_int, _vp, _vp, _i64, _i64, ctypes.c_int32, _vp, ctypes.c_size_t, _vp, ctypes.POINTER(_i64)]),
+    "rp_coverage_map_remap_dev": (_int, [_int, _vp, _i64, _vp, _i64, ctypes.c_int32, _vp]),
     "rp_coverage_big_positions_dev": (_int, [_int, _vp, _i64, _vp, _i64, ctypes.POINTER(_i64), _vp]),
     # host side (no GPU): TSV row rendering
     "rp_format_rows_host": (_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp,

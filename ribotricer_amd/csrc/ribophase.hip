@@ -890,6 +890,20 @@ int rp_coverage_map_create_dev(int device, int64_t *d_iv_start, const int32_t *d
     return RP_OK;
 }
 
+int rp_coverage_map_remap_dev(int device, int64_t *d_positions, int64_t n_positions, const void *d_map_mem, int64_t dense_len,
+                              int32_t block_positions, void *hip_stream)
+{
+    if (n_positions < 0 || dense_len < 0) return fail(RP_ERR_SIZE, "negative size");
+    if (!rp::map_block_ok(block_positions)) return fail(RP_ERR_ARG, "block_positions must be a power of two from 1 to 64, got %d", (int)block_positions);
+    if (n_positions == 0) return RP_OK;
+    if (!d_positions || !d_map_mem) return fail(RP_ERR_NULL, "d_positions / d_map_mem is null");
+    RP_ON_DEVICE(device);
+    hipLaunchKernelGGL(rp::k_map_remap, dim3((unsigned)((n_positions + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, d_positions,
+                       (long long)n_positions, block_map_of(d_map_mem, dense_len, rp::map_shift(block_positions)));
+    RP_HIP(hipGetLastError());
+    return RP_OK;
+}
+
 namespace {
 // err bit 0: a sum passed RP_MAX_COUNT (fine when the caller asked to be told: it finishes those ORFs in float64);
 // bit 1: negative, or past INT32_MAX -- not representable in the int32 coverage

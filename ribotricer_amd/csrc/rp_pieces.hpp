@@ -25,8 +25,9 @@ namespace rp {
 typedef unsigned long long chunk_desc_t;
 
 constexpr unsigned long long kPieceNeg = 1ull << 63;  // start word: the piece runs down the coverage array
-constexpr int kMaxChunks = 352;                    // slots of a tile's fixed-stride row (2.75 KiB per 31 KiB tile)
 constexpr int kFastSlots = 256;                    // the slots the fast path stages from: four waves x 64 lanes
+constexpr int kMaxChunks = kFastSlots;             // slots of a tile's fixed-stride row (2 KiB per 31 KiB tile; until round 5 the stride was
+                                                   // 352 slots of which 96 were never read: 0.75 KiB of plan memory per tile for nothing)
 constexpr long long kTileSlow = INT64_MIN;         // tile_lo of a tile whose chunks do not fit its row
 
 // A chunk (8 bytes): <= 64 consecutive positions of one run, inside one tile -- every field one scalar instruction
@@ -204,7 +205,7 @@ __device__ __forceinline__ bool chunk_is_wide(chunk_desc_t cd) { return ((cd >> 
 
 // One workgroup per tile: find the piece that holds the tile's first position, clip the
 // tile's pieces to [t0, t0 + TILE + HALO), number their chunks and write the row.  A tile
-// with more than kMaxChunks chunks (or pieces > 4 GiB apart) is marked kTileSlow.
+// whose chunks do not fit the row's two lane regions (or with pieces > 512 GiB apart) is marked kTileSlow.
 constexpr int kRowBlock = 256;
 
 // Pieces that CONTINUE their predecessor -- the same base and direction: consecutive profile positions read consecutive

@@ -970,9 +970,9 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
 #if RP_ROW_PREFETCH > 0 && defined(RP_ROW_PREFETCH_EARLY)
         {   // (A/B: the same prefetch issued at ENTRY, beside the tile's own row loads -- it returns with them)
             const long long bn = b + RP_ROW_PREFETCH;
-            if (wave == 0 && bn < plan.n_tiles && lane < 30) {
+            if (wave == 0 && bn < plan.n_tiles && lane < 8 + kMaxChunks / 16) {
                 const char *line = lane < 7    ? reinterpret_cast<const char *>(ws.head + bn * kHeadRow) + 128 * lane
-                                   : lane < 29 ? reinterpret_cast<const char *>(pp.rows + bn * kMaxChunks) + 128 * (lane - 7)
+                                   : lane < 7 + kMaxChunks / 16 ? reinterpret_cast<const char *>(pp.rows + bn * kMaxChunks) + 128 * (lane - 7)
                                                : reinterpret_cast<const char *>(pp.tile_lo + 2 * bn);
                 asm volatile("global_load_dword %0, %1, off" : "=v"(prefetched) : "v"(line) : "memory");
             }
@@ -994,9 +994,9 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
         // adds nothing to the wait at barrier 1.
         {
             const long long bn = b + RP_ROW_PREFETCH;
-            if (wave == 0 && bn < plan.n_tiles && lane < 30) {
+            if (wave == 0 && bn < plan.n_tiles && lane < 8 + kMaxChunks / 16) {
                 const char *line = lane < 7    ? reinterpret_cast<const char *>(ws.head + bn * kHeadRow) + 128 * lane
-                                   : lane < 29 ? reinterpret_cast<const char *>(pp.rows + bn * kMaxChunks) + 128 * (lane - 7)
+                                   : lane < 7 + kMaxChunks / 16 ? reinterpret_cast<const char *>(pp.rows + bn * kMaxChunks) + 128 * (lane - 7)
                                                : reinterpret_cast<const char *>(pp.tile_lo + 2 * bn);
                 asm volatile("global_load_dword %0, %1, off" : "=v"(prefetched) : "v"(line) : "memory");
             }

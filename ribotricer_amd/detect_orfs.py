@@ -160,7 +160,9 @@ def gather_profiles_indexed(index, merged_alignments, device=None):
     from .alignments import build_coverage_device
     from .gather import gather_profiles_device, interval_table_from_index, make_gather_plan
 
-    coverage, base = build_coverage_device(merged_alignments, index, device)
+    # (big={}: a gather has no fp32 limit -- a count beyond 2^24 - 1 is copied like any other; only callers that hand the
+    # coverage to the fp32 scorers themselves need the strict contract)
+    coverage, base = build_coverage_device(merged_alignments, index, device, big={})
     table = interval_table_from_index(index, base)
     return gather_profiles_device(coverage, table, device, plan=make_gather_plan(table, coverage.numel(), device))
 

@@ -169,21 +169,35 @@ def interval_table_from_index(index, base) -> IntervalTable:
 
 class CompactTable:
     """The interval table of an index in the coordinates of a compact coverage: the fields of :class:`IntervalTable`,
-    with ``iv_start`` fetched from the device on first use -- the one-GPU export never asks (its gather plan is built
-    from the device copy), the sharded path and the big-count fixup do (180 MB across PCIe for 22.8 M exons, 40 ms of
-    a first sample otherwise)."""
+    with ``iv_start`` made on first use -- the one-GPU export never asks (its gather plan is built from the device copy),
+    the sharded path and the big-count fixup do.  While the device copy lives (until the gather plan has digested it:
+    ``CoverageMap.release_device_intervals``) the host copy is one read-back; afterwards the dense starts go through the
+    coverage map once more (``rp_coverage_map_remap_dev``: an upload, one small kernel, a read-back) -- nothing of the
+    180 MB (22.8 M exons) stays on the device for a caller that may never come."""
 
-    def __init__(self, dense: IntervalTable, d_iv_start):
-        self._d_iv_start = d_iv_start  # (device tensor, dropped once the host copy exists)
+    def __init__(self, dense: IntervalTable, d_iv_start, remap):
+        self._d_iv_start = d_iv_start  # (device tensor, dropped once the plan is built or the host copy exists)
+        self._dense_iv_start = dense.iv_start  # (host; what the remap starts from)
+        self._remap = remap  # dense starts (host int64 array) -> compact starts (host), through the map on the device
         self._iv_start = None
         self.iv_len, self.orf_iv, self.reverse, self.offsets = dense.iv_len, dense.orf_iv, dense.reverse, dense.offsets
 
     @property
     def iv_start(self) -> np.ndarray:
         if self._iv_start is None:
-            self._iv_start = self._d_iv_start.cpu().numpy()
-            self._d_iv_start = None
+            self._iv_start = self._d_iv_start.cpu().numpy() if self._d_iv_start is not None else self._remap(self._dense_iv_start)
+            self._d_iv_start = self._dense_iv_start = self._remap = None
         return self._iv_start
+
+    def drop_device_copy(self) -> None:
+        self._d_iv_start = None
+
+
+def _alive(ref):
+    obj = ref()
+    if obj is None:
+        raise RuntimeError("the CoverageMap of this compact table is gone: ask for table.iv_start while the map is alive")
+    return obj
 
 
 COVERAGE_BLOCK = 1  # positions per block of a compact coverage (RIBOTRICER_AMD_COVERAGE_BLOCK: a power of two, 1 ... 64)
@@ -224,11 +238,25 @@ class CoverageMap:
         _lib.check(_lib.load().rp_coverage_map_create_dev(dev.index, _ptr(iv_start), _ptr(iv_len), iv_start.numel(), self.dense_len, self.block_positions,
                                                          _ptr(self._mem), self._mem.numel(), stream, ctypes.byref(compact)))
         self.compact_len = int(compact.value)
-        self.table = CompactTable(dense_table, iv_start)  # (keeps the device copy until its host copy is asked for)
+        import weakref
+
+        me = weakref.ref(self)  # (no cycle: the table must not keep the map -- and its dense_len / 4 bytes of device memory -- alive)
+        self.table = CompactTable(dense_table, iv_start, lambda dense: _alive(me).remap(dense))
         self.device_intervals = (iv_start, iv_len)  # (for the gather plan that follows; dropped by release_device_intervals)
 
     def release_device_intervals(self) -> None:
+        """The gather plan has digested the device copies of the interval table (0.3 GB for 22.8 M exons): drop them,
+        the compact starts' copy inside ``table`` included -- its host copy, if anybody asks, is re-made through the map."""
         self.device_intervals = None
+        self.table.drop_device_copy()
+
+    def remap(self, dense_positions: np.ndarray) -> np.ndarray:
+        """Dense-layout positions that lie under an exon (interval starts) -> their slots in the compact coverage."""
+        d = _as_device(np.ascontiguousarray(dense_positions, dtype=np.int64), torch.int64, self.device).clone()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(_lib.load().rp_coverage_map_remap_dev(self.device.index, _ptr(d), d.numel(), _ptr(self._mem), self.dense_len,
+                                                        self.block_positions, stream))
+        return d.cpu().numpy()
 
     @property
     def ptr(self):

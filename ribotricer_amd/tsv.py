@@ -55,17 +55,19 @@ def record_tables(records):
     return head, head_off, tail, tail_off
 
 
-_SPARE: list = []  # chunk buffers handed back by a consumer that has written them (format_rows_native(recycle=True))
+_SPARE: dict = {}  # size -> chunk buffers handed back by a consumer that has written them (format_rows_native(recycle=True))
 _SPARE_LOCK = threading.Lock()
-_SPARE_MAX = 96
+_SPARE_MAX = 96  # buffers kept, all sizes together
 
 
 def _take_buffer(cap: int) -> np.ndarray:
+    """A chunk buffer of exactly ``cap`` bytes: a spare one of that size if the pool holds one (its pages are mapped
+    already: a fresh 4 MB buffer costs a thousand page faults).  The pool is keyed by size, so callers with different
+    ``chunk_bytes`` -- or one over-long row's one-off buffer -- do not evict each other's spares."""
     with _SPARE_LOCK:
-        while _SPARE:
-            buf = _SPARE.pop()
-            if buf.size == cap:
-                return buf  # (its pages are mapped already: a fresh 4 MB buffer costs a thousand page faults)
+        spare = _SPARE.get(cap)
+        if spare:
+            return spare.pop()
     return np.empty(cap, np.uint8)
 
 
@@ -73,8 +75,8 @@ def _give_back(chunk) -> None:
     buf = getattr(chunk, "obj", None)
     if isinstance(buf, np.ndarray):
         with _SPARE_LOCK:
-            if len(_SPARE) < _SPARE_MAX:
-                _SPARE.append(buf)
+            if sum(len(v) for v in _SPARE.values()) < _SPARE_MAX:
+                _SPARE.setdefault(int(buf.size), []).append(buf)
 
 
 def _format_range(arrays, tables_c, report_all, first, last, chunk_bytes) -> list:
@@ -101,13 +103,16 @@ def _format_range(arrays, tables_c, report_all, first, last, chunk_bytes) -> lis
         )
         if rc == RP_ERR_SIZE and ln.value > cap:
             cur = nxt.value      # (skipped rows before it are done with)
-            cap = int(ln.value)  # one row longer than the chunk: give it room and retry
+            if out.size == chunk_bytes:
+                _give_back(memoryview(out))  # (untouched: back to the pool)
+            cap = int(ln.value)  # one row longer than the chunk: a buffer of its own for THIS row, and retry
             out = np.empty(cap, np.uint8)
             continue
         _lib.check(rc)
         if ln.value:
             chunks.append(memoryview(out)[: ln.value])  # (a view: it keeps its buffer alive until it is written)
             if nxt.value < last:
+                cap = chunk_bytes  # (after an over-long row: back to the normal chunk size and the pooled buffers)
                 out = _take_buffer(cap)
         cur = nxt.value
     return chunks

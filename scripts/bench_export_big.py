@@ -62,7 +62,7 @@ from ribotricer_amd.gather import interval_table_from_index, make_gather_plan  #
 from ribotricer_amd.index import NativeIndex  # noqa: E402
 
 index = NativeIndex.from_file(index_path)
-coverage, base = build_coverage_device(cols, index)
+coverage, base = build_coverage_device(cols, index, big={})
 table = interval_table_from_index(index, base)
 plan = make_gather_plan(table, coverage.numel())
 eng = get_engine("cuda:0")

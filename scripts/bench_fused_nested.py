@@ -43,7 +43,7 @@ del ex, pick, pos
 index = NativeIndex.from_file(index_path)
 os.remove(index_path)
 os.remove(prefix + "_exons.bin")
-coverage, base = build_coverage_device(cols, index)
+coverage, base = build_coverage_device(cols, index, big={})
 table = interval_table_from_index(index, base)
 plan = make_gather_plan(table, coverage.numel())
 eng = get_engine("cuda:0")

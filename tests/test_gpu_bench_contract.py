@@ -48,6 +48,15 @@ def test_bench_line_has_the_contract_fields():
     f = d["fused"]
     assert f["kernel_ms"] > 0 and 0 < f["frac"] < 1 and f["verify"]["ok"] is True and f["verify"]["orfs_checked"] >= 60000
     assert d["value_single_sample"] > 0 and d["single_sample"]["ms_per_step"] > 0  # (a 60 000-ORF set is launch-bound: no ordering claim)
+    sp = d["slice_projection"]  # rank 0's slice of the 2 / 4 / 8-GPU runs, timed on this GPU: the projected scaling curve
+    assert [row["gpus"] for row in sp["slices"]] == [2, 4, 8] and sp["step_ms_1gpu"] > 0
+    for row in sp["slices"]:
+        for key in ("orfs", "nt", "step_ms", "kernel_ms", "finish_ms", "step_frac", "projected_value", "projected_efficiency"):
+            assert row[key] is not None and row[key] > 0, (row["gpus"], key)
+        assert abs(row["projected_value"] - 60000 / (row["step_ms"] * 1e-3)) < 1e-6 * row["projected_value"]
+        assert abs(row["projected_efficiency"] - sp["step_ms_1gpu"] / (row["gpus"] * row["step_ms"])) < 1e-9
+        assert row["integers_equal_headline"] is True and row["max_abs_dphase_vs_headline"] <= 1e-6
+        assert abs(row["nt"] - d["config"]["nt_total"] / row["gpus"]) <= 0.02 * d["config"]["nt_total"]  # nt-balanced
     fn = d["fused_nested"]  # the nested-index law (transcripts on different chromosomes: pieces of a tile gigabytes apart)
     assert fn["kernel_ms"] > 0 and fn["verify"]["ok"] is True and fn["verify"]["orfs_checked"] >= 60000
     assert fn["gather_plan"]["slow_tiles"] <= 0.01 * fn["gather_plan"]["tiles"] + 1 and "nested" in fn["workload"]

@@ -146,6 +146,13 @@ def test_compact_coverage_map(block):
     slot_of_block = np.cumsum(blocks) - 1
     want_start = slot_of_block[t.iv_start // block] * block + t.iv_start % block
     assert np.array_equal(cmap.table.iv_start, want_start)
+    # a second map whose device copy of the compact starts is dropped before anybody asks for the host copy (what the
+    # export does once its gather plan is built): the host copy is re-made through the map (rp_coverage_map_remap_dev)
+    late = CoverageMap(t, dense_len, block_positions=block)
+    late.release_device_intervals()
+    assert late.table._d_iv_start is None and late.device_intervals is None
+    assert np.array_equal(late.table.iv_start, want_start) and np.array_equal(late.remap(t.iv_start[:7]), want_start[:7])
+    del late
     padded = np.zeros(blocks.size * block, np.int32)
     padded[:dense_len] = cov
     compact = padded.reshape(-1, block)[blocks].reshape(-1)  # the compact coverage as the build kernel would fill it

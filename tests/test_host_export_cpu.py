@@ -357,7 +357,33 @@ def test_recycled_chunk_buffers_carry_the_same_rows(packed):
                 assert isinstance(chunk, memoryview)
                 got.append(bytes(chunk))  # (consumed before the next one is asked for)
             assert b"".join(got) == want
-    assert len(tsv._SPARE) <= tsv._SPARE_MAX
+    assert sum(len(v) for v in tsv._SPARE.values()) <= tsv._SPARE_MAX
+
+
+def test_one_long_row_does_not_drain_the_chunk_pool(packed):
+    """An over-long row (longer than ``chunk_bytes``) gets a one-off buffer; the chunks after it go back to the normal
+    size and to the pooled buffers, and callers with other chunk sizes keep their spares (the pool is keyed by size)."""
+    from ribotricer_amd import tsv
+
+    records, counts, offsets = packed
+    res = oracle_results(counts, offsets)
+    tables = tsv.record_tables(records)
+    args = (counts, offsets, res["phase"], res["valid"], res["read_count"], res["status"], tables)
+    want = b"".join(tsv.format_rows_native(*args, True, threads=1))
+    longest = max(len(line) for line in want.split(b"\n")) + 1
+    small = max(256, longest // 3)  # several rows do not fit a chunk of this size
+    tsv._SPARE.clear()
+    for _ in range(2):
+        assert b"".join(bytes(c) for c in tsv.format_rows_native(*args, True, threads=1, chunk_bytes=1 << 16, recycle=True)) == want
+    kept = len(tsv._SPARE.get(1 << 16, []))
+    assert kept >= 1
+    got = b"".join(bytes(c) for c in tsv.format_rows_native(*args, True, threads=1, chunk_bytes=small, recycle=True))
+    assert got == want
+    assert len(tsv._SPARE.get(1 << 16, [])) == kept  # the other caller's spares are still there
+    assert set(tsv._SPARE) <= {1 << 16, small} | {k for k in tsv._SPARE if k > small}  # one-off buffers are the long rows' own sizes
+    sizes_before = {k: len(v) for k, v in tsv._SPARE.items()}
+    got = b"".join(bytes(c) for c in tsv.format_rows_native(*args, True, threads=1, chunk_bytes=small, recycle=True))
+    assert got == want and len(tsv._SPARE.get(small, [])) >= sizes_before.get(small, 0) >= 1  # normal-size chunks came from the pool again
 
 
 def test_native_index_threaded_equals_sequential(monkeypatch):
