@@ -184,6 +184,23 @@ bool known_algo(int algo) { return algo == RP_ALGO_AUTO || algo == RP_ALGO_WAVE 
 
 std::atomic<int> g_measurement_tag{0};
 
+// Workgroups of the per-ORF finish pass that `device` holds at once (occupancy x compute units), per kernel flavour.
+// A/B knob only: RP_FINISH_PERSIST=m (environment, read once) runs the pass with m x that many persistent workgroups;
+// unset / 0 = one workgroup per batch of 64 ORFs, which measured faster (rp_tile.hpp, k_orf_finish).
+template <typename Kernel>
+long long resident_blocks(Kernel kernel, int device, int block)
+{
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || per_cu <= 0 || cus <= 0) {
+        (void)hipGetLastError();
+        return 0;  // (unknown: the caller keeps the one-shot grid)
+    }
+    return (long long)per_cu * cus;
+}
+
+long long finish_grid(int device, bool fused, int tile);  // (defined behind the kernels' template instantiations below)
+
 // workgroups of the scoring launch (RP_TILES_PER_WG tiles each, rp_tile.hpp)
 inline unsigned score_grid(long long n_tiles)
 {
@@ -206,7 +223,7 @@ int launch_plan_kernels(const int64_t *d_offsets, int64_t n_orfs, const rp::Tile
     if (n_orfs > 0) {
         const int grid = (int)((n_orfs + block - 1) / block);
         RP_WITH_TILE(tile, hipLaunchKernelGGL(rp::k_tile_desc<TILE>, dim3(grid), dim3(block), 0, stream, d_offsets,
-                                              (long long)n_orfs, plan, ws.tile_first, ws.head, ws.desc));
+                                              (long long)n_orfs, plan, ws.tile_first, ws.head, ws.desc, d_err ? d_err + 1 : nullptr));
         RP_HIP(hipGetLastError());
     }
     {
@@ -228,6 +245,7 @@ struct rp_plan {
     long long n_orfs, total_nt;
     int mis;         // (counts address / 4) % 4 the plan was built for
     int tile;        // positions per tile (rp::pick_tile of the index)
+    int n_long;      // ORFs longer than rp::kLongWalk (counted up to about rp::kLongCountCap): sizes / skips the k_rewalk_long launch
     void *tables;    // device, caller-owned (inside d_plan_mem): tile index + segment descriptors
     int *err;        // device, first word of d_plan_mem
 };
@@ -252,6 +270,29 @@ constexpr size_t kPlanHeader = 128;
 rp::PiecePlan piece_plan_of(const rp_gather_plan *g)
 {
     return rp::PiecePlan{g->mem.start, g->mem.base, g->mem.orf_piece, g->mem.tile_piece0, g->mem.tile_lo, g->mem.rows, g->n_pieces, g->coverage_len};
+}
+
+std::mutex g_grid_mutex;
+long long g_finish_grid[kMaxDevices][2][2];  // [device][fused][small tile]: 0 = not asked yet, -1 = one-shot grid
+long long finish_grid(int device, bool fused, int tile)
+{
+    if (device < 0 || device >= kMaxDevices) return 0;
+    std::lock_guard<std::mutex> lock(g_grid_mutex);
+    long long &slot = g_finish_grid[device][fused ? 1 : 0][tile == rp::kTile ? 0 : 1];
+    if (slot == 0) {
+        const char *env = std::getenv("RP_FINISH_PERSIST");
+        double mult = env ? std::atof(env) : 0.0;  // (workgroups per resident slot; 0 = the one-shot grid)
+        long long r = 0;
+        if (mult > 0.0) {
+            if (fused)
+                RP_WITH_TILE(tile, r = resident_blocks(rp::k_orf_finish<TILE, rp::CoverageSource>, device, rp::kFinishBlock));
+            else
+                RP_WITH_TILE(tile, r = resident_blocks(rp::k_orf_finish<TILE, rp::CsrSource>, device, rp::kFinishBlock));
+            r = (long long)(r * mult);
+        }
+        slot = r > 0 ? r : -1;
+    }
+    return slot > 0 ? slot : 0;
 }
 
 int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, int64_t n_orfs,
@@ -344,10 +385,13 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     }
     RP_HIP(hipGetLastError());
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));
-    // 3. one thread per ORF: add its records, score, filter, store
+    // 3. one thread per ORF: add its records, score, filter, store (one one-wave workgroup per batch of 64 ORFs;
+    //    RP_FINISH_PERSIST: fewer, looping ones -- an A/B knob, rp_tile.hpp k_orf_finish)
     {
         const int block = rp::kFinishBlock;
-        const long long grid = (n_orfs + block - 1) / block;
+        long long grid = (n_orfs + block - 1) / block;
+        const long long resident = finish_grid(device, gather != nullptr, tile);
+        if (resident > 0 && grid > resident) grid = resident;
         if (gather != nullptr)
             RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_orf_finish<TILE, rp::CoverageSource>), dim3((unsigned)grid), dim3(block), 0, stream,
                                                   rp::CoverageSource{d_counts, piece_plan_of(gather)}, d_offsets, (long long)n_orfs, plan, ws, out, fp));
@@ -355,9 +399,12 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
             RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_orf_finish<TILE, rp::CsrSource>), dim3((unsigned)grid), dim3(block), 0, stream,
                                                   rp::CsrSource{d_counts}, d_offsets, (long long)n_orfs, plan, ws, out, fp));
         RP_HIP(hipGetLastError());
-        // 4. the long too-close-to-call ORFs it queued (usually none): a workgroup each
-        if (total_nt > rp::kLongWalk) {
-            const long long cap = rp::long_capacity(total_nt);
+        // 4. the long too-close-to-call ORFs it queued (usually none): a workgroup each.  A plan knows how many ORFs of
+        //    its index are that long at all: none -> no launch (an empty 512-workgroup launch is 11 us, 3 % of the step of
+        //    an eighth of the 11 M-ORF set), a few -> a grid of that many
+        long long cap = rp::long_capacity(total_nt);
+        if (plan_h != nullptr && plan_h->n_long < cap) cap = plan_h->n_long;
+        if (total_nt > rp::kLongWalk && cap > 0) {
             const dim3 lgrid((unsigned)(cap < RP_LONG_GRID ? cap : RP_LONG_GRID));
             if (gather != nullptr)
                 RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_rewalk_long<TILE, rp::CoverageSource>), lgrid, dim3(rp::kLongBlock), 0, stream,
@@ -507,9 +554,10 @@ int rp_plan_create_dev(int device, const int64_t *d_offsets, int64_t n_orfs, int
     RP_HIP(hipMemsetAsync(d_err, 0, kPlanHeader, stream));
     rc = launch_plan_kernels(d_offsets, n_orfs, plan, tile, ws, d_err, stream);
     if (rc != RP_OK) return rc;
-    int h_err = 0;
-    RP_HIP(hipMemcpyAsync(&h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    int h_head[2] = {0, 0};  // {error bits, ORFs longer than kLongWalk}
+    RP_HIP(hipMemcpyAsync(h_head, d_err, sizeof(h_head), hipMemcpyDeviceToHost, stream));
     RP_HIP(hipStreamSynchronize(stream));
+    const int h_err = h_head[0];
     if (h_err != 0) return fail(RP_ERR_OFFSETS, "offsets must start at 0, be monotone and end at total_nt");
     rp_plan *h = new (std::nothrow) rp_plan;
     if (!h) return fail(RP_ERR_SIZE, "out of memory");
@@ -518,6 +566,7 @@ int rp_plan_create_dev(int device, const int64_t *d_offsets, int64_t n_orfs, int
     h->total_nt = total_nt;
     h->mis = counts_phase;
     h->tile = tile;
+    h->n_long = h_head[1];
     h->tables = tables;
     h->err = d_err;
     *out = h;

@@ -148,6 +148,7 @@ static_assert(kTile / (3 * kRun) + kHeadSlots + 1 <= 256, "a head-row tile must 
 // single wave streams a 100 k-nt profile for a millisecond.
 constexpr long long kLongWalk = 4096;
 constexpr int kLongBlock = 1024;
+constexpr int kLongCountCap = 4096;  // k_tile_desc counts the index's ORFs beyond kLongWalk up to (about) here
 
 struct TileWorkspace {
     long long *tile_first;  // [n_tiles + 1] first ORF starting at/after each tile start
@@ -265,7 +266,7 @@ __global__ void k_tile_index(const int64_t *__restrict__ offsets, long long n_or
 template <int TILE>
 __global__ void k_tile_desc(const int64_t *__restrict__ offsets, long long n_orfs, TilePlan plan,
                             const long long *__restrict__ tile_first, seg_desc_t *__restrict__ head,
-                            seg_desc_t *__restrict__ desc)
+                            seg_desc_t *__restrict__ desc, int *__restrict__ n_long)
 {
     const long long orf = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (orf >= n_orfs) return;
@@ -273,6 +274,9 @@ __global__ void k_tile_desc(const int64_t *__restrict__ offsets, long long n_orf
     const long long end = offsets[orf + 1];
     if (end <= beg) return;  // empty profile: its slot stays a gap, k_orf_finish reads no record for it
     if (beg < 0 || end > plan.total_nt) return;  // not a CSR index (rp_plan_create_dev reports it): stay in bounds
+    // how many ORFs could ever reach k_rewalk_long (capped: all that the launcher wants to know is 0, a few, or >= its
+    // grid) -- a plan's scoring calls size that launch by it and skip it for an index without such ORFs
+    if (n_long != nullptr && end - beg > kLongWalk && *n_long < kLongCountCap) atomicAdd(n_long, 1);
     const long long b_first = (beg + plan.mis) / TILE;
     const long long b_last = (end - 1 + plan.mis) / TILE;
     for (long long b = b_first; b <= b_last; ++b) {
@@ -1278,7 +1282,16 @@ __global__ __launch_bounds__(kFinishBlock, RP_FINISH_WAVES) void k_orf_finish(So
     const int lane = threadIdx.x & (kWave - 1);
     ReplayLds &s_replay = s_replay_w[threadIdx.x / kWave];
     int *const s_stage = s_stage_w[threadIdx.x / kWave];
-    const long long orf = (long long)blockIdx.x * kFinishBlock + threadIdx.x;
+    // A wave takes the batches blockIdx.x, blockIdx.x + gridDim.x, ... of 64 ORFs.  The launcher's grid covers every batch
+    // (one pass of this loop) unless RP_FINISH_PERSIST asks for persistent waves -- an A/B knob: round 5 measured them
+    // SLOWER (0.347 vs 0.302 ms at 11 M ORFs with as many workgroups as the chip holds, 0.329 with twice, 0.303 with four
+    // times as many; fused 0.545 / 0.511 / 0.460 vs 0.450: profiles/r05_ab_finish_persist.txt).  The pass is not bound by
+    // the rate at which waves start: SQ_WAVE_CYCLES (quad-cycles) over the elapsed time puts 4 500 of the 5 120 wave slots
+    // in use, and 83 % of that wave time is the re-walks and replays of the 0.6 % too-close-to-call ORFs (~15 us of a whole
+    // wave each, 64 000 of them) -- a latency-bound tail that the one-shot grid balances perfectly (a finished wave's slot
+    // goes to the next batch) and a static assignment of batches to persistent waves does not.
+    for (long long batch0 = (long long)blockIdx.x * kFinishBlock; batch0 < n_orfs; batch0 += (long long)gridDim.x * kFinishBlock) {
+    const long long orf = batch0 + threadIdx.x;
     long long beg = 0, len = 0, count = 0;
     int min_codon = RP_MIN_CODON_COV_EMPTY;
     unsigned split = 0;
@@ -1352,6 +1365,7 @@ __global__ __launch_bounds__(kFinishBlock, RP_FINISH_WAVES) void k_orf_finish(So
         }
         finish_unsafe(source.orf(orf_s, beg_s), orf_s, len_s, count_s, min_s, split_s, lane, &s_replay, out, fp);
     }
+    }  // (the batches of this wave)
 }
 
 // ---------------------------------------------------------------------------
