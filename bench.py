@@ -98,7 +98,7 @@ def parse_args():
 def vbios_versions():
     """The GPUs' VBIOS versions as the amdgpu driver reports them (sysfs; no GPU call).  Round 4 found the boxes on which
     no workspace placement helps (kernel 2.86-3.06 ms) on 113-M355-01-1K1-020F and the ones where it does (2.6-2.7 ms) on
-    -030A (profiles/r04_box_kinds.txt): the line carries the version so that a reader can tell which kind a run met."""
+    -030A (profiles/archive/r04_box_kinds.txt): the line carries the version so that a reader can tell which kind a run met."""
     import glob
 
     seen = []
@@ -630,7 +630,10 @@ def main():
         e1.record()
         torch.cuda.synchronize(dev)
         first_alloc_ms = e0.elapsed_time(e1) / n_first
-        placement = eng.tune_workspace(counts, offsets, thresholds=thresholds)
+        # (copies=2: every candidate is a block of TWO workspaces side by side -- the second one serves the other stream
+        # of the two-stream section below, so both samples in flight write where this search found the writes cheapest)
+        two_streams = world == 1 and not args.no_pipelined
+        placement = eng.tune_workspace(counts, offsets, thresholds=thresholds, copies=2 if two_streams else 1)
         lib_tag.rp_measurement_tag(was_tag)
         if placement.get("spacers"):
             # the driver wipes the memory handed back in the background, which takes 1-4 % off the kernels meanwhile (and
@@ -757,27 +760,26 @@ def main():
         single_ms = e0.elapsed_time(e1) / n_single
         out = step()  # (the outputs checked below come from the planned path the headline times)
         torch.cuda.synchronize(dev)
-    # Many samples against one index, PIPELINED over two streams (round-3 verdict, item 4): sample k on stream k % 2,
-    # each stream with a record workspace and outputs of its own (the engine keeps both per stream), so the per-ORF
-    # finish pass of one sample -- latency-bound, 9 % of a step -- runs beside the scoring kernel of the next.  Same
-    # work per step as the headline (every sample is scored and finished, nothing is skipped); reported BESIDE
-    # `value`, never instead of it.
+    # Many samples against one index: the engine's MANY-SAMPLES MODE -- sample k on stream k % 2, each stream with a record
+    # workspace and outputs of its own, so that the per-ORF finish pass of one sample (latency-bound, 9 % of a step) runs
+    # beside the scoring kernel of the next -- WHERE THAT WINS.  Two memory-bound kernels side by side share one HBM: on
+    # some boxes the overlap gains 2-5 %, on others it loses (round 4's driver box: -9 %).  So the mode times both ways on
+    # the batch at hand, same K-step protocol, and runs the faster one; `value_pipelined` is what it then delivers, and the
+    # block says which way it went.  Both streams' workspaces come from the ONE block the headline's placement search chose
+    # (engine.tune_workspace(copies=2) / share_placed_workspace), not from searches of their own.  Same work per step as the
+    # headline (every sample is scored and finished); reported BESIDE `value`, never instead of it.
     pipelined = None
     if world == 1 and plan is not None and not args.no_pipelined and total_nt >= (64 << 20):
         lanes = [torch.cuda.Stream(device=dev) for _ in range(2)]
-        placements = []
         tag_lib = _lib.load()
         tag_was = tag_lib.rp_measurement_tag(1)  # (overlapped launches last longer: kept out of a profiler's rp::k_tile_score statistics)
+        shared = eng.share_placed_workspace(lanes)  # (0 when the search did not run: the streams then allocate their own)
         for st in lanes:
             st.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(st):
                 for _ in range(3):
                     step()
-                if not args.no_tune_workspace:  # each stream's workspace placed like the headline's
-                    placements.append(eng.tune_workspace(counts, offsets, thresholds=thresholds)["step_ms"])
         torch.cuda.synchronize(dev)
-        if placements:
-            time.sleep(1.0)
         n_pipe = max(4, args.steps // 2 * 2)
         for k in range(4):
             with torch.cuda.stream(lanes[k % 2]):
@@ -794,11 +796,26 @@ def main():
         e1.record(lanes[0])
         torch.cuda.synchronize(dev)
         wall_p = time.perf_counter() - t0p
-        ms_p = e0.elapsed_time(e1) / n_pipe
+        ms_two = e0.elapsed_time(e1) / n_pipe
         same = all(bool(torch.equal(getattr(out_p, k_), getattr(out, k_))) for k_ in ("phase", "valid", "read_count", "min_codon_cov", "status"))
-        pipelined = {"ms_per_step": ms_p, "wall_ms_per_step": 1e3 * wall_p / n_pipe, "steps": n_pipe, "streams": 2,
-                     "results_equal_headline": same, "workspace_search_step_ms": placements,
-                     "what": "sample k on stream k % 2, a record workspace and outputs per stream: finish(k) beside score(k + 1)"}
+        # ... and one stream, the same protocol, right after it (the box in the same state): the mode keeps the faster
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n_pipe):
+            step()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms_one = e0.elapsed_time(e1) / n_pipe
+        streams_chosen = 2 if ms_two < ms_one else 1
+        pipelined = {"ms_per_step": min(ms_two, ms_one), "streams": streams_chosen, "two_streams_ms_per_step": ms_two, "one_stream_ms_per_step": ms_one,
+                     "wall_ms_per_step_two_streams": 1e3 * wall_p / n_pipe, "steps": n_pipe, "results_equal_headline": same,
+                     "workspaces_from_the_headline_placement": shared,
+                     "what": "many-samples mode: sample k on stream k % 2 (a record workspace and outputs per stream: finish(k) beside "
+                             "score(k + 1)) or all on one stream, whichever the trial on this batch finds faster -- both timed with the "
+                             "same protocol back to back; `streams` says which one the mode runs"}
         tag_lib.rp_measurement_tag(tag_was)
         for st in lanes:
             eng.release_stream(st)
@@ -876,7 +893,7 @@ def main():
         # After the timed region: what does a plain read of the SAME counts buffer reach in this process, on this
         # box, right now?  (csrc/stream_probe.hip: 32 KiB pieces DMA'd into LDS by one loader wave, four workgroups
         # per CU -- the scoring kernel's skeleton and nothing else.)  The scoring kernel was seen between 2.6 and
-        # 3.1 ms on the same bytes depending on where its buffers lie (profiles/r03_clock_trace.txt); the plain
+        # 3.1 ms on the same bytes depending on where its buffers lie (profiles/archive/r03_clock_trace.txt); the plain
         # read is the yardstick that does not move.
         try:
             from ribotricer_amd._probe import stream_read_GBps
@@ -886,7 +903,7 @@ def main():
                            "what": "csrc/stream_probe.hip k_stream_read_lds over the counts buffer of this run, after the timed region"}
             # ... and where do this run's record workspace and counts lie relative to each other?  (the write stream
             # costs a read stream ~10 % or ~23 % depending on whether the two share a class of the physical address
-            # space: profiles/r03_probe_rw_regions.txt; the records are dead after the steps, the probe overwrites them)
+            # space: profiles/archive/r03_probe_rw_regions.txt; the records are dead after the steps, the probe overwrites them)
             from ribotricer_amd._probe import write_penalty
 
             ws_t = next(iter(eng._workspace.values()), None)

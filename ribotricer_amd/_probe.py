@@ -60,7 +60,7 @@ def write_penalty(read_buf, write_buf, read_bytes: int = 2 << 30, launches: int 
     planes: the scoring kernel's record stream) cost a read stream over a 2 GiB slice of `read_buf` (`where`)?  Returns
     (penalty, ms without writes, ms with writes); penalty = with / without - 1.  On MI355X the penalty is ~0.10 when
     the two buffers lie in different classes of the physical address space and ~0.23 when they share one
-    (profiles/r03_probe_rw_regions.txt) -- the spread of the scoring kernel over "placements".  Overwrites the
+    (profiles/archive/r03_probe_rw_regions.txt) -- the spread of the scoring kernel over "placements".  Overwrites the
     head of `write_buf` (a uint8 tensor of >= 3 * 384 * read_bytes / 32768 bytes)."""
     import torch
 

@@ -530,7 +530,7 @@ __device__ __forceinline__ bool near_cutoff(const FilterParams &fp, double phase
 }
 
 // Stores of data that this kernel will not touch again.  Measured on gfx950 (scripts/probe_rw.py,
-// profiles/r03_probe_rw.txt): a read stream at 7.15 TB/s that also writes 1 152 bytes per 32 KiB read
+// profiles/archive/r03_probe_rw.txt): a read stream at 7.15 TB/s that also writes 1 152 bytes per 32 KiB read
 // -- 3.5 % more bytes, the segment records of k_tile_score -- loses 17 % with ordinary stores and 9 %
 // with `nt` stores (sc1: 10 %; sc0, dword instead of dwordx4, scalar stores, atomics, one plane or
 // three, earlier in the workgroup: all 16-19 %).  Writes cost five times their share of the bytes

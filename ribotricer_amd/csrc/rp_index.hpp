@@ -418,7 +418,7 @@ inline int parse(const char *text, size_t len, bool skip_header, Index &ix, int 
 {
     if (threads <= 0) {
         // twice the usable cores: half of the parse is page faults on the output arrays, which overlap
-        // (16 usable cores: 16 threads 0.57 s, 24-32 threads 0.46-0.50 s, profiles/r03_index_parse_threads.txt)
+        // (16 usable cores: 16 threads 0.57 s, 24-32 threads 0.46-0.50 s, profiles/archive/r03_index_parse_threads.txt)
         threads = 2 * rphost::usable_threads();
         threads = threads > 32 ? 32 : threads;
     }

@@ -38,7 +38,7 @@ constexpr long long kTileSlow = INT64_MIN;         // tile_lo of a tile whose ch
 //   bits 39-45  the byte offset's high half (units of 4 GiB; round 4): the pieces of one tile may lie anywhere
 //               in a coverage of up to 512 GiB -- an index whose consecutive transcripts sit on different
 //               chromosomes (gigabytes apart in the dense coverage) sent 93 % of its tiles down the scalar slow
-//               path while the offset had 32 bits (profiles/r04_fused_nested_before.json)
+//               path while the offset had 32 bits (profiles/archive/r04_fused_nested_before.json)
 //   bits 48-63  LDS BYTE offset of its first position (the high word >> 16)
 // The first kFastSlots slots of a row are what the fast path stages from, thread (wave w, lane i) holding slot 4 i + w:
 // the FORWARD chunks fill them from slot 0 upwards, the '-' strand chunks from slot kFastSlots - 1 downwards, so that
@@ -168,7 +168,7 @@ constexpr long long kMaxTileSpan = (1ll << 37) - 256;  // positions between a ti
 // Where a run is cut into chunks: at multiples of 64 ELEMENTS OF THE COVERAGE (256-byte lines of the source: the
 // array is allocated on such a boundary), not at multiples of 64 positions of the run -- a chunk then asks the L1 for
 // two whole cache lines instead of three partial ones, and no line is asked for by two chunks of one run (the fused
-// kernel sent 1.8x the plain kernel's read requests to the L2: profiles/r04_fused_ta_tcp_counters.txt).  The price is
+// kernel sent 1.8x the plain kernel's read requests to the L2: profiles/archive/r04_fused_ta_tcp_counters.txt).  The price is
 // the run's first chunk: `head` positions up to the first boundary (0: the run starts on one).
 #ifndef RP_CHUNK_ALIGN
 #define RP_CHUNK_ALIGN 1
@@ -218,7 +218,7 @@ constexpr int kRowBlock = 256;
 // source and an LDS address that are only 4-byte aligned, scripts/probes/dma16_probe.hip -- with a second row region and
 // a second issue loop: a fifth fewer requests, bit-identical results, and the fused kernel 10 % SLOWER on both bench
 // layouts, whether the quad part started with the run, at a 16-byte aligned source or at a 16-byte aligned LDS address
-// (profiles/r04_ab_quad_chunks.txt).  Source and destination alignments differ piece by piece, so one of the two is
+// (profiles/archive/r04_ab_quad_chunks.txt).  Source and destination alignments differ piece by piece, so one of the two is
 // always off; the dword chunks stay.)
 __device__ __forceinline__ Clipped merge_runs(Clipped c, long long base, long long *s_base, int *s_n, int *s_cont, int t)
 {
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kRowBlock) void k_chunk_rows(PiecePlanMem plan, lon
 // 64-bit scalar add of the chunk's offset to the tile's base, and one global_load_lds whose vector operand is
 // loop-invariant: lane * 4 going up, (63 - lane) * 4 for a '-' strand chunk.  Two vector instructions per chunk, where
 // rounds 2-4 spent four (the lane's offset computed per step): the scorer runs at 80 % VALU occupancy and the fused
-// kernel at 87 %, and four MORE per step cost it 9 % (profiles/r04_ab_scalar_issue.txt; issuing through the scalar unit
+// kernel at 87 %, and four MORE per step cost it 9 % (profiles/archive/r04_ab_scalar_issue.txt; issuing through the scalar unit
 // alone -- descriptors by s_load_dwordx16 -- lost what it gained to the scalar loads' latency, which cannot be overlapped
 // beyond one group: scalar loads return out of order, the only wait is for all of them).  (A scalar loop over pieces,
 // with its decode and branch chain, was measured at ~1 000 cycles per piece next to three other workgroups' lane runs.)

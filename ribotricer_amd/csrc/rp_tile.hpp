@@ -45,7 +45,7 @@ namespace rp {
 constexpr int kTileBlock = 256;
 #ifndef RP_ROW_PREFETCH
 #define RP_ROW_PREFETCH 0  // fused kernel: prefetch the plan rows of tile b + this many into L2 (a multiple of 8).  A/B knob, OFF: measured
-                          // 2-3 % SLOWER at 512 / 1024 / 2048 on both layouts (profiles/r04_ab_fused_row_prefetch.txt)
+                          // 2-3 % SLOWER at 512 / 1024 / 2048 on both layouts (profiles/archive/r04_ab_fused_row_prefetch.txt)
 #endif
 #ifndef RP_LOADERS
 #define RP_LOADERS 1
@@ -99,7 +99,7 @@ struct TilePlan {
 // (Finishing the ORFs that lie inside one tile in the scoring kernel itself -- no record, no
 // round trip -- was built and measured in round 3: the float64 chain at the end of every
 // workgroup costs the scoring kernel +12 %, three times what the round trip costs;
-// profiles/r03_ab_inkernel_finish.txt.)
+// profiles/archive/r03_ab_inkernel_finish.txt.)
 constexpr size_t kRecordBytes = 48;
 
 // position -> tile for x >= 0 without a 64-bit division (TILE = 2^k * m, m odd and small): the
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kHeadBlock) void k_tile_head(long long n_tiles, con
 // What one 16-lane row contributes to one segment (48 bytes): the six float sums, and -- since
 // round 3 -- the integer results as well, carried through the same segmented DPP scan instead of
 // per-segment LDS atomics (8-16 lanes on one address: a kernel without them ran 6.7 % faster,
-// profiles/r03_ab_no_int_atomics_upper_bound.txt):
+// profiles/archive/r03_ab_no_int_atomics_upper_bound.txt):
 //   S[f]      the census sum of reading frame f, 2^13 (E + 256 Z) + eps (see kDust*): E, Z <= 240 per row
 //   clo, chi  the read count as two floats (low 16 bits, high bits): row sums < 2^24, exact
 //   mn        the minimum codon coverage
@@ -1073,7 +1073,7 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
     // ---- many short ORFs: > kHeadSlots segments, 64 slots at a time ------------------------------
     // (128 slots a round -- two table sets, waves {0,1} and {2,3} each walking 64 slots side by side --
     // was built and measured in round 3: no gain on all-60-nt tiles, the longer runs eat the saved
-    // round, and the extra table indirection cost the common path 6 %: profiles/r03_ab_dual_rounds.txt)
+    // round, and the extra table indirection cost the common path 6 %: profiles/archive/r03_ab_dual_rounds.txt)
     // Same scheme, minus the head row and the lane map: every wave reads the chunk's descriptors
     // from the per-segment array (slot L of chunk c = ORF a0 - 1 + 64 c + L) and finds its
     // lanes' segments through 64 private words of LDS (marks at the segments' first lanes, then
@@ -1199,11 +1199,11 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score_probe(c
 // 1 M -- and rebuilt the queue with 64 lists in 64 cache lines and a wave-per-ORF drain kernel behind the pass: 0.297 /
 // 0.074 ms, slower again.  It is not the imbalance: 0.6 % of the ORFs are exact frame ties, each replay is a serial
 // float64 fold, and spread over the 172 000 waves of this pass that work hides better than in a kernel of its own;
-// profiles/r04_ab_finish_rewalk.txt, r04_ab_finish_rewalk_queue.patch.)
+// profiles/archive/r04_ab_finish_rewalk.txt, r04_ab_finish_rewalk_queue.patch.)
 // (Measured alternatives, both slower: a global queue filled with one atomicAdd per wave and
 // drained by a wave-per-ORF kernel -- 40 000 atomics on one word cost 0.46 ms at 11 M ORFs,
-// profiles/r03_ab_finish_split.txt; finishing one-tile ORFs inside the scoring kernel -- +12 %
-// on that kernel, profiles/r03_ab_inkernel_finish.txt.)
+// profiles/archive/r03_ab_finish_split.txt; finishing one-tile ORFs inside the scoring kernel -- +12 %
+// on that kernel, profiles/archive/r03_ab_inkernel_finish.txt.)
 // The fused path (CoverageSource) first copies the ORF's profile out of the coverage into LDS,
 // piece by piece and coalesced ('-' strand pieces backwards): walk and replay then read plain
 // LDS instead of finding the piece of every position they touch.
@@ -1216,7 +1216,7 @@ static_assert(kFinishBlock % kWave == 0 && kFinishBlock <= 1024, "whole waves");
 #ifndef RP_STAGE_NT
 #define RP_STAGE_NT 1016
 #endif
-constexpr int kStageNt = RP_STAGE_NT;       // fused path: profiles up to this long are copied to LDS first (4 KB per wave: with 8 KB the pass itself loses occupancy, profiles/r03_ab_stage_nt.txt)
+constexpr int kStageNt = RP_STAGE_NT;       // fused path: profiles up to this long are copied to LDS first (4 KB per wave: with 8 KB the pass itself loses occupancy, profiles/archive/r03_ab_stage_nt.txt)
 
 // copy the profile of ORF `orf` out of the coverage into `stage`, piece by piece, coalesced; the
 // piece descriptors of up to 63 pieces are fetched lane-parallel first (one round trip, not one

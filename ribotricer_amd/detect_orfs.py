@@ -541,12 +541,12 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
         # workspace where its writes cost the coverage reads least (engine.tune_workspace; nothing but ONE workspace stays
         # allocated).  Off by default because it does not pay here: a human-sized dense coverage (25-85 GB) spans every
         # class of physical memory, so the candidates differ by 2-3 % of a 3 ms kernel (0.1 ms per sample), while the
-        # search costs 0.07 s -- 0.56 s on boxes whose driver takes 20 ms per GiB allocated (profiles/r04_placement_check.txt,
+        # search costs 0.07 s -- 0.56 s on boxes whose driver takes 20 ms per GiB allocated (profiles/archive/r04_placement_check.txt,
         # r04_export_e2e_11M_selected_gather.json).  The CSR path with a 16 GB counts array is where it gains 14 %:
         # bench.py runs it there.
         extras["workspace_placement"] = get_engine(device).tune_workspace(
             coverage, thresholds=make_filter(phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio,
-                                             min_density_over_orf), gather_plan=plan, tries=3, spread=0.03)  # (a coverage far larger than a memory class: little to find, profiles/r04_placement_check.txt)
+                                             min_density_over_orf), gather_plan=plan, tries=3, spread=0.03)  # (a coverage far larger than a memory class: little to find, profiles/archive/r04_placement_check.txt)
         if timings is not None:
             timings["workspace_placement_report"] = extras["workspace_placement"]
         t = lap("workspace_placement", t)

@@ -193,6 +193,7 @@ class PhaseScoreEngine:
         self._workspace: dict = {}  # stream handle -> uint8 tensor
         self._out: dict = {}  # stream handle -> PhaseScores
         self._plans: list = []  # most recently used last
+        self._placed_blocks: dict = {}  # stream handle -> the workspaces of the block tune_workspace(copies=k) placed for it
         self._lock = threading.Lock()
 
     # -- buffers -----------------------------------------------------------------
@@ -207,14 +208,14 @@ class PhaseScoreEngine:
 
     def tune_workspace(self, counts, offsets=None, thresholds: Optional[FilterParams] = None, tries: int = 6,
                        spacer_gib: float = 8.0, launches: int = 4, spread: float = 0.05, gather_plan=None,
-                       release: bool = True) -> dict:
+                       release: bool = True, copies: int = 1) -> dict:
         """Once per engine and index: place the current stream's record workspace where its writes do not share a
         class of physical memory with the counts they ride beside -- and hold nothing else afterwards.
 
         On MI355X a write stream costs a read stream ~10 % when the two buffers lie in different classes of the
         physical address space (runs of 16-32 GiB) and ~23 % when they share one; the tile kernel writes its
         segment records while it streams the counts and takes 2.6 or 3.0 ms per 4 G nt accordingly (DESIGN.md
-        section 4, profiles/r03_probe_rw_regions.txt).  HIP has no placement hint and a fresh allocation usually
+        section 4, profiles/archive/r03_probe_rw_regions.txt).  HIP has no placement hint and a fresh allocation usually
         lands next to the previous one, so candidates are made one after the other -- each exactly the size the
         batch needs, each behind a SPACER of ``spacer_gib`` that walks the next one through physical memory -- the
         scoring step of THIS batch is timed on each, and the search stops once a new candidate beats the slowest
@@ -225,7 +226,11 @@ class PhaseScoreEngine:
         allocated is a candidate); ~0.1 s.  The drop-in export runs it once per cached index
         (``detect_orfs.score_index``), ``bench.py`` once before its timed steps.
         With ``gather_plan`` the fused path is tuned instead: ``counts`` is then the dense coverage
-        (:meth:`score_coverage`).  Returns what it measured."""
+        (:meth:`score_coverage`).  ``copies`` > 1: every candidate is one block of that many workspaces side by side
+        (the step is timed on the first); the others of the chosen block are kept for further streams of the same
+        batch (:meth:`share_placed_workspace`: two samples in flight on two streams write their records into the
+        SAME class of physical memory the search found, instead of each stream searching on its own and one of them
+        ending up where the first allocation put it).  Returns what it measured."""
         dev = self.device
         if gather_plan is None:
             counts = _as_device(counts, torch.int32, dev)
@@ -241,6 +246,9 @@ class PhaseScoreEngine:
                 self.score_coverage(counts, gather_plan, thresholds=thresholds, reuse_outputs=True, timings=t)
         stream_key = int(torch.cuda.current_stream(dev).cuda_stream)
         need = _lib.workspace_bytes(n, total_nt, _lib.RP_ALGO_TILE)
+        copies = max(1, int(copies))
+        copy_stride = (need + 4095) & ~4095  # (each copy starts on a 4 KiB boundary of the block)
+        block_bytes = need if copies == 1 else copy_stride * copies
         what = ("engine.tune_workspace: candidate record workspaces of the batch's own size, each behind a spacer allocation, "
                 "the scoring step timed on each; spacers and rejected candidates freed")
         if n <= 0 or need == 0:
@@ -266,6 +274,9 @@ class PhaseScoreEngine:
             first = self._workspace.get(stream_key)
             if first is None:
                 first = self._get_workspace(need, stream_key)
+            if copies > 1:  # (the first candidate too must be a block of `copies`: allocated now, right where a fresh allocation lands)
+                first = torch.empty(block_bytes, dtype=torch.uint8, device=dev)
+                self._workspace[stream_key] = first[:need]
             candidates.append(first)
             times.append(step_ms())
             if release:  # no cached block may serve a candidate: each must be a fresh allocation behind its spacer
@@ -277,11 +288,11 @@ class PhaseScoreEngine:
                     # and the third one may start 40 GiB further on)
                     stride = spacer_gib * (2.0 if len(candidates) > 3 else 1.0)
                     spacers.append(torch.empty(int(stride * (1 << 30)), dtype=torch.uint8, device=dev))
-                    cand = torch.empty(need, dtype=torch.uint8, device=dev)
+                    cand = torch.empty(block_bytes, dtype=torch.uint8, device=dev)
                 except torch.cuda.OutOfMemoryError:
                     oom = True
                     break
-                self._workspace[stream_key] = cand
+                self._workspace[stream_key] = cand[:need] if copies > 1 else cand
                 candidates.append(cand)
                 times.append(step_ms())
         finally:
@@ -292,14 +303,37 @@ class PhaseScoreEngine:
             if times and times[best] > 0.99 * times[0]:
                 best = 0  # nothing to gain on this box: stay where the first allocation put it (no move for noise)
             if candidates:  # (an exception before the first timing leaves the workspace as it was)
-                self._workspace[stream_key] = candidates[best]
+                chosen = candidates[best]
+                if copies > 1 and chosen.numel() >= block_bytes:
+                    self._workspace[stream_key] = chosen[:need]
+                    self._placed_blocks[stream_key] = [chosen[k * copy_stride : k * copy_stride + need] for k in range(copies)]
+                else:
+                    self._workspace[stream_key] = chosen
+                    self._placed_blocks.pop(stream_key, None)
+                del chosen
             n_spacers = len(spacers)
             del spacers, candidates, first
             if release:
                 torch.cuda.empty_cache()
         return {"step_ms": [round(t, 4) for t in times], "chosen": best, "spacer_gib": spacer_gib, "spacers": n_spacers,
-                "workspace_bytes": need, "out_of_memory": oom, "released_to_driver": bool(release),
+                "workspace_bytes": need, "copies": copies, "out_of_memory": oom, "released_to_driver": bool(release),
                 "reserved_bytes_after": int(torch.cuda.memory_reserved(dev)), "what": what}
+
+    def share_placed_workspace(self, streams, source_stream=None) -> int:
+        """Give ``streams[k]`` the k-th workspace of the block that ``tune_workspace(copies=...)`` placed for
+        ``source_stream`` (default: the current stream; its own workspace is copy 0).  Samples in flight on several
+        streams then all write their records where the search found the write stream cheapest.  Returns how many
+        streams were served (0: no such block -- the streams allocate their own on first use)."""
+        src = int((source_stream if source_stream is not None else torch.cuda.current_stream(self.device)).cuda_stream)
+        block = self._placed_blocks.get(src)
+        if not block:
+            return 0
+        served = 0
+        for k, st in enumerate(streams):
+            if k < len(block):
+                self._workspace[int(st.cuda_stream)] = block[k]
+                served += 1
+        return served
 
     def _get_outputs(self, n: int, with_status: bool, stream_key: int) -> PhaseScores:
         o = self._out.get(stream_key)
@@ -517,6 +551,7 @@ class PhaseScoreEngine:
         key = int(stream.cuda_stream)
         self._workspace.pop(key, None)
         self._out.pop(key, None)
+        self._placed_blocks.pop(key, None)
 
 
 def status_host(thresholds: FilterParams, phase, valid, read_count, min_codon_cov, lengths) -> np.ndarray:

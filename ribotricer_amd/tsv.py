@@ -231,7 +231,7 @@ def write_rows_native(
     ``_OrderedOffsets``) through a shared MAPPING of the file, so neither the rendering nor the copy into the page cache
     is serial and no intermediate ``bytes`` object is made: a human-sized `report_all` export writes 12.8 GB
     (detect_orfs.py:301-324 writes them row by row).  (``pwrite`` from many threads was measured first: buffered writes
-    to one file serialise on the inode lock -- 5.2 s against 2.5 s for a single writer, profiles/r04_export_e2e_11M_pwrite.json.)
+    to one file serialise on the inode lock -- 5.2 s against 2.5 s for a single writer, profiles/archive/r04_export_e2e_11M_pwrite.json.)
     The file is extended to an upper bound of the text first (sparse) and cut to the exact end afterwards."""
     counts = np.ascontiguousarray(counts, dtype=np.int32)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The bench's fused sections over compact coverages of 64-, 8- and 1-position blocks (and the dense layout), alternating,
-# one box: kernel ms, fraction of peak, coverage positions, chunks per tile.  -> profiles/r04_ab_coverage_block.txt
+# one box: kernel ms, fraction of peak, coverage positions, chunks per tile.  -> profiles/archive/r04_ab_coverage_block.txt
 for rep in 1 2; do
   for flag in "--coverage-block 64" "--coverage-block 1" "--coverage-block 8" "--dense-coverage"; do
     timeout 400 python bench.py --cpu-sample 0 --no-pipelined $flag 2>/dev/null | python -c "

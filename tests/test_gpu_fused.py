@@ -310,7 +310,7 @@ def test_fused_score_equals_gather_then_score(case, lam):
 def test_pieces_of_one_tile_gigabytes_apart():
     """Consecutive ORFs of an index on different chromosomes: the pieces of ONE tile lie gigabytes apart in the
     dense coverage (12.9 GB here, three islands).  Until round 4 a chunk's byte offset had 32 bits and such tiles
-    took the scalar slow path (93 % of the tiles of the 11 M-ORF nested index: profiles/r04_fused_nested_before.json);
+    took the scalar slow path (93 % of the tiles of the 11 M-ORF nested index: profiles/archive/r04_fused_nested_before.json);
     now the offset carries 7 more bits.  Tile gather == per-ORF gather (a code path of its own), fused == gather +
     score bit for bit, and the oracle agrees."""
     import torch
