@@ -242,7 +242,7 @@ def upload_columns(merged, device=None) -> UploadedColumns:
                            to_dev(cols.count, np.int64), list(cols.chroms), dev)
 
 
-def build_coverage_device(merged, index, device=None, big=None, cmap=None):
+def build_coverage_device(merged, index, device=None, big=None, cmap=None, out=None):
     """Dense P-site coverage of every (strand, chrom) group of ``index`` (a ``NativeIndex``) in
     HBM: ``(coverage int32 device tensor, base)`` with ``base[(strand, chrom)] = (index of position
     lo, lo)`` -- what ``gather.interval_table_from_index`` takes.  ``merged``: :class:`MergedColumns`
@@ -259,7 +259,10 @@ def build_coverage_device(merged, index, device=None, big=None, cmap=None):
 
     ``cmap`` (``gather.CoverageMap`` of this index): the COMPACT coverage -- only the blocks (positions, by default) under an exon
     interval have a slot (``cmap.compact_len`` positions instead of the dense layout's; ``cmap.table`` is the interval
-    table that goes with it); rows under no exon are dropped on the device, as the reference never looks them up."""
+    table that goes with it); rows under no exon are dropped on the device, as the reference never looks them up.
+
+    ``out``: an int32 device tensor of at least the coverage's length to build into (zeroed here) instead of a fresh
+    allocation -- a caller that scores many samples against one index keeps one buffer (``shards.IndexShards``)."""
     import torch
 
     from .engine import _ptr, get_engine
@@ -274,7 +277,14 @@ def build_coverage_device(merged, index, device=None, big=None, cmap=None):
     keys = index.group_keys
     if cmap is not None and cmap.dense_len != total:
         raise ValueError(f"the coverage map was built for a dense layout of {cmap.dense_len} positions, this index spans {total}")
-    coverage = torch.zeros(total if cmap is None else cmap.compact_len, dtype=torch.int32, device=dev)
+    n_cov = total if cmap is None else cmap.compact_len
+    if out is not None:
+        if out.dtype != torch.int32 or out.device != dev or out.numel() < n_cov:
+            raise ValueError("build_coverage_device(out=...): an int32 tensor of the coverage's length on the build's device is needed")
+        coverage = out[:n_cov] if out.numel() > n_cov and n_cov > 0 else out
+        coverage.zero_()
+    else:
+        coverage = torch.zeros(n_cov, dtype=torch.int32, device=dev)
     if big is not None:
         big["positions"] = np.zeros(0, np.int64)
     if int(cols.pos.numel() if up is not None else cols.pos.size) == 0 or total == 0:

@@ -309,9 +309,15 @@ def export_orf_coverages(
 
     from .alignments import UploadedColumns, upload_columns
 
+    sharded = devices is not None and len(devices) > 1
     with ThreadPoolExecutor(max_workers=1) as side:
         uploaded = None
-        if not isinstance(merged_alignments, UploadedColumns):
+        if sharded:  # every distinct device takes the columns up itself (shards.columns_on_devices), all beside the parse
+            from .shards import ColumnsOnDevices, columns_on_devices
+
+            if not isinstance(merged_alignments, (UploadedColumns, ColumnsOnDevices)):
+                uploaded = side.submit(columns_on_devices, merged_alignments, devices)
+        elif not isinstance(merged_alignments, UploadedColumns):
             uploaded = side.submit(upload_columns, merged_alignments, None if not devices else f"cuda:{int(devices[0])}")
         index = _index_of(ribotricer_index)  # parsed once per file: detect-orfs scores one index against many samples
         if timings is not None:
@@ -338,17 +344,26 @@ def export_orf_coverages(
         import os
 
         mapped = os.environ.get("RIBOTRICER_AMD_TSV_WRITER", TSV_WRITER) == "mapped"
-        for a, b, part in _profile_slices(counts, offsets):
-            sliced = (tables[0], tables[1][a : b + 1], tables[2], tables[3][a : b + 1])
-            args = (part, offsets[a : b + 1] - offsets[a], res["phase"][a:b], res["valid"][a:b], res["read_count"][a:b],
-                    res["status"][a:b], sliced, report_all)
-            if mapped:
-                at += tsv.write_rows_native(output.fileno(), at, *args)
-            else:  # render threads hand their chunks, in order, to this one writer
-                for chunk in tsv.format_rows_native(*args, recycle=True):  # (written before the next one is asked for)
-                    output.write(chunk)
+        # (several devices: one part per slice of the index, each on the device that gathered it -- shards.IndexShards)
+        parts = counts if isinstance(counts, ProfileParts) else ProfileParts([(counts, offsets, 0)])
+        for part_counts, part_offsets, first in parts:
+            for a, b, part in _profile_slices(part_counts, part_offsets):
+                lo, hi = first + a, first + b
+                sliced = (tables[0], tables[1][lo : hi + 1], tables[2], tables[3][lo : hi + 1])
+                args = (part, part_offsets[a : b + 1] - part_offsets[a], res["phase"][lo:hi], res["valid"][lo:hi], res["read_count"][lo:hi],
+                        res["status"][lo:hi], sliced, report_all)
+                if mapped:
+                    at += tsv.write_rows_native(output.fileno(), at, *args)
+                else:  # render threads hand their chunks, in order, to this one writer
+                    for chunk in tsv.format_rows_native(*args, recycle=True):  # (written before the next one is asked for)
+                        output.write(chunk)
     if timings is not None:
         timings["profiles_d2h_tsv_render_write"] = time.perf_counter() - t0
+
+
+class ProfileParts(list):
+    """The profiles the TSV prints as ``(counts, offsets of the part's ORFs, first ORF)`` triples in index order -- one per
+    slice of a sharded export, each ``counts`` on the device that gathered it (``score_index`` with several devices)."""
 
 
 TSV_WRITER = "stream"  # "mapped": tsv.write_rows_native (parallel copies into a mapping of the file); RIBOTRICER_AMD_TSV_WRITER overrides
@@ -504,6 +519,8 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     never written to HBM -- and only the translating ORFs' profiles are gathered afterwards;
     ``offsets`` then gives every other ORF an empty range.  With several ``devices`` both modes
     shard the ORFs (``engine.score_sharded`` / ``engine.score_coverage_sharded``)."""
+    import os
+
     import numpy as np
     import torch
 
@@ -525,6 +542,43 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     from .gather import coverage_layout
 
     base0, total0 = coverage_layout(index.extents)
+    if devices is not None and len(devices) > 1 and os.environ.get("RIBOTRICER_AMD_SHARD_ON_FIRST_DEVICE", "0") != "1":
+        # several devices: every device builds ITS slice's compact coverage from the sample's columns and does for the slice
+        # what the code below does for the whole index (shards.IndexShards); nothing is built on devices[0] and shipped
+        from ._lib import ERR_INTERVALS, RibophaseError
+        from .shards import IndexShards
+
+        cache = index.__dict__.setdefault("_shard_cache", {})
+        key = (tuple(str(d) for d in devices), int(total0))
+        try:
+            if key not in cache:
+                for old in cache.values():
+                    old.release()
+                cache.clear()
+                cache[key] = IndexShards(index, interval_table_from_index(index, base0), total0, devices)
+            t = lap("interval_table_slices", t)
+            thresholds = make_filter(phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio, min_density_over_orf)
+            res, parts = cache[key].score(merged_alignments, thresholds, report_all, timings=timings, reuse_result_buffers=reuse_result_buffers)
+            lap("sharded_build_score_gather", t)
+            if profiles_on_device:
+                return ProfileParts(parts), None, res
+            # (host arrays wanted: the parts are copied back and joined; they cover the index's ORFs in order)
+            offsets = np.zeros(index.n_orfs + 1, np.int64)
+            chunks, base = [], 0
+            for c, off_k, first in parts:
+                offsets[first : first + off_k.size] = off_k + base
+                base += int(off_k[-1])
+                chunks.append(c.cpu().numpy())
+            counts = np.concatenate(chunks) if chunks else np.zeros(0, np.int32)
+            return counts, offsets, res
+        except RibophaseError as e:  # (a table that cannot be mapped / planned: the per-ORF kernels below cope)
+            if e.status != ERR_INTERVALS:
+                raise
+            cache.pop(key, None)
+    from .shards import ColumnsOnDevices
+
+    if isinstance(merged_alignments, ColumnsOnDevices):  # (the whole-coverage-on-one-device flow below: that device's copy)
+        merged_alignments = merged_alignments[get_engine(device).device]
     # everything that depends on the index alone first (kept on the cached index: table, coverage map, plans), then
     # this sample's coverage -- compact: only the blocks under an exon have a slot (gather.CoverageMap)
     table, plan, extras = _table_and_plan(index, base0, total0, device)

@@ -239,10 +239,17 @@ def test_export_sharded_over_two_slices_equals_single(tmp_path):
     export_orf_coverages(index, load_alignments(), str(tmp_path / "d3b"), devices=[0, 0, 0])
     assert open(str(tmp_path / "d3b_translating_ORFs.tsv")).read() == open(str(tmp_path / "d3_translating_ORFs.tsv")).read()
     cached = next(reversed(d._INDEX_CACHE.values()))
-    (table, plan, extras), = cached.__dict__["_layout_cache"].values()
-    cov_shards = extras[("coverage", (0, 0, 0))]
-    assert cov_shards.plans_built == 3  # two samples, one build per slice
-    assert extras[("csr", (0, 0))].plans_built <= 2 and ("csr", (0, 0, 0)) in extras
+    (shards,) = cached.__dict__["_shard_cache"].values()  # (shards.IndexShards: every slice builds its own map, plans, coverage buffer)
+    assert len(shards.devices) == 3 and shards.plans_built == 3  # three samples over these devices, one build per slice
+    # the round-3/4 flow (whole coverage on devices[0], windows shipped out) is still there behind a switch, same bytes
+    os.environ["RIBOTRICER_AMD_SHARD_ON_FIRST_DEVICE"] = "1"
+    try:
+        export_orf_coverages(index, load_alignments(), str(tmp_path / "old3"), devices=[0, 0, 0])
+        export_orf_coverages(index, load_alignments(), str(tmp_path / "old2"), report_all=True, devices=[0, 0])
+    finally:
+        del os.environ["RIBOTRICER_AMD_SHARD_ON_FIRST_DEVICE"]
+    assert open(str(tmp_path / "old3_translating_ORFs.tsv")).read() == open(str(tmp_path / "d3_translating_ORFs.tsv")).read()
+    assert open(str(tmp_path / "old2_translating_ORFs.tsv")).read() == one
 
 
 def test_index_is_parsed_once_per_file_and_reparsed_when_it_changes(tmp_path):
