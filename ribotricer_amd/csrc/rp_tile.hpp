@@ -101,6 +101,26 @@ struct TilePlan {
 // workgroup costs the scoring kernel +12 %, three times what the round trip costs;
 // profiles/archive/r03_ab_inkernel_finish.txt.)
 constexpr size_t kRecordBytes = 48;
+// Round 5, RP_NARROW_RECORDS=1: a segment that is a WHOLE ORF (the ORF lies inside one tile: 95 % of them; descriptor bit
+// `whole`) leaves a 32-byte record in planes 0 and 1 only -- not its raw sums but what the finish pass would make of them first:
+//   plane 0  score_0  score_2  N_0 | N_2 << 16   extra_0      score_f = (P^2 + PQ + Q^2) / (N M) computed by the record stage in
+//   plane 1  score_1  extra_2  N_1               extra_1      float64 from the UNROUNDED float64 sums and stored as fp32 (one
+//                                                             rounding, 6e-8; 0 for N = 0, NaN for M = 0 < N); extras as above
+// Wave 2 hands its three words (score_2, N_2, extra_2) to waves 0 / 1 through 192 dwords of LDS and one workgroup barrier
+// and stores nothing for such a segment.  Why: a byte written next to the read stream costs about five read, and on the
+// boxes where no workspace placement helps the kernel ran 2-7 % faster with two planes stored instead of three (timing
+// experiments, profiles/r05_ab_record_bytes.txt; 16 bytes buy nothing more).  A lossless 32-byte record of the raw sums
+// does not exist (six fp32 sums 24 B + six 12-bit census counts 9 B + read count and minimum 8 B), and segments of ORFs
+// that span tiles must add their P and Q up in k_orf_finish: they keep the three-plane record.  k_orf_finish tells the
+// two kinds apart by the ORF's geometry (first tile == last tile), exactly the test k_tile_desc makes.
+// BUILT TO PARITY (143 GPU tests green) AND NOT KEPT: on three boxes the real thing is 2-7 % SLOWER than the 48-byte records
+// (kernel 2.90-3.11 vs 2.70-3.03 ms median over nine placements, finish 0.325 vs 0.303 ms: the narrow / wide branch makes
+// nearly every wave of the finish pass run both paths), and even its idealised forms -- fp32 scoring, no store at all
+// for the split segments (results wrong) -- only tie them: 2.72 vs 2.70-2.75.  What the timing experiments had promised
+// was placement noise.  The code stays behind this switch (profiles/r05_ab_record_bytes.txt, r05_ab_narrow_records.txt).
+#ifndef RP_NARROW_RECORDS
+#define RP_NARROW_RECORDS 0  // 1: whole-ORF segments leave the 32-byte record of scores described above (A/B builds)
+#endif
 
 // position -> tile for x >= 0 without a 64-bit division (TILE = 2^k * m, m odd and small): the
 // shifted value fits 32 bits for every set that fits this GPU's memory (x < 2^(32 + k) >= 2^40
@@ -122,8 +142,10 @@ __device__ __forceinline__ long long tile_of(long long x)
 //   bits 38-50  tail     LDS index of an owned partial last codon (L % 3 != 0) ...
 //   bits 51-52  part     ... and its length (0 = none)
 //   bits 53-60  lanes    ceil(ntrip / kRun)
+//   bit  61     whole    the ORF lies inside this one tile: the segment is the whole ORF (32-byte record of scores, below)
 //   bit  63     live     0 = this id is a gap (no segment: empty ORF, or an unused id)
 typedef unsigned long long seg_desc_t;
+constexpr int kDescWholeBit = 61;
 static_assert(kTile + kHalo < 8192 && kTile / 3 < 4096 && (kTile / 3 + kRun - 1) / kRun < 256, "descriptor field widths");
 static_assert(kTileSmall <= kTile && kTileSmall % 256 == 0, "the small tile reuses the big tile's field widths and table sizes");
 
@@ -307,7 +329,8 @@ __global__ void k_tile_desc(const int64_t *__restrict__ offsets, long long n_orf
         }
         const int lanes = (ntrip + kRun - 1) / kRun;
         const seg_desc_t d = (seg_desc_t)qfirst | ((seg_desc_t)endq << 13) | ((seg_desc_t)ntrip << 26) |
-                             ((seg_desc_t)tail << 38) | ((seg_desc_t)part << 51) | ((seg_desc_t)lanes << 53) | (1ull << 63);
+                             ((seg_desc_t)tail << 38) | ((seg_desc_t)part << 51) | ((seg_desc_t)lanes << 53) |
+                             ((seg_desc_t)(b_first == b_last ? 1 : 0) << kDescWholeBit) | (1ull << 63);
         desc[orf + b] = d;
         const long long slot = orf - (tile_first[b] - 1);  // slot 0 = the ORF straddling in from the left
         if (slot >= 0 && slot < kHeadSlots) head[b * kHeadRow + 2 + slot] = d;
@@ -764,58 +787,97 @@ __device__ __forceinline__ void tile_pass(const int *__restrict__ s_counts, RunR
     }
 }
 
-// Record stage: the row records of a segment -> ONE 48-byte record.  The three words of a record
-// live in three planes (rec[f * n_rec + id]), one per reading frame; wave f < 3 writes plane f for
-// all 64 slots (thread = slot), so the three short dependency chains run side by side on three
-// SIMDs and every store instruction covers consecutive 16-byte words.  Per row the census sum of
-// the frame is decoded -- k = round(S / 2^13) = E + 256 Z, the row's flat and all-zero codons --
-// and the frame's codon starts come from the segment's geometry (s_geom: how many of its start
-// positions are valid), so N = codons - Z and M = N - E need no counting anywhere.
+// What k_orf_finish would make of a whole-ORF segment's sums first: the frame score, here from the UNROUNDED float64
+// sums, as fp32 (0 for an empty frame, NaN for a frame of flat codons only -- frame_score's own conventions).
+__device__ __forceinline__ float segment_score(double p, double q, unsigned n, unsigned m)
+{
+    return (float)frame_score(p, q, (int)n, (int)m).score;
+}
+
+// Record stage: the row records of a segment -> ONE record.  The words of a record live in planes (rec[f * n_rec + id]);
+// wave f < 3 sums reading frame f for all 64 slots (thread = slot), so the three short dependency chains run side by
+// side on three SIMDs and every store instruction covers consecutive 16-byte words.  Per row the census sum of the frame
+// is decoded -- k = round(S / 2^13) = E + 256 Z, the row's flat and all-zero codons -- and the frame's codon starts come
+// from the segment's geometry (s_geom: how many of its start positions are valid), so N = codons - Z and M = N - E need
+// no counting anywhere.  A segment of an ORF that spans tiles leaves plane f = {P_f, Q_f, N_f | M_f << 16, extra_f} (48
+// bytes: k_orf_finish adds the tiles' sums up); a WHOLE ORF leaves its three frame scores in planes 0 and 1 (32 bytes,
+// kRecordBytes above): wave 2 hands its three words over through `s_xchg` and a workgroup barrier -- which EVERY thread
+// of the workgroup must reach: no early return in front of it.
 __device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, const RunRec *__restrict__ s_rec,
                                              const int *__restrict__ s_vlstart, const int *__restrict__ s_tail,
-                                             const int *__restrict__ s_live, const int *__restrict__ s_geom,
+                                             const int *__restrict__ s_live, const int *__restrict__ s_geom, int *__restrict__ s_xchg,
                                              uint4 *__restrict__ rec, long long n_rec, long long id0, int wave, int seg)
 {
-    if (wave >= 3 || !s_live[seg]) return;
-    const int vs = s_vlstart[seg];
-    const int ve = s_vlstart[seg + 1];
-    const int w_first = vs >> 4;
-    const int w_last = ve > vs ? (ve - 1) >> 4 : w_first - 1;
-    const int tail = s_tail[seg];
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const int live_bits = wave < 3 ? s_live[seg] : 0;  // bit 0: the slot holds a segment, bit 1: that segment is a whole ORF
+    const bool live = (live_bits & 1) != 0;
     double a0 = 0.0, a1 = 0.0;
-    int flat = 0, zero = 0;
+    unsigned n = 0, m = 0;
     unsigned extra = wave == 1 ? (unsigned)RP_MIN_CODON_COV_EMPTY : 0u;  // wave 0: sum of clo, wave 1: minimum, wave 2: sum of chi
-    for (int w = w_first; w <= w_last; ++w) {
-        const RunRec &r = s_rec[seg + w];
-        a0 += (double)(wave == 0 ? r.p[0] : wave == 1 ? r.p[1] : r.p[2]);
-        a1 += (double)(wave == 0 ? r.q[0] : wave == 1 ? r.q[1] : r.q[2]);
-        const int k = (int)__builtin_fmaf(wave == 0 ? r.S[0] : wave == 1 ? r.S[1] : r.S[2], kFlatUnit, 0.5f);  // E + 256 Z of this row
-        flat += k & 255;
-        zero += k >> 8;
+    if (live) {
+        const int vs = s_vlstart[seg];
+        const int ve = s_vlstart[seg + 1];
+        const int w_first = vs >> 4;
+        const int w_last = ve > vs ? (ve - 1) >> 4 : w_first - 1;
+        const int tail = s_tail[seg];
+        int flat = 0, zero = 0;
+        for (int w = w_first; w <= w_last; ++w) {
+            const RunRec &r = s_rec[seg + w];
+            a0 += (double)(wave == 0 ? r.p[0] : wave == 1 ? r.p[1] : r.p[2]);
+            a1 += (double)(wave == 0 ? r.q[0] : wave == 1 ? r.q[1] : r.q[2]);
+            const int k = (int)__builtin_fmaf(wave == 0 ? r.S[0] : wave == 1 ? r.S[1] : r.S[2], kFlatUnit, 0.5f);  // E + 256 Z of this row
+            flat += k & 255;
+            zero += k >> 8;
+            if (wave == 0)
+                extra += (unsigned)r.clo;  // <= 11 rows x 2^20
+            else if (wave == 1)
+                extra = min(extra, r.mn);
+            else
+                extra += (unsigned)r.chi;  // <= 11 rows x 2^18
+        }
+        const int lim_seg = s_geom[seg];  // the segment's valid codon starts are its first lim_seg start positions
+        const int codons = ((lim_seg + 2 - wave) * 21846) >> 16;  // those of frame `wave`: floor((lim + 2 - f) / 3), lim < 8 192
+        n = (unsigned)(codons - zero);
+        m = n - (unsigned)flat;
+        if (tail >= 0 && wave < 2) {  // an owned partial last codon (L % 3 != 0): common.py:164-180 still sums it
+            unsigned codon = (unsigned)s_counts[tail & 0xffff];
+            if ((tail >> 16) == 2) codon += (unsigned)s_counts[(tail & 0xffff) + 1];
+            extra = wave == 0 ? extra + codon : min(extra, codon);  // (<= 2 x 2^24 on top of the clo sum: fits)
+        }
+    }
+#if RP_NARROW_RECORDS
+    const bool whole = (live_bits & 2) != 0;
+    float score = 0.f;
+    if (whole) {
+        score = segment_score(a0, a1, n, m);
+        if (wave == 2) {
+            s_xchg[3 * seg] = (int)__float_as_uint(score);
+            s_xchg[3 * seg + 1] = (int)n;
+            s_xchg[3 * seg + 2] = (int)extra;
+        }
+    }
+    __syncthreads();
+    if (whole) {
+#if !defined(RP_EXPERIMENT_NO_RECORD_STORE)
         if (wave == 0)
-            extra += (unsigned)r.clo;  // <= 11 rows x 2^20
+            stream_store(reinterpret_cast<u32x4_t *>(rec + id0 + seg),
+                         u32x4_t{__float_as_uint(score), (unsigned)s_xchg[3 * seg], n | ((unsigned)s_xchg[3 * seg + 1] << 16), extra});
         else if (wave == 1)
-            extra = min(extra, r.mn);
-        else
-            extra += (unsigned)r.chi;  // <= 11 rows x 2^18
+            stream_store(reinterpret_cast<u32x4_t *>(rec + n_rec + id0 + seg), u32x4_t{__float_as_uint(score), (unsigned)s_xchg[3 * seg + 2], n, extra});
+#endif
+        return;
     }
-    const int lim_seg = s_geom[seg];  // the segment's valid codon starts are its first lim_seg start positions
-    const int codons = ((lim_seg + 2 - wave) * 21846) >> 16;  // those of frame `wave`: floor((lim + 2 - f) / 3), lim < 8 192
-    const unsigned n = (unsigned)(codons - zero);
-    const unsigned m = n - (unsigned)flat;
-    if (tail >= 0 && wave < 2) {  // an owned partial last codon (L % 3 != 0): common.py:164-180 still sums it
-        unsigned codon = (unsigned)s_counts[tail & 0xffff];
-        if ((tail >> 16) == 2) codon += (unsigned)s_counts[(tail & 0xffff) + 1];
-        extra = wave == 0 ? extra + codon : min(extra, codon);  // (<= 2 x 2^24 on top of the clo sum: fits)
-    }
+#endif
+    if (!live) return;
+#ifdef RP_EXPERIMENT_RECORD_PLANES  // timing experiment only (results wrong): records of 16 / 32 bytes -- only the first 1 / 2 planes are stored
+    if (wave >= RP_EXPERIMENT_RECORD_PLANES) return;
+#endif
 #ifdef RP_EXPERIMENT_NO_RECORD_STORE  // timing experiment only (results wrong): what the record stream costs the kernel
     if (a0 == 12345.678) rec[wave * n_rec + id0 + seg] = make_uint4(0, 0, n, extra);
 #else
-    {   // written once, read once by the next kernel: a streaming store (rp_device.hpp, stream_store)
-        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-        stream_store(reinterpret_cast<u32x4_t *>(rec + wave * n_rec + id0 + seg),
-                     u32x4_t{__float_as_uint((float)a0), __float_as_uint((float)a1), n | (m << 16), extra});
-    }
+    // written once, read once by the next kernel: a streaming store (rp_device.hpp, stream_store)
+    stream_store(reinterpret_cast<u32x4_t *>(rec + wave * n_rec + id0 + seg),
+                 u32x4_t{__float_as_uint((float)a0), __float_as_uint((float)a1), n | (m << 16), extra});
 #endif
 }
 
@@ -878,7 +940,7 @@ __device__ __forceinline__ void short_round(seg_desc_t dc, const int *s_counts, 
         s_vlstart[lane] = vs_i;
         if (lane == kWave - 1) s_vlstart[kSegChunk] = incl;
         s_tail[lane] = part ? (((int)(dc >> 38) & 0x1fff) | (part << 16)) : -1;
-        s_live[lane] = (int)(dc >> 63);
+        s_live[lane] = (int)(dc >> 63) | ((int)((dc >> kDescWholeBit) & 1) << 1);
         s_geom[lane] = seg_geom(dc);
     }
     __syncthreads();  // the previous round's record stage is done with the row records
@@ -919,15 +981,29 @@ __device__ __forceinline__ void lane_segments(const int *__restrict__ s_counts, 
         mn = min(mn, codon);
     }
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    unsigned n[3], m[3];
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         const int k = (int)__builtin_fmaf(sv.S[f], kFlatUnit, 0.5f);  // E + 256 Z of this lane's run
         const int codons = ((lim + 2 - f) * 21846) >> 16;             // floor((lim + 2 - f) / 3), lim < 8 192
-        const unsigned n = (unsigned)(codons - (k >> 8));
-        const unsigned m = n - (unsigned)(k & 255);
+        n[f] = (unsigned)(codons - (k >> 8));
+        m[f] = n[f] - (unsigned)(k & 255);
+    }
+#if RP_NARROW_RECORDS
+    if ((d >> kDescWholeBit) & 1) {  // the whole ORF in this lane: its three scores in 32 bytes (kRecordBytes above)
+        float sc[3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) sc[f] = segment_score((double)sv.p[f], (double)sv.q[f], n[f], m[f]);
+        stream_store(reinterpret_cast<u32x4_t *>(rec + id), u32x4_t{__float_as_uint(sc[0]), __float_as_uint(sc[2]), n[0] | (n[2] << 16), lo});
+        stream_store(reinterpret_cast<u32x4_t *>(rec + n_rec + id), u32x4_t{__float_as_uint(sc[1]), hi, n[1], mn});
+        return;
+    }
+#endif
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
         const unsigned extra = f == 0 ? lo : f == 1 ? mn : hi;
         stream_store(reinterpret_cast<u32x4_t *>(rec + f * n_rec + id),
-                     u32x4_t{__float_as_uint(sv.p[f]), __float_as_uint(sv.q[f]), n | (m << 16), extra});
+                     u32x4_t{__float_as_uint(sv.p[f]), __float_as_uint(sv.q[f]), n[f] | (m[f] << 16), extra});
     }
 }
 
@@ -1053,7 +1129,7 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
             s_vlstart[lane] = vs_i;
             if (lane == kWave - 1) s_vlstart[kSegChunk] = incl;
             s_tail[lane] = part ? (((int)(d >> 38) & 0x1fff) | (part << 16)) : -1;
-            s_live[lane] = (int)(d >> 63);
+            s_live[lane] = (int)(d >> 63) | ((int)((d >> kDescWholeBit) & 1) << 1);
             s_geom[lane] = seg_geom(d);
         }
         RP_STAMP();  // 3: mapped, arrived at barrier 1
@@ -1064,7 +1140,7 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
         RP_STAMP();  // 5: this wave's lane runs done
         __syncthreads();
         RP_STAMP();  // 6: all lane runs done (barrier 2)
-        record_stage(s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, ws.rec, ws.n_rec, a0 - 1 + b, wave, lane);
+        record_stage(s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, s_owner, ws.rec, ws.n_rec, a0 - 1 + b, wave, lane);
         RP_STAMP();  // 7: records stored
         RP_STAMP_FLUSH();
         return;
@@ -1134,7 +1210,7 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
 #ifdef RP_STAMPS
         if (n_stamp_ < 7) RP_STAMP();  // short path: 2, 4, 6 = after barrier 2 of rounds 0, 1, 2
 #endif
-        record_stage(s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, ws.rec, ws.n_rec, a0 - 1 + c0 + b, wave, lane);
+        record_stage(s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, s_owner, ws.rec, ws.n_rec, a0 - 1 + c0 + b, wave, lane);
 #ifdef RP_STAMPS
         if (n_stamp_ < 7) RP_STAMP();  // short path: 3, 5, 7 = records of rounds 0, 1, 2 stored
 #endif
@@ -1301,9 +1377,27 @@ __global__ __launch_bounds__(kFinishBlock, RP_FINISH_WAVES) void k_orf_finish(So
         len = (long long)offsets[orf + 1] - beg;
         double p[3] = {0, 0, 0}, q[3] = {0, 0, 0};
         int n[3] = {0, 0, 0}, m[3] = {0, 0, 0};
+        FrameScore fr[3];
+        bool scored = false;  // the record already holds the frame scores (a whole-ORF segment's 32-byte record)
         if (len > 0) {
             const long long b_first = tile_of<TILE>(beg + plan.mis);
             const long long b_last = tile_of<TILE>(beg + len - 1 + plan.mis);
+#if RP_NARROW_RECORDS
+            if (b_first == b_last) {  // (the test k_tile_desc made for the descriptor's `whole` bit)
+                const uint4 w0 = ws.rec[orf + b_first], w1 = ws.rec[ws.n_rec + orf + b_first];
+                fr[0].score = (double)__uint_as_float(w0.x);
+                fr[2].score = (double)__uint_as_float(w0.y);
+                fr[1].score = (double)__uint_as_float(w1.x);
+                fr[0].n = (int)(w0.z & 0xffffu);
+                fr[2].n = (int)(w0.z >> 16);
+                fr[1].n = (int)(w1.z & 0xffffu);
+#pragma unroll
+                for (int f = 0; f < 3; ++f) fr[f].m = fr[f].score == fr[f].score ? fr[f].n : 0;  // (only ever asked: is it 0)
+                count = (long long)(((unsigned long long)w1.y << 16) + w0.w);
+                min_codon = (int)w1.w;
+                scored = true;
+            } else
+#endif
             for (long long b = b_first; b <= b_last; ++b) {  // tile order: deterministic sums
                 const uint4 w0 = ws.rec[orf + b], w1 = ws.rec[ws.n_rec + orf + b], w2 = ws.rec[2 * ws.n_rec + orf + b];
                 p[0] += (double)__uint_as_float(w0.x);
@@ -1323,9 +1417,10 @@ __global__ __launch_bounds__(kFinishBlock, RP_FINISH_WAVES) void k_orf_finish(So
             }
             if (b_last > b_first) split = RP_FLAG_SPLIT;
         }
-        FrameScore fr[3];
+        if (!scored) {
 #pragma unroll
-        for (int f = 0; f < 3; ++f) fr[f] = frame_score(p[f], q[f], n[f], m[f]);
+            for (int f = 0; f < 3; ++f) fr[f] = frame_score(p[f], q[f], n[f], m[f]);
+        }
         double phase;
         int valid;
         unsigned flags;

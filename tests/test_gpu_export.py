@@ -115,7 +115,13 @@ def test_compact_and_dense_coverage_write_the_same_file(tmp_path, report_all):
     d._INDEX_CACHE.clear()
     for tag in ("plain", "big", "sharded"):
         assert outs[(tag, "1")] == outs[(tag, "0")], tag
-    assert outs[("big", "1")] == outs[("sharded", "1")] or not report_all  # (default mode: another tiling may move an unflagged phase by <= 2e-7)
+    # one GPU vs three slices: another tiling may move an unflagged phase by <= 2e-7; every other column
+    # -- the integer results, the status, the saturated ORFs' float64 fix-ups, the printed profiles -- is the same text
+    one, three = (outs[(tag, "1")].decode().splitlines() for tag in ("big", "sharded"))
+    assert len(one) == len(three) and one[0] == three[0]
+    for a, b in zip(one[1:], three[1:]):
+        a, b = a.split("\t"), b.split("\t")
+        assert a[:3] == b[:3] and a[4:] == b[4:] and abs(float(a[3]) - float(b[3])) <= 1e-6
 
 
 def test_phasescore_mirror(g1, g5):
@@ -209,6 +215,14 @@ def test_export_edge_indexes(tmp_path):
     assert f[17] == str([0] * 9 + [0, 0, 0, 0, 0, 0, 5, 0, 0])
 
 
+def same_rows(a_text: str, b_text: str, tol: float = 1e-6) -> None:
+    a_rows, b_rows = a_text.splitlines(), b_text.splitlines()
+    assert len(a_rows) == len(b_rows) and a_rows[0] == b_rows[0]
+    for a, b in zip(a_rows[1:], b_rows[1:]):
+        a, b = a.split("\t"), b.split("\t")
+        assert a[:3] == b[:3] and a[4:] == b[4:] and abs(float(a[3]) - float(b[3])) <= tol, (a[:9], b[:9])
+
+
 def test_export_sharded_over_two_slices_equals_single(tmp_path):
     """configs[3] through the product entry point: export_orf_coverages(devices=[0, 0]) cuts the
     index into two nt-balanced slices (two streams of the one GPU here) and writes the same file."""
@@ -223,7 +237,10 @@ def test_export_sharded_over_two_slices_equals_single(tmp_path):
     finally:
         del os.environ["RIBOTRICER_AMD_DEVICES"]
     one = open(str(tmp_path / "one_translating_ORFs.tsv")).read()
-    assert one == open(str(tmp_path / "two_translating_ORFs.tsv")).read() == open(str(tmp_path / "env_translating_ORFs.tsv")).read()
+    # (every column the same text except the phase score: a slice is tiled on its own, which may move an unflagged phase
+    # by <= 2e-7 -- DESIGN.md section 5; the small one-GPU batch even takes the wave kernel)
+    same_rows(one, open(str(tmp_path / "two_translating_ORFs.tsv")).read())
+    same_rows(one, open(str(tmp_path / "env_translating_ORFs.tsv")).read())
     # default mode: the fused gather + score, sharded the same way (engine.score_coverage_sharded)
     export_orf_coverages(index, load_alignments(), str(tmp_path / "d1"))
     export_orf_coverages(index, load_alignments(), str(tmp_path / "d3"), devices=[0, 0, 0])
@@ -248,8 +265,8 @@ def test_export_sharded_over_two_slices_equals_single(tmp_path):
         export_orf_coverages(index, load_alignments(), str(tmp_path / "old2"), report_all=True, devices=[0, 0])
     finally:
         del os.environ["RIBOTRICER_AMD_SHARD_ON_FIRST_DEVICE"]
-    assert open(str(tmp_path / "old3_translating_ORFs.tsv")).read() == open(str(tmp_path / "d3_translating_ORFs.tsv")).read()
-    assert open(str(tmp_path / "old2_translating_ORFs.tsv")).read() == one
+    same_rows(open(str(tmp_path / "old3_translating_ORFs.tsv")).read(), open(str(tmp_path / "d3_translating_ORFs.tsv")).read())
+    same_rows(open(str(tmp_path / "old2_translating_ORFs.tsv")).read(), one)
 
 
 def test_index_is_parsed_once_per_file_and_reparsed_when_it_changes(tmp_path):
