@@ -184,22 +184,6 @@ bool known_algo(int algo) { return algo == RP_ALGO_AUTO || algo == RP_ALGO_WAVE 
 
 std::atomic<int> g_measurement_tag{0};
 
-// Workgroups of the per-ORF finish pass that `device` holds at once (occupancy x compute units), per kernel flavour.
-// A/B knob only: RP_FINISH_PERSIST=m (environment, read once) runs the pass with m x that many persistent workgroups;
-// unset / 0 = one workgroup per batch of 64 ORFs, which measured faster (rp_tile.hpp, k_orf_finish).
-template <typename Kernel>
-long long resident_blocks(Kernel kernel, int device, int block)
-{
-    int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || per_cu <= 0 || cus <= 0) {
-        (void)hipGetLastError();
-        return 0;  // (unknown: the caller keeps the one-shot grid)
-    }
-    return (long long)per_cu * cus;
-}
-
-long long finish_grid(int device, bool fused, int tile);  // (defined behind the kernels' template instantiations below)
 
 // workgroups of the scoring launch (RP_TILES_PER_WG tiles each, rp_tile.hpp)
 inline unsigned score_grid(long long n_tiles)
@@ -270,29 +254,6 @@ constexpr size_t kPlanHeader = 128;
 rp::PiecePlan piece_plan_of(const rp_gather_plan *g)
 {
     return rp::PiecePlan{g->mem.start, g->mem.base, g->mem.orf_piece, g->mem.tile_piece0, g->mem.tile_lo, g->mem.rows, g->n_pieces, g->coverage_len};
-}
-
-std::mutex g_grid_mutex;
-long long g_finish_grid[kMaxDevices][2][2];  // [device][fused][small tile]: 0 = not asked yet, -1 = one-shot grid
-long long finish_grid(int device, bool fused, int tile)
-{
-    if (device < 0 || device >= kMaxDevices) return 0;
-    std::lock_guard<std::mutex> lock(g_grid_mutex);
-    long long &slot = g_finish_grid[device][fused ? 1 : 0][tile == rp::kTile ? 0 : 1];
-    if (slot == 0) {
-        const char *env = std::getenv("RP_FINISH_PERSIST");
-        double mult = env ? std::atof(env) : 0.0;  // (workgroups per resident slot; 0 = the one-shot grid)
-        long long r = 0;
-        if (mult > 0.0) {
-            if (fused)
-                RP_WITH_TILE(tile, r = resident_blocks(rp::k_orf_finish<TILE, rp::CoverageSource>, device, rp::kFinishBlock));
-            else
-                RP_WITH_TILE(tile, r = resident_blocks(rp::k_orf_finish<TILE, rp::CsrSource>, device, rp::kFinishBlock));
-            r = (long long)(r * mult);
-        }
-        slot = r > 0 ? r : -1;
-    }
-    return slot > 0 ? slot : 0;
 }
 
 int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, int64_t n_orfs,
@@ -385,13 +346,10 @@ int score_impl(int device, const int32_t *d_counts, const int64_t *d_offsets, in
     }
     RP_HIP(hipGetLastError());
     if (tm && tm->on) RP_HIP(hipEventRecord(tm->ev[2], stream));
-    // 3. one thread per ORF: add its records, score, filter, store (one one-wave workgroup per batch of 64 ORFs;
-    //    RP_FINISH_PERSIST: fewer, looping ones -- an A/B knob, rp_tile.hpp k_orf_finish)
+    // 3. one thread per ORF: add its records, score, filter, store (one one-wave workgroup per batch of 64 ORFs)
     {
         const int block = rp::kFinishBlock;
-        long long grid = (n_orfs + block - 1) / block;
-        const long long resident = finish_grid(device, gather != nullptr, tile);
-        if (resident > 0 && grid > resident) grid = resident;
+        const long long grid = (n_orfs + block - 1) / block;
         if (gather != nullptr)
             RP_WITH_TILE(tile, hipLaunchKernelGGL((rp::k_orf_finish<TILE, rp::CoverageSource>), dim3((unsigned)grid), dim3(block), 0, stream,
                                                   rp::CoverageSource{d_counts, piece_plan_of(gather)}, d_offsets, (long long)n_orfs, plan, ws, out, fp));

@@ -1358,16 +1358,16 @@ __global__ __launch_bounds__(kFinishBlock, RP_FINISH_WAVES) void k_orf_finish(So
     const int lane = threadIdx.x & (kWave - 1);
     ReplayLds &s_replay = s_replay_w[threadIdx.x / kWave];
     int *const s_stage = s_stage_w[threadIdx.x / kWave];
-    // A wave takes the batches blockIdx.x, blockIdx.x + gridDim.x, ... of 64 ORFs.  The launcher's grid covers every batch
-    // (one pass of this loop) unless RP_FINISH_PERSIST asks for persistent waves -- an A/B knob: round 5 measured them
-    // SLOWER (0.347 vs 0.302 ms at 11 M ORFs with as many workgroups as the chip holds, 0.329 with twice, 0.303 with four
-    // times as many; fused 0.545 / 0.511 / 0.460 vs 0.450: profiles/r05_ab_finish_persist.txt).  The pass is not bound by
-    // the rate at which waves start: SQ_WAVE_CYCLES (quad-cycles) over the elapsed time puts 4 500 of the 5 120 wave slots
-    // in use, and 83 % of that wave time is the re-walks and replays of the 0.6 % too-close-to-call ORFs (~15 us of a whole
-    // wave each, 64 000 of them) -- a latency-bound tail that the one-shot grid balances perfectly (a finished wave's slot
-    // goes to the next batch) and a static assignment of batches to persistent waves does not.
-    for (long long batch0 = (long long)blockIdx.x * kFinishBlock; batch0 < n_orfs; batch0 += (long long)gridDim.x * kFinishBlock) {
-    const long long orf = batch0 + threadIdx.x;
+    // One batch of 64 ORFs per one-wave workgroup.  (Round 5 tried PERSISTENT waves -- as many workgroups as the chip holds,
+    // each looping over batches, the cure for a pass bound by the rate at which waves start: SLOWER, 0.347 vs 0.302 ms at
+    // 11 M ORFs, 0.329 with twice and 0.303 with four times as many workgroups; fused 0.545 / 0.511 / 0.460 vs 0.450
+    // (profiles/r05_ab_finish_persist.txt, .patch).  The pass is bound by WAVE TIME at full occupancy: SQ_WAVE_CYCLES
+    // (quad-cycles) over the elapsed time puts 4 500 of the 5 120 wave slots in use, and 83 % of that wave time is the
+    // re-walks and replays of the 0.6 % too-close-to-call ORFs, ~15 us of a whole wave each.  A one-shot grid hands a
+    // finished wave's slot to the next batch, which balances that tail perfectly; statically assigned batches do not.  And
+    // the loop itself cost four VGPRs -- 97 instead of 93, i.e. FOUR waves per SIMD instead of five: 0.256 -> 0.30 ms even
+    // with one batch per wave, which is how much every wave slot is worth to this pass.)
+    const long long orf = (long long)blockIdx.x * kFinishBlock + threadIdx.x;
     long long beg = 0, len = 0, count = 0;
     int min_codon = RP_MIN_CODON_COV_EMPTY;
     unsigned split = 0;
@@ -1460,7 +1460,6 @@ __global__ __launch_bounds__(kFinishBlock, RP_FINISH_WAVES) void k_orf_finish(So
         }
         finish_unsafe(source.orf(orf_s, beg_s), orf_s, len_s, count_s, min_s, split_s, lane, &s_replay, out, fp);
     }
-    }  // (the batches of this wave)
 }
 
 // ---------------------------------------------------------------------------

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_stream_read_lds(const char* __r
 //   mode 8  as 1 but at the START of the workgroup, before its DMA
 //   mode 9  return-less 64-bit atomic swaps (execute at the L2), two per 16 bytes
 //   mode 10 dword nt   11 sc1 nt   12 sc0 sc1 nt   13 sc0   14 sc1   15 three planes, nt      (+ 0x100: no reads at all)
+//   mode 16 / 17  one wave, nt / ordinary: the workgroup's 64-byte pieces `plane_bytes` apart (strided; see the case)
 __global__ __launch_bounds__(kThreads, 4) void k_stream_rw(const char* __restrict__ p, char* __restrict__ out, long long plane_bytes,
                                                            int w_bytes, int mode, unsigned long long* sink) {
     __shared__ __attribute__((aligned(16))) unsigned s_tile[kPiece / 4];
@@ -113,6 +114,16 @@ __global__ __launch_bounds__(kThreads, 4) void k_stream_rw(const char* __restric
     case 15: if (wave < 3 && lane * 16 < w_bytes / 3)  // three planes, nt
             __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + wave * plane_bytes + (size_t)blockIdx.x * (w_bytes / 3) + lane * 16));
         break;
+    case 16: case 17: if (wave == 0) {  // 64-byte pieces of one workgroup `plane_bytes` (= stride S, a multiple of 64) apart, memory filled densely:
+            // S / 64 consecutive workgroups share a region of pieces x S bytes, workgroup j owning the 64-byte column j of every row.
+            // (If a write costs the read stream a bus turn-around per channel visit, pieces that meet in one channel should be cheaper.)
+            const long long S = plane_bytes, per = S / 64, pieces = (w_bytes + 63) / 64;
+            char* region = out + ((long long)blockIdx.x / per) * (pieces * S) + ((long long)blockIdx.x % per) * 64;
+            for (int o = lane * 16; o < w_bytes; o += 1024) {
+                u32x4* q = reinterpret_cast<u32x4*>(region + (long long)(o / 64) * S + (o % 64));
+                if (mode == 16) __builtin_nontemporal_store(v, q); else *q = v;
+            }
+        } break;
     default: break;
     }
 }

@@ -593,11 +593,13 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     if plan is not None and not sharded and "workspace_placement" not in extras and extras["samples"] >= 2 and _place_workspace_for(table):
         # OPT-IN (RIBOTRICER_AMD_PLACE_WORKSPACE=1), once per cached index when its second sample arrives: put the record
         # workspace where its writes cost the coverage reads least (engine.tune_workspace; nothing but ONE workspace stays
-        # allocated).  Off by default because it does not pay here: a human-sized dense coverage (25-85 GB) spans every
-        # class of physical memory, so the candidates differ by 2-3 % of a 3 ms kernel (0.1 ms per sample), while the
-        # search costs 0.07 s -- 0.56 s on boxes whose driver takes 20 ms per GiB allocated (profiles/archive/r04_placement_check.txt,
-        # r04_export_e2e_11M_selected_gather.json).  The CSR path with a 16 GB counts array is where it gains 14 %:
-        # bench.py runs it there.
+        # allocated).  Off by default for a reason of PROPORTION: a sample of the 11 M-line index takes 0.21 s here, 5 ms of
+        # it on the device; the best placement buys at most 10 % of the 2.5 ms scoring kernel --
+        # 0.25 ms, a thousandth of a sample -- while the search costs 0.07 s, 0.5 s on boxes whose driver takes 20 ms per GiB
+        # allocated: some 300 samples of one index to pay it back.  (With the compact coverage -- 6.3 GB for that index, not
+        # the 25-85 GB dense layout the round-4 note argued from -- the coverage can lie inside one class of physical memory,
+        # so the search does find 3-10 % on the boxes that have classes: profiles/r05_placement_check.txt.  It is the
+        # kernel's gain, not the export's.)  bench.py, whose step IS the device work, runs the search.
         extras["workspace_placement"] = get_engine(device).tune_workspace(
             coverage, thresholds=make_filter(phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio,
                                              min_density_over_orf), gather_plan=plan, tries=3, spread=0.03)  # (a coverage far larger than a memory class: little to find, profiles/archive/r04_placement_check.txt)

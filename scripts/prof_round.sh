@@ -13,13 +13,13 @@ rm -rf $W; mkdir -p $W $OUT
 timeout 600 python3 bench.py $ARGS > $OUT/bench_default.json 2> $OUT/bench_default.err
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $W/stats -o stats -- python3 $R/bench.py $ARGS --steps 20 --warmup 3 --cpu-sample 0 > $OUT/bench_under_rocprofv3.json 2> $OUT/stats.err
-timeout 600 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $W/pmc1 -o pmc1 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-fused-nested > $OUT/pmc1_bench.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $W/pmc2 -o pmc2 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-fused-nested > $OUT/pmc2_bench.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $W/pmc1 -o pmc1 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-slice-projection --no-fused-nested > $OUT/pmc1_bench.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $W/pmc2 -o pmc2 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-slice-projection --no-fused-nested > $OUT/pmc2_bench.log 2>&1
 # (the two fused layouts launch the same kernel name: counted in separate passes -- pmc3/4 the run's own length law, pmc5/6 the nested index)
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $W/pmc3 -o pmc3 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-fused-nested > $OUT/pmc3_bench.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $W/pmc4 -o pmc4 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-fused-nested > $OUT/pmc4_bench.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $W/pmc5 -o pmc5 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-fused-exons > $OUT/pmc5_bench.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $W/pmc6 -o pmc6 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-fused-exons > $OUT/pmc6_bench.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $W/pmc3 -o pmc3 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-slice-projection --no-fused-nested > $OUT/pmc3_bench.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $W/pmc4 -o pmc4 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-slice-projection --no-fused-nested > $OUT/pmc4_bench.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $W/pmc5 -o pmc5 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-slice-projection --no-fused-exons > $OUT/pmc5_bench.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $W/pmc6 -o pmc6 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-slice-projection --no-fused-exons > $OUT/pmc6_bench.log 2>&1
 cd $R
 cp $(find $W/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 python3 - "$W" "$OUT" <<'PY'

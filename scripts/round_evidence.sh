@@ -2,7 +2,7 @@
 # Everything the round's BASELINE.md / DESIGN.md numbers quote, from ONE box and one gpurun call:
 # prof_round.sh (default bench line, rocprofv3 stats, four PMC passes) + the other configs' bench
 # lines + shapes + the 1 M-ORF export bench + the front end.  usage: bash scripts/round_evidence.sh r03
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 OUT=$R/gpurun_out/prof_$TAG
