@@ -594,6 +594,8 @@ def main():
     n_orfs = offsets.numel() - 1
     total_nt = counts.numel()
     eng = PhaseScoreEngine(dev)
+    if world == 1 and not args.no_pipelined:
+        eng.workspace_copies = 2  # (a stream's workspace is a block of two: the second serves the other stream of the two-stream trial)
     thresholds = make_filter()
     algo = args.algo
     resolved = ("tile" if total_nt >= (2 << 20) else "wave") if algo == "auto" else algo

@@ -191,9 +191,13 @@ class PhaseScoreEngine:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self._workspace: dict = {}  # stream handle -> uint8 tensor
+        # > 1: a stream's workspace is allocated as a block of that many workspaces side by side (set BEFORE the first call);
+        # the others serve further streams of the same batch (share_placed_workspace) -- and the block as first allocated
+        # is then a candidate of tune_workspace like any other, so the search can only improve on it
+        self.workspace_copies = 1
+        self._placed_blocks: dict = {}  # stream handle -> the workspaces (views) of the block that holds the stream's workspace
         self._out: dict = {}  # stream handle -> PhaseScores
         self._plans: list = []  # most recently used last
-        self._placed_blocks: dict = {}  # stream handle -> the workspaces of the block tune_workspace(copies=k) placed for it
         self._lock = threading.Lock()
 
     # -- buffers -----------------------------------------------------------------
@@ -202,7 +206,15 @@ class PhaseScoreEngine:
             return None
         ws = self._workspace.get(stream_key)
         if ws is None or ws.numel() < nbytes:
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            copies = max(1, int(self.workspace_copies))
+            if copies == 1:
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                self._placed_blocks.pop(stream_key, None)
+            else:
+                stride = (nbytes + 4095) & ~4095
+                block = torch.empty(stride * copies, dtype=torch.uint8, device=self.device)
+                self._placed_blocks[stream_key] = [block[k * stride : k * stride + nbytes] for k in range(copies)]
+                ws = self._placed_blocks[stream_key][0]
             self._workspace[stream_key] = ws
         return ws
 
@@ -263,7 +275,7 @@ class PhaseScoreEngine:
 
         lib = _lib.load()
         was = lib.rp_measurement_tag(1)  # the search's launches run under a second kernel name (profilers)
-        first = None
+        first = first_views = None
         candidates: list = []
         spacers: list = []
         times: list = []
@@ -274,9 +286,10 @@ class PhaseScoreEngine:
             first = self._workspace.get(stream_key)
             if first is None:
                 first = self._get_workspace(need, stream_key)
-            if copies > 1:  # (the first candidate too must be a block of `copies`: allocated now, right where a fresh allocation lands)
-                first = torch.empty(block_bytes, dtype=torch.uint8, device=dev)
-                self._workspace[stream_key] = first[:need]
+            # candidate 0 is the workspace AS FIRST ALLOCATED, whatever its shape (a block of `copies` when the engine
+            # was told so before its first call -- workspace_copies -- else the single workspace: if that one wins, further
+            # streams allocate their own): the search may only improve on what the process had
+            first_views = self._placed_blocks.get(stream_key)
             candidates.append(first)
             times.append(step_ms())
             if release:  # no cached block may serve a candidate: each must be a fresh allocation behind its spacer
@@ -304,7 +317,13 @@ class PhaseScoreEngine:
                 best = 0  # nothing to gain on this box: stay where the first allocation put it (no move for noise)
             if candidates:  # (an exception before the first timing leaves the workspace as it was)
                 chosen = candidates[best]
-                if copies > 1 and chosen.numel() >= block_bytes:
+                if best == 0:  # the first allocation stays, with whatever block it belongs to
+                    self._workspace[stream_key] = chosen
+                    if first_views:
+                        self._placed_blocks[stream_key] = first_views
+                    else:
+                        self._placed_blocks.pop(stream_key, None)
+                elif copies > 1 and chosen.numel() >= block_bytes:
                     self._workspace[stream_key] = chosen[:need]
                     self._placed_blocks[stream_key] = [chosen[k * copy_stride : k * copy_stride + need] for k in range(copies)]
                 else:
@@ -312,7 +331,7 @@ class PhaseScoreEngine:
                     self._placed_blocks.pop(stream_key, None)
                 del chosen
             n_spacers = len(spacers)
-            del spacers, candidates, first
+            del spacers, candidates, first, first_views
             if release:
                 torch.cuda.empty_cache()
         return {"step_ms": [round(t, 4) for t in times], "chosen": best, "spacer_gib": spacer_gib, "spacers": n_spacers,
