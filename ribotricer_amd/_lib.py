@@ -130,6 +130,14 @@ def load() -> ctypes.CDLL:
             "`make -C ribotricer_amd/csrc` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "Both backends (hip and cpu) live in that library."
         )
+    # PyTorch ships its own HIP / HSA runtime libraries; this library is linked against the system's (/opt/rocm).  Whichever
+    # is loaded FIRST serves the whole process (same sonames), and a process that starts on the system's runtime and then
+    # imports torch loses its device ("no ROCm-capable device is detected": seen with __graft_entry__.build() + smoke() in one
+    # process).  So torch, where it is installed, goes first -- as it does in every other entry point of the package.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # (a host without torch: the *_host entry points need neither)
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol

@@ -1290,9 +1290,17 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score_probe(c
 constexpr int kFinishBlock = RP_FINISH_BLOCK;  // threads per workgroup; the waves of a workgroup never synchronise (a re-walk holds up nobody else)
 static_assert(kFinishBlock % kWave == 0 && kFinishBlock <= 1024, "whole waves");
 #ifndef RP_STAGE_NT
-#define RP_STAGE_NT 1016
+#define RP_STAGE_NT 632
 #endif
-constexpr int kStageNt = RP_STAGE_NT;       // fused path: profiles up to this long are copied to LDS first (4 KB per wave: with 8 KB the pass itself loses occupancy, profiles/archive/r03_ab_stage_nt.txt)
+// fused path: profiles up to this long are copied to LDS first.  632 nt = 2.5 KB per wave: with the replay's 4.7 KB that
+// leaves room for five one-wave workgroups per SIMD (20 per CU), which the fused flavour is then asked to fit its registers
+// into (95 VGPRs instead of 103, 12 bytes of scratch per lane): every wave slot counts in this pass.
+// Measured against 1 016 nt / four waves (profiles/r05_ab_finish_occupancy.txt): fused finish 0.413 -> 0.388 ms; 760 nt:
+// 0.405; 504 nt: 0.393; 440 nt / six waves: 0.457 (spills).  Longer profiles are read through their pieces.
+constexpr int kStageNt = RP_STAGE_NT;
+#ifndef RP_FINISH_WAVES_FUSED
+#define RP_FINISH_WAVES_FUSED 5
+#endif
 
 // copy the profile of ORF `orf` out of the coverage into `stage`, piece by piece, coalesced; the
 // piece descriptors of up to 63 pieces are fetched lane-parallel first (one round trip, not one
@@ -1345,7 +1353,7 @@ __device__ __forceinline__ void finish_unsafe(Counts v, long long orf, long long
 #define RP_FINISH_WAVES 1
 #endif
 template <int TILE, typename Source>
-__global__ __launch_bounds__(kFinishBlock, RP_FINISH_WAVES) void k_orf_finish(Source source,
+__global__ __launch_bounds__(kFinishBlock, sizeof(Source) != sizeof(CsrSource) ? RP_FINISH_WAVES_FUSED : RP_FINISH_WAVES) void k_orf_finish(Source source,
                                                              const int64_t *__restrict__ offsets,
                                                              long long n_orfs, TilePlan plan,
                                                              TileWorkspace ws, OrfOutputs out,
