@@ -169,7 +169,7 @@ class IndexShards:
                     if report_all:
                         d_counts, offsets_k = b["plan"].gather(cov), np.asarray(part["table"].offsets, np.int64)
                     else:
-                        keep = mine["status"] != 0
+                        keep = mine["status"] != 0 if mine["status"] is not None else np.ones(hi - lo, bool)  # (no thresholds: nothing is filtered)
                         d_counts, offsets_k = b["plan"].gather_selected(cov, keep, lengths=b["lengths"], reuse_arrays=reuse_result_buffers)
                     stream.synchronize()
                     stages[k]["ties_and_profiles"] = time.perf_counter() - lap
