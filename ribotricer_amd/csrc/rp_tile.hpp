@@ -121,6 +121,23 @@ constexpr size_t kRecordBytes = 48;
 #ifndef RP_NARROW_RECORDS
 #define RP_NARROW_RECORDS 0  // 1: whole-ORF segments leave the 32-byte record of scores described above (A/B builds)
 #endif
+// RP_AOS_RECORDS=1 (A/B builds): the three words of a record side by side in memory (rec[3 * id + f]) and the records of a
+// tile stored as ONE contiguous run by consecutive lanes -- the three waves' words meet in LDS first (two workgroup
+// barriers), then thread t stores word t of the run: two store instructions for a tile of 23 segments (one of them five
+// lanes wide) instead of three, every cache line written by one instruction.  (Round 3's "aos" experiment kept one store
+// per wave, each striding through the whole run.)
+#ifndef RP_AOS_RECORDS
+#define RP_AOS_RECORDS 0
+#endif
+static_assert(!(RP_AOS_RECORDS && RP_NARROW_RECORDS), "one record experiment at a time");
+__device__ __forceinline__ long long rec_index(long long n_rec, long long id, int f)
+{
+#if RP_AOS_RECORDS
+    return 3 * id + f;
+#else
+    return f * n_rec + id;
+#endif
+}
 
 // position -> tile for x >= 0 without a 64-bit division (TILE = 2^k * m, m odd and small): the
 // shifted value fits 32 bits for every set that fits this GPU's memory (x < 2^(32 + k) >= 2^40
@@ -418,6 +435,7 @@ struct alignas(16) RunRec {
     float clo, chi;
     unsigned mn;
 };
+static_assert(!RP_AOS_RECORDS || kMaxRecs * sizeof(RunRec) >= 3 * kSegChunk * 16, "the staged run of a round overlays the row records");
 
 }  // namespace rp
 #include "rp_pieces.hpp"
@@ -806,7 +824,8 @@ __device__ __forceinline__ float segment_score(double p, double q, unsigned n, u
 __device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, const RunRec *__restrict__ s_rec,
                                              const int *__restrict__ s_vlstart, const int *__restrict__ s_tail,
                                              const int *__restrict__ s_live, const int *__restrict__ s_geom, int *__restrict__ s_xchg,
-                                             uint4 *__restrict__ rec, long long n_rec, long long id0, int wave, int seg)
+                                             uint4 *__restrict__ rec, long long n_rec, long long id0, int wave, int seg, int n_slots,
+                                             int *__restrict__ s_stage)
 {
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     const int live_bits = wave < 3 ? s_live[seg] : 0;  // bit 0: the slot holds a segment, bit 1: that segment is a whole ORF
@@ -868,6 +887,19 @@ __device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, c
         return;
     }
 #endif
+#if RP_AOS_RECORDS
+    {   // every slot of the round leaves its three words in LDS (dead slots: zeros), then thread t stores word t of the run
+        __syncthreads();  // (all waves are done with the row records: s_stage overlays them)
+        u32x4_t *stage = reinterpret_cast<u32x4_t *>(s_stage);
+        if (wave < 3 && seg < n_slots)
+            stage[3 * seg + wave] = live ? u32x4_t{__float_as_uint((float)a0), __float_as_uint((float)a1), n | (m << 16), extra} : u32x4_t{0u, 0u, 0u, 0u};
+        __syncthreads();
+        const int t = wave * kWave + seg;  // (seg == lane)
+        // (a dead slot's id belongs to nobody -- and slot 0 of tile 0 has id -1: skipped, the run keeps its place)
+        if (t < 3 * n_slots && (s_live[t / 3] & 1)) stream_store(reinterpret_cast<u32x4_t *>(rec + 3 * id0) + t, stage[t]);
+        return;
+    }
+#endif
     if (!live) return;
 #ifdef RP_EXPERIMENT_RECORD_PLANES  // timing experiment only (results wrong): records of 16 / 32 bytes -- only the first 1 / 2 planes are stored
     if (wave >= RP_EXPERIMENT_RECORD_PLANES) return;
@@ -876,7 +908,7 @@ __device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, c
     if (a0 == 12345.678) rec[wave * n_rec + id0 + seg] = make_uint4(0, 0, n, extra);
 #else
     // written once, read once by the next kernel: a streaming store (rp_device.hpp, stream_store)
-    stream_store(reinterpret_cast<u32x4_t *>(rec + wave * n_rec + id0 + seg),
+    stream_store(reinterpret_cast<u32x4_t *>(rec + rec_index(n_rec, id0 + seg, wave)),
                  u32x4_t{__float_as_uint((float)a0), __float_as_uint((float)a1), n | (m << 16), extra});
 #endif
 }
@@ -1002,7 +1034,7 @@ __device__ __forceinline__ void lane_segments(const int *__restrict__ s_counts, 
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         const unsigned extra = f == 0 ? lo : f == 1 ? mn : hi;
-        stream_store(reinterpret_cast<u32x4_t *>(rec + f * n_rec + id),
+        stream_store(reinterpret_cast<u32x4_t *>(rec + rec_index(n_rec, id, f)),
                      u32x4_t{__float_as_uint(sv.p[f]), __float_as_uint(sv.q[f]), n[f] | (m[f] << 16), extra});
     }
 }
@@ -1140,7 +1172,7 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
         RP_STAMP();  // 5: this wave's lane runs done
         __syncthreads();
         RP_STAMP();  // 6: all lane runs done (barrier 2)
-        record_stage(s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, s_owner, ws.rec, ws.n_rec, a0 - 1 + b, wave, lane);
+        record_stage(s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, s_owner, ws.rec, ws.n_rec, a0 - 1 + b, wave, lane, (int)(a1 - a0 + 1), reinterpret_cast<int *>(s_rec));
         RP_STAMP();  // 7: records stored
         RP_STAMP_FLUSH();
         return;
@@ -1210,7 +1242,8 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
 #ifdef RP_STAMPS
         if (n_stamp_ < 7) RP_STAMP();  // short path: 2, 4, 6 = after barrier 2 of rounds 0, 1, 2
 #endif
-        record_stage(s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, s_owner, ws.rec, ws.n_rec, a0 - 1 + c0 + b, wave, lane);
+        record_stage(s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, s_owner, ws.rec, ws.n_rec, a0 - 1 + c0 + b, wave, lane,
+                     (int)(n_slots - c0 < kSegChunk ? n_slots - c0 : kSegChunk), reinterpret_cast<int *>(s_rec));
 #ifdef RP_STAMPS
         if (n_stamp_ < 7) RP_STAMP();  // short path: 3, 5, 7 = records of rounds 0, 1, 2 stored
 #endif
@@ -1407,7 +1440,8 @@ __global__ __launch_bounds__(kFinishBlock, sizeof(Source) != sizeof(CsrSource) ?
             } else
 #endif
             for (long long b = b_first; b <= b_last; ++b) {  // tile order: deterministic sums
-                const uint4 w0 = ws.rec[orf + b], w1 = ws.rec[ws.n_rec + orf + b], w2 = ws.rec[2 * ws.n_rec + orf + b];
+                const uint4 w0 = ws.rec[rec_index(ws.n_rec, orf + b, 0)], w1 = ws.rec[rec_index(ws.n_rec, orf + b, 1)],
+                            w2 = ws.rec[rec_index(ws.n_rec, orf + b, 2)];
                 p[0] += (double)__uint_as_float(w0.x);
                 q[0] += (double)__uint_as_float(w0.y);
                 p[1] += (double)__uint_as_float(w1.x);
