@@ -64,6 +64,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_stream_read_lds(const char* __r
 //   mode 9  return-less 64-bit atomic swaps (execute at the L2), two per 16 bytes
 //   mode 10 dword nt   11 sc1 nt   12 sc0 sc1 nt   13 sc0   14 sc1   15 three planes, nt      (+ 0x100: no reads at all)
 //   mode 16 / 17  one wave, nt / ordinary: the workgroup's 64-byte pieces `plane_bytes` apart (strided; see the case)
+//   mode 18 / 19  one wave, nt / ordinary: contiguous chunks round a ring of `plane_bytes` (does a small write footprint stay on the die?)
 __global__ __launch_bounds__(kThreads, 4) void k_stream_rw(const char* __restrict__ p, char* __restrict__ out, long long plane_bytes,
                                                            int w_bytes, int mode, unsigned long long* sink) {
     __shared__ __attribute__((aligned(16))) unsigned s_tile[kPiece / 4];
@@ -122,6 +123,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_stream_rw(const char* __restric
             for (int o = lane * 16; o < w_bytes; o += 1024) {
                 u32x4* q = reinterpret_cast<u32x4*>(region + (long long)(o / 64) * S + (o % 64));
                 if (mode == 16) __builtin_nontemporal_store(v, q); else *q = v;
+            }
+        } break;
+    case 18: case 19: if (wave == 0) {  // nt / ordinary: the chunks go round a RING of plane_bytes (a footprint the Infinity Cache could hold)
+            char* ring = out + ((long long)blockIdx.x % (plane_bytes / w_bytes)) * w_bytes;
+            for (int o = lane * 16; o < w_bytes; o += 1024) {
+                if (mode == 18) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(ring + o)); else *reinterpret_cast<u32x4*>(ring + o) = v;
             }
         } break;
     default: break;
