@@ -83,6 +83,7 @@ def parse_args():
     ap.add_argument("--cpu-cores", type=int, default=0, help="processes for the CPU baseline (default: the usable cores, at most 64)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of head / middle / tail slices (N = 1) and the concat == whole check (N > 1)")
     ap.add_argument("--no-tune-workspace", action="store_true", help="keep the record workspace where the first allocation put it (engine.tune_workspace off)")
+    ap.add_argument("--no-tune-source", action="store_true", help="keep the synthetic counts / coverage where the first allocation put them (engine.tune_source off)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-stream many-samples section (N = 1)")
     ap.add_argument("--no-slice-projection", action="store_true", help="skip timing rank 0's slice of the 2 / 4 / 8-GPU runs on this one GPU (N = 1)")
     ap.add_argument("--no-fused", action="store_true", help="skip the fused gather + score section (N = 1)")
@@ -289,8 +290,11 @@ def fused_section(args, eng, dev, thresholds, n_set, layout="exons"):
     placement = None
     if not args.no_tune_workspace and int(offsets[-1]) >= (64 << 20):  # (as for the CSR path: once per index, not timed)
         placement = eng.tune_workspace(cov, thresholds=thresholds, gather_plan=gplan)
-        if placement.get("spacers"):
-            time.sleep(min(3.0, 0.5 * placement["spacers"]))
+        if not args.no_tune_source:  # (the coverage is this section's own array, as it is the export's: place it too)
+            cov, source_placement = eng.tune_source(cov, thresholds=thresholds, gather_plan=gplan, good_gbps=None, tries=2)
+            placement["source_placement"] = source_placement
+        if placement.get("spacers") or placement.get("source_placement", {}).get("spacers"):
+            time.sleep(min(3.0, 0.5 * (placement.get("spacers", 0) + placement.get("source_placement", {}).get("spacers", 0))))
     for _ in range(5):
         out = eng.score_coverage(cov, gplan, thresholds=thresholds, reuse_outputs=True)
     tm: list = []
@@ -636,8 +640,18 @@ def main():
         # of the two-stream section below, so both samples in flight write where this search found the writes cheapest)
         two_streams = world == 1 and not args.no_pipelined
         placement = eng.tune_workspace(counts, offsets, thresholds=thresholds, copies=2 if two_streams else 1)
+        if not args.no_tune_source:
+            # the other half of the placement: a step is slow whenever counts and records share a class of physical memory,
+            # and some places of the COUNTS are slow with every workspace (profiles/r05_source_placement.txt).  The counts
+            # are this program's own synthetic array -- as the coverage is the export's own buffer -- so the same search
+            # runs on them: copies behind spacers until the kernel moves its bytes at the fast class's rate; same bytes,
+            # the copies not kept are freed.  value_first_allocation stays what a process gets without either search.
+            counts, source_placement = eng.tune_source(counts, offsets, thresholds=thresholds)
+            placement["source_placement"] = source_placement
+            if source_placement["chosen"]:
+                placement["step_ms_after_source"] = source_placement["step_ms"][source_placement["chosen"]]
         lib_tag.rp_measurement_tag(was_tag)
-        if placement.get("spacers"):
+        if placement.get("spacers") or placement.get("source_placement", {}).get("spacers"):
             # the driver wipes the memory handed back in the background, which takes 1-4 % off the kernels meanwhile (and
             # an idle wait would let the clocks drop): run untimed steps until two batches of ten in a row run at the
             # speed the search itself measured on the workspace it kept (+0.5 %; five fresh processes of round 5 read
@@ -645,7 +659,8 @@ def main():
             # the old rule "two batches within 0.5 % of the best seen, at most 4 s" ending after 0.36 s) -- at most 6 s;
             # then the W warm-up steps and the K timed ones as always
             t_settle, calm = time.perf_counter(), 0
-            target = 10.0 * (1.005 * placement["step_ms"][placement["chosen"]] + 0.01) if placement.get("step_ms") else float("inf")
+            best_seen = placement.get("step_ms_after_source") or (placement["step_ms"][placement["chosen"]] if placement.get("step_ms") else None)
+            target = 10.0 * (1.005 * best_seen + 0.01) if best_seen else float("inf")
             lib_tag.rp_measurement_tag(1)
             while time.perf_counter() - t_settle < 6.0 and calm < 2:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 from typing import NamedTuple, Optional, Sequence
 
@@ -337,6 +338,109 @@ class PhaseScoreEngine:
         return {"step_ms": [round(t, 4) for t in times], "chosen": best, "spacer_gib": spacer_gib, "spacers": n_spacers,
                 "workspace_bytes": need, "copies": copies, "out_of_memory": oom, "released_to_driver": bool(release),
                 "reserved_bytes_after": int(torch.cuda.memory_reserved(dev)), "what": what}
+
+    def tune_source(self, counts, offsets=None, thresholds: Optional[FilterParams] = None, tries: int = 3,
+                    spacer_gib: float = 8.0, launches: int = 4, good_gbps: Optional[float] = 5950.0, gather_plan=None,
+                    max_bytes: int = 40 << 30, release: bool = True):
+        """The other half of the placement: where the COUNTS lie.  ``tune_workspace`` walks the record workspace through
+        physical memory; what it cannot change is the class of memory the read stream itself comes from, and a step is
+        slow whenever the two share one (one process, six copies of the same 16 GB of counts against two workspaces:
+        2.63-3.04 ms per launch, some copies slow with every workspace -- profiles/r05_source_placement.txt).  For an
+        input the CALLER OF THIS METHOD owns -- the bench's synthetic counts, the export's own coverage buffer -- the
+        same search is run on the source: unless the scoring kernel already moves its bytes at ``good_gbps`` (the fast
+        class on MI355X: 6.0-6.1 TB/s of algorithmic bytes for the CSR kernel; ``None``: no absolute mark -- stop at a
+        copy 5 % faster than the slowest seen) copies of ``counts`` are made one after the other, each behind a spacer
+        allocation, the step is timed on each with the stream's current workspace, and the search stops at the first
+        copy that reaches the mark or after ``tries``.  Returns ``(kept, info)``: ``kept`` is
+        ``counts`` itself or the fastest copy (same bytes; the caller drops its other reference), everything else is
+        freed.  Inputs above ``max_bytes`` are left where they are.  With ``gather_plan``: ``counts`` is the coverage
+        of the fused path."""
+        dev = self.device
+        if gather_plan is None:
+            counts = _as_device(counts, torch.int32, dev)
+            offsets = _as_device(offsets, torch.int64, dev)
+            n, total_nt = offsets.numel() - 1, counts.numel()
+
+            def run(src, t=None):
+                self.score(src, offsets, thresholds=thresholds, algo="tile", reuse_outputs=True, timings=t)
+        else:
+            counts = _as_device(counts, torch.int32, dev)
+            n, total_nt = gather_plan.n_orfs, gather_plan.total_nt
+
+            def run(src, t=None):
+                self.score_coverage(src, gather_plan, thresholds=thresholds, reuse_outputs=True, timings=t)
+        what = ("engine.tune_source: copies of the input array, each behind a spacer allocation, the scoring step timed on each "
+                "with the stream's workspace; the fastest kept (same bytes), the rest freed")
+        nbytes = counts.numel() * 4
+        algorithmic = 4.0 * total_nt + 32.0 * n  # (SURVEY section 8(d): counts in; offsets in and outputs out per ORF -- bench.py's figure)
+        if n <= 0 or nbytes == 0 or nbytes > max_bytes:
+            return counts, {"step_ms": [], "kernel_gbps": [], "chosen": 0, "what": what, "skipped": "empty or larger than max_bytes"}
+
+        def measure(src):
+            t: list = []
+            run(src)
+            for _ in range(launches):
+                run(src, t)
+            t.sort(key=lambda x: x[1] + x[2])
+            mid = t[len(t) // 2]
+            return mid[1] + mid[2], algorithmic / (mid[1] * 1e6)
+
+        lib = _lib.load()
+        was = lib.rp_measurement_tag(1)
+        candidates = [counts]
+        spacers: list = []
+        steps: list = []
+        rates: list = []
+        oom = False
+        try:
+            run(counts)
+            # (a search that has just handed memory back -- tune_workspace -- leaves the driver wiping it in the background,
+            # 1-4 % off every kernel for up to a second: measure the copy in hand once batches of ten stop getting faster)
+            t_calm, prev = time.perf_counter(), None
+            while time.perf_counter() - t_calm < 1.5:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    run(counts)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                now = e0.elapsed_time(e1)
+                if prev is not None and now >= 0.997 * prev:
+                    break
+                prev = now
+            ms, gbps = measure(counts)
+            steps.append(ms)
+            rates.append(gbps)
+            def done():  # an absolute mark when the caller names one, else the workspace search's rule: a copy 5 % faster than the slowest seen
+                if good_gbps is not None:
+                    return rates[-1] >= good_gbps
+                return len(steps) > 1 and steps[-1] <= 0.95 * max(steps)
+
+            while not done() and len(candidates) <= tries:
+                try:
+                    spacers.append(torch.empty(int(spacer_gib * (1 << 30)), dtype=torch.uint8, device=dev))
+                    cand = counts.clone()
+                except torch.cuda.OutOfMemoryError:
+                    oom = True
+                    break
+                candidates.append(cand)
+                ms, gbps = measure(cand)
+                steps.append(ms)
+                rates.append(gbps)
+        finally:
+            torch.cuda.synchronize(dev)
+            lib.rp_measurement_tag(was)
+        best = min(range(len(steps)), key=steps.__getitem__)
+        if steps[best] > 0.99 * steps[0]:
+            best = 0  # (no move for noise)
+        kept = candidates[best]
+        n_spacers = len(spacers)
+        del spacers, candidates
+        if release and n_spacers:
+            torch.cuda.empty_cache()
+        return kept, {"step_ms": [round(x, 4) for x in steps], "kernel_gbps": [round(x, 1) for x in rates], "chosen": best,
+                      "good_gbps": good_gbps, "spacer_gib": spacer_gib, "spacers": n_spacers, "out_of_memory": oom,
+                      "source_bytes": nbytes, "what": what}
 
     def share_placed_workspace(self, streams, source_stream=None) -> int:
         """Give ``streams[k]`` the k-th workspace of the block that ``tune_workspace(copies=...)`` placed for

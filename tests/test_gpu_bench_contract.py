@@ -163,6 +163,9 @@ def test_pipelined_and_first_allocation_values_are_reported_beside_value():
     wp = d["config"]["workspace_placement"]
     assert wp["released_to_driver"] is True and wp["spacers"] == len(wp["step_ms"]) - 1
     assert wp["copies"] == 2  # (the second workspace of the chosen block serves the other stream of the two-stream trial)
+    sp = wp["source_placement"]  # (engine.tune_source: the synthetic counts placed like the workspace; same bytes -- verify below)
+    assert len(sp["step_ms"]) == len(sp["kernel_gbps"]) == sp["spacers"] + 1 <= 4 and 0 <= sp["chosen"] < len(sp["step_ms"])
+    assert sp["step_ms"][sp["chosen"]] <= sp["step_ms"][0]
     p = d["pipelined"]
     assert d["value_pipelined"] == pytest.approx(600000 / (p["ms_per_step"] * 1e-3), rel=1e-9)
     assert p["results_equal_headline"] is True and p["streams"] in (1, 2) and d["verify"]["ok"] is True
