@@ -31,7 +31,11 @@ line says so (`config.ranks_share_gpus`): a self-test of the N-rank control flow
 Once per index and outside the timed region, like the plan build: `engine.tune_workspace` tries a few
 placements of the record workspace and keeps the fastest (on MI355X a write stream costs a read stream
 10 % or 23 % depending on the classes of physical memory the two buffers lie in, DESIGN.md section 4);
-what it saw is reported in `config.workspace_placement`, `--no-tune-workspace` switches it off.
+what it saw is reported in `config.workspace_placement`, `--no-tune-workspace` switches it off.  The other half
+of that relation is where the COUNTS lie: `engine.tune_source` places this program's own synthetic array the same
+way (copies behind spacers until the kernel runs at the fast class's rate; same bytes; reported in
+`config.workspace_placement.source_placement`, `--no-tune-source` switches it off).  `value_first_allocation` is
+the step before either search.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (algorithmic bytes
 B = 4*sum(L) + 8*(n+1) + 24*n per launch over its HIP-event duration, vs the 8 TB/s
