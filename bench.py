@@ -620,7 +620,8 @@ def main():
 
     placement = None
     first_alloc_ms = None
-    if plan is not None and not args.no_tune_workspace and total_nt >= (64 << 20):
+    shared_gpu = world > max(1, torch.cuda.device_count())  # (the one-GPU self-test of the N-rank flow: no searches that allocate tens of GiB per rank)
+    if plan is not None and not args.no_tune_workspace and total_nt >= (64 << 20) and not shared_gpu:
         # once per index, like the plan and outside the timed region: where the record workspace lies relative to the
         # counts decides between 2.6 and 3.0 ms per launch on this part; the engine tries a few
         # placements, keeps the fastest and frees the rest -- exactly what the drop-in export does once per cached index

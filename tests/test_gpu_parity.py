@@ -519,3 +519,30 @@ def test_tune_workspace_changes_placement_not_results():
     for k in ("phase", "valid", "read_count", "min_codon_cov", "flags", "status"):
         assert torch.equal(getattr(before, k), getattr(after, k)), k
 
+
+
+def test_tune_source_returns_the_same_bytes_wherever_it_puts_them():
+    """engine.tune_source: the array itself or a copy in another place -- same bytes, same results; the search's record."""
+    import torch
+
+    from ribotricer_amd.engine import PhaseScoreEngine, make_filter
+    from ribotricer_amd.synth import synth_csr_device
+
+    counts, offsets = synth_csr_device(300_000, cfg="cfg3", device="cuda:0")
+    eng = PhaseScoreEngine("cuda:0")
+    th = make_filter()
+    want = eng.score(counts, offsets, thresholds=th).cpu_numpy()
+    # a mark no kernel reaches: every try is made (small spacers: this is a test of the bookkeeping, not of the placement)
+    kept, info = eng.tune_source(counts, offsets, thresholds=th, tries=2, spacer_gib=0.25, good_gbps=1e9)
+    assert len(info["step_ms"]) == len(info["kernel_gbps"]) == 3 and info["spacers"] == 2 and 0 <= info["chosen"] < 3
+    assert info["step_ms"][info["chosen"]] <= info["step_ms"][0] and info["source_bytes"] == counts.numel() * 4
+    assert torch.equal(kept, counts) and (kept is counts) == (info["chosen"] == 0)
+    got = eng.score(kept, offsets, thresholds=th).cpu_numpy()
+    for key in want:
+        assert np.array_equal(got[key], want[key], equal_nan=True), key
+    # already at the mark: nothing is copied
+    kept2, info2 = eng.tune_source(counts, offsets, thresholds=th, good_gbps=1.0)
+    assert kept2 is counts and info2["spacers"] == 0 and info2["chosen"] == 0
+    # too large for the search (max_bytes): left where it is
+    kept3, info3 = eng.tune_source(counts, offsets, thresholds=th, max_bytes=1024)
+    assert kept3 is counts and "skipped" in info3
