@@ -101,42 +101,15 @@ struct TilePlan {
 // workgroup costs the scoring kernel +12 %, three times what the round trip costs;
 // profiles/archive/r03_ab_inkernel_finish.txt.)
 constexpr size_t kRecordBytes = 48;
-// Round 5, RP_NARROW_RECORDS=1: a segment that is a WHOLE ORF (the ORF lies inside one tile: 95 % of them; descriptor bit
-// `whole`) leaves a 32-byte record in planes 0 and 1 only -- not its raw sums but what the finish pass would make of them first:
-//   plane 0  score_0  score_2  N_0 | N_2 << 16   extra_0      score_f = (P^2 + PQ + Q^2) / (N M) computed by the record stage in
-//   plane 1  score_1  extra_2  N_1               extra_1      float64 from the UNROUNDED float64 sums and stored as fp32 (one
-//                                                             rounding, 6e-8; 0 for N = 0, NaN for M = 0 < N); extras as above
-// Wave 2 hands its three words (score_2, N_2, extra_2) to waves 0 / 1 through 192 dwords of LDS and one workgroup barrier
-// and stores nothing for such a segment.  Why: a byte written next to the read stream costs about five read, and on the
-// boxes where no workspace placement helps the kernel ran 2-7 % faster with two planes stored instead of three (timing
-// experiments, profiles/r05_ab_record_bytes.txt; 16 bytes buy nothing more).  A lossless 32-byte record of the raw sums
-// does not exist (six fp32 sums 24 B + six 12-bit census counts 9 B + read count and minimum 8 B), and segments of ORFs
-// that span tiles must add their P and Q up in k_orf_finish: they keep the three-plane record.  k_orf_finish tells the
-// two kinds apart by the ORF's geometry (first tile == last tile), exactly the test k_tile_desc makes.
-// BUILT TO PARITY (143 GPU tests green) AND NOT KEPT: on three boxes the real thing is 2-7 % SLOWER than the 48-byte records
-// (kernel 2.90-3.11 vs 2.70-3.03 ms median over nine placements, finish 0.325 vs 0.303 ms: the narrow / wide branch makes
-// nearly every wave of the finish pass run both paths), and even its idealised forms -- fp32 scoring, no store at all
-// for the split segments (results wrong) -- only tie them: 2.72 vs 2.70-2.75.  What the timing experiments had promised
-// was placement noise.  The code stays behind this switch (profiles/r05_ab_record_bytes.txt, r05_ab_narrow_records.txt).
-#ifndef RP_NARROW_RECORDS
-#define RP_NARROW_RECORDS 0  // 1: whole-ORF segments leave the 32-byte record of scores described above (A/B builds)
-#endif
-// RP_AOS_RECORDS=1 (A/B builds): the three words of a record side by side in memory (rec[3 * id + f]) and the records of a
-// tile stored as ONE contiguous run by consecutive lanes -- the three waves' words meet in LDS first (two workgroup
-// barriers), then thread t stores word t of the run: two store instructions for a tile of 23 segments (one of them five
-// lanes wide) instead of three, every cache line written by one instruction.  (Round 3's "aos" experiment kept one store
-// per wave, each striding through the whole run.)
-#ifndef RP_AOS_RECORDS
-#define RP_AOS_RECORDS 0
-#endif
-static_assert(!(RP_AOS_RECORDS && RP_NARROW_RECORDS), "one record experiment at a time");
+// Round 5 built two other record formats to parity and dropped both (the builds are kept as patches):
+// 32-byte records for whole-ORF segments -- the three frame scores instead of the raw sums, wave 2's words handed to waves
+// 0 / 1 through LDS; a lossless 32-byte record of the sums themselves does not exist (six fp32 sums 24 B + six 12-bit
+// census counts 9 B + read count and minimum 8 B) -- 2-7 % slower on three boxes (profiles/r05_ab_narrow_records.txt,
+// r05_ab_narrow_aos_records.patch); and a tile's records as ONE contiguous run (rec[3 * id + f], the waves' words meeting
+// in LDS first): inside the placement spread (profiles/r05_ab_aos_records.txt, same patch).
 __device__ __forceinline__ long long rec_index(long long n_rec, long long id, int f)
 {
-#if RP_AOS_RECORDS
-    return 3 * id + f;
-#else
     return f * n_rec + id;
-#endif
 }
 
 // position -> tile for x >= 0 without a 64-bit division (TILE = 2^k * m, m odd and small): the
@@ -159,10 +132,8 @@ __device__ __forceinline__ long long tile_of(long long x)
 //   bits 38-50  tail     LDS index of an owned partial last codon (L % 3 != 0) ...
 //   bits 51-52  part     ... and its length (0 = none)
 //   bits 53-60  lanes    ceil(ntrip / kRun)
-//   bit  61     whole    the ORF lies inside this one tile: the segment is the whole ORF (32-byte record of scores, below)
 //   bit  63     live     0 = this id is a gap (no segment: empty ORF, or an unused id)
 typedef unsigned long long seg_desc_t;
-constexpr int kDescWholeBit = 61;
 static_assert(kTile + kHalo < 8192 && kTile / 3 < 4096 && (kTile / 3 + kRun - 1) / kRun < 256, "descriptor field widths");
 static_assert(kTileSmall <= kTile && kTileSmall % 256 == 0, "the small tile reuses the big tile's field widths and table sizes");
 
@@ -347,7 +318,7 @@ __global__ void k_tile_desc(const int64_t *__restrict__ offsets, long long n_orf
         const int lanes = (ntrip + kRun - 1) / kRun;
         const seg_desc_t d = (seg_desc_t)qfirst | ((seg_desc_t)endq << 13) | ((seg_desc_t)ntrip << 26) |
                              ((seg_desc_t)tail << 38) | ((seg_desc_t)part << 51) | ((seg_desc_t)lanes << 53) |
-                             ((seg_desc_t)(b_first == b_last ? 1 : 0) << kDescWholeBit) | (1ull << 63);
+                             (1ull << 63);
         desc[orf + b] = d;
         const long long slot = orf - (tile_first[b] - 1);  // slot 0 = the ORF straddling in from the left
         if (slot >= 0 && slot < kHeadSlots) head[b * kHeadRow + 2 + slot] = d;
@@ -435,7 +406,6 @@ struct alignas(16) RunRec {
     float clo, chi;
     unsigned mn;
 };
-static_assert(!RP_AOS_RECORDS || kMaxRecs * sizeof(RunRec) >= 3 * kSegChunk * 16, "the staged run of a round overlays the row records");
 
 }  // namespace rp
 #include "rp_pieces.hpp"
@@ -805,31 +775,20 @@ __device__ __forceinline__ void tile_pass(const int *__restrict__ s_counts, RunR
     }
 }
 
-// What k_orf_finish would make of a whole-ORF segment's sums first: the frame score, here from the UNROUNDED float64
-// sums, as fp32 (0 for an empty frame, NaN for a frame of flat codons only -- frame_score's own conventions).
-__device__ __forceinline__ float segment_score(double p, double q, unsigned n, unsigned m)
-{
-    return (float)frame_score(p, q, (int)n, (int)m).score;
-}
-
 // Record stage: the row records of a segment -> ONE record.  The words of a record live in planes (rec[f * n_rec + id]);
 // wave f < 3 sums reading frame f for all 64 slots (thread = slot), so the three short dependency chains run side by
 // side on three SIMDs and every store instruction covers consecutive 16-byte words.  Per row the census sum of the frame
 // is decoded -- k = round(S / 2^13) = E + 256 Z, the row's flat and all-zero codons -- and the frame's codon starts come
 // from the segment's geometry (s_geom: how many of its start positions are valid), so N = codons - Z and M = N - E need
-// no counting anywhere.  A segment of an ORF that spans tiles leaves plane f = {P_f, Q_f, N_f | M_f << 16, extra_f} (48
-// bytes: k_orf_finish adds the tiles' sums up); a WHOLE ORF leaves its three frame scores in planes 0 and 1 (32 bytes,
-// kRecordBytes above): wave 2 hands its three words over through `s_xchg` and a workgroup barrier -- which EVERY thread
-// of the workgroup must reach: no early return in front of it.
+// no counting anywhere.  The segment leaves plane f = {P_f, Q_f, N_f | M_f << 16, extra_f} (48 bytes: k_orf_finish adds
+// the sums of the tiles an ORF spans).
 __device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, const RunRec *__restrict__ s_rec,
                                              const int *__restrict__ s_vlstart, const int *__restrict__ s_tail,
-                                             const int *__restrict__ s_live, const int *__restrict__ s_geom, int *__restrict__ s_xchg,
-                                             uint4 *__restrict__ rec, long long n_rec, long long id0, int wave, int seg, int n_slots,
-                                             int *__restrict__ s_stage)
+                                             const int *__restrict__ s_live, const int *__restrict__ s_geom,
+                                             uint4 *__restrict__ rec, long long n_rec, long long id0, int wave, int seg)
 {
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    const int live_bits = wave < 3 ? s_live[seg] : 0;  // bit 0: the slot holds a segment, bit 1: that segment is a whole ORF
-    const bool live = (live_bits & 1) != 0;
+    const bool live = wave < 3 && s_live[seg] != 0;  // the slot holds a segment
     double a0 = 0.0, a1 = 0.0;
     unsigned n = 0, m = 0;
     unsigned extra = wave == 1 ? (unsigned)RP_MIN_CODON_COV_EMPTY : 0u;  // wave 0: sum of clo, wave 1: minimum, wave 2: sum of chi
@@ -864,53 +823,10 @@ __device__ __forceinline__ void record_stage(const int *__restrict__ s_counts, c
             extra = wave == 0 ? extra + codon : min(extra, codon);  // (<= 2 x 2^24 on top of the clo sum: fits)
         }
     }
-#if RP_NARROW_RECORDS
-    const bool whole = (live_bits & 2) != 0;
-    float score = 0.f;
-    if (whole) {
-        score = segment_score(a0, a1, n, m);
-        if (wave == 2) {
-            s_xchg[3 * seg] = (int)__float_as_uint(score);
-            s_xchg[3 * seg + 1] = (int)n;
-            s_xchg[3 * seg + 2] = (int)extra;
-        }
-    }
-    __syncthreads();
-    if (whole) {
-#if !defined(RP_EXPERIMENT_NO_RECORD_STORE)
-        if (wave == 0)
-            stream_store(reinterpret_cast<u32x4_t *>(rec + id0 + seg),
-                         u32x4_t{__float_as_uint(score), (unsigned)s_xchg[3 * seg], n | ((unsigned)s_xchg[3 * seg + 1] << 16), extra});
-        else if (wave == 1)
-            stream_store(reinterpret_cast<u32x4_t *>(rec + n_rec + id0 + seg), u32x4_t{__float_as_uint(score), (unsigned)s_xchg[3 * seg + 2], n, extra});
-#endif
-        return;
-    }
-#endif
-#if RP_AOS_RECORDS
-    {   // every slot of the round leaves its three words in LDS (dead slots: zeros), then thread t stores word t of the run
-        __syncthreads();  // (all waves are done with the row records: s_stage overlays them)
-        u32x4_t *stage = reinterpret_cast<u32x4_t *>(s_stage);
-        if (wave < 3 && seg < n_slots)
-            stage[3 * seg + wave] = live ? u32x4_t{__float_as_uint((float)a0), __float_as_uint((float)a1), n | (m << 16), extra} : u32x4_t{0u, 0u, 0u, 0u};
-        __syncthreads();
-        const int t = wave * kWave + seg;  // (seg == lane)
-        // (a dead slot's id belongs to nobody -- and slot 0 of tile 0 has id -1: skipped, the run keeps its place)
-        if (t < 3 * n_slots && (s_live[t / 3] & 1)) stream_store(reinterpret_cast<u32x4_t *>(rec + 3 * id0) + t, stage[t]);
-        return;
-    }
-#endif
     if (!live) return;
-#ifdef RP_EXPERIMENT_RECORD_PLANES  // timing experiment only (results wrong): records of 16 / 32 bytes -- only the first 1 / 2 planes are stored
-    if (wave >= RP_EXPERIMENT_RECORD_PLANES) return;
-#endif
-#ifdef RP_EXPERIMENT_NO_RECORD_STORE  // timing experiment only (results wrong): what the record stream costs the kernel
-    if (a0 == 12345.678) rec[wave * n_rec + id0 + seg] = make_uint4(0, 0, n, extra);
-#else
     // written once, read once by the next kernel: a streaming store (rp_device.hpp, stream_store)
     stream_store(reinterpret_cast<u32x4_t *>(rec + rec_index(n_rec, id0 + seg, wave)),
                  u32x4_t{__float_as_uint((float)a0), __float_as_uint((float)a1), n | (m << 16), extra});
-#endif
 }
 
 // the segment's number of valid codon-start positions (every frame counted), from its descriptor:
@@ -972,7 +888,7 @@ __device__ __forceinline__ void short_round(seg_desc_t dc, const int *s_counts, 
         s_vlstart[lane] = vs_i;
         if (lane == kWave - 1) s_vlstart[kSegChunk] = incl;
         s_tail[lane] = part ? (((int)(dc >> 38) & 0x1fff) | (part << 16)) : -1;
-        s_live[lane] = (int)(dc >> 63) | ((int)((dc >> kDescWholeBit) & 1) << 1);
+        s_live[lane] = (int)(dc >> 63);
         s_geom[lane] = seg_geom(dc);
     }
     __syncthreads();  // the previous round's record stage is done with the row records
@@ -1021,16 +937,6 @@ __device__ __forceinline__ void lane_segments(const int *__restrict__ s_counts, 
         n[f] = (unsigned)(codons - (k >> 8));
         m[f] = n[f] - (unsigned)(k & 255);
     }
-#if RP_NARROW_RECORDS
-    if ((d >> kDescWholeBit) & 1) {  // the whole ORF in this lane: its three scores in 32 bytes (kRecordBytes above)
-        float sc[3];
-#pragma unroll
-        for (int f = 0; f < 3; ++f) sc[f] = segment_score((double)sv.p[f], (double)sv.q[f], n[f], m[f]);
-        stream_store(reinterpret_cast<u32x4_t *>(rec + id), u32x4_t{__float_as_uint(sc[0]), __float_as_uint(sc[2]), n[0] | (n[2] << 16), lo});
-        stream_store(reinterpret_cast<u32x4_t *>(rec + n_rec + id), u32x4_t{__float_as_uint(sc[1]), hi, n[1], mn});
-        return;
-    }
-#endif
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         const unsigned extra = f == 0 ? lo : f == 1 ? mn : hi;
@@ -1161,7 +1067,7 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
             s_vlstart[lane] = vs_i;
             if (lane == kWave - 1) s_vlstart[kSegChunk] = incl;
             s_tail[lane] = part ? (((int)(d >> 38) & 0x1fff) | (part << 16)) : -1;
-            s_live[lane] = (int)(d >> 63) | ((int)((d >> kDescWholeBit) & 1) << 1);
+            s_live[lane] = (int)(d >> 63);
             s_geom[lane] = seg_geom(d);
         }
         RP_STAMP();  // 3: mapped, arrived at barrier 1
@@ -1172,7 +1078,7 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
         RP_STAMP();  // 5: this wave's lane runs done
         __syncthreads();
         RP_STAMP();  // 6: all lane runs done (barrier 2)
-        record_stage(s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, s_owner, ws.rec, ws.n_rec, a0 - 1 + b, wave, lane, (int)(a1 - a0 + 1), reinterpret_cast<int *>(s_rec));
+        record_stage(s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, ws.rec, ws.n_rec, a0 - 1 + b, wave, lane);
         RP_STAMP();  // 7: records stored
         RP_STAMP_FLUSH();
         return;
@@ -1242,8 +1148,7 @@ __device__ __forceinline__ void tile_body(const int32_t *__restrict__ counts, co
 #ifdef RP_STAMPS
         if (n_stamp_ < 7) RP_STAMP();  // short path: 2, 4, 6 = after barrier 2 of rounds 0, 1, 2
 #endif
-        record_stage(s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, s_owner, ws.rec, ws.n_rec, a0 - 1 + c0 + b, wave, lane,
-                     (int)(n_slots - c0 < kSegChunk ? n_slots - c0 : kSegChunk), reinterpret_cast<int *>(s_rec));
+        record_stage(s_counts, s_rec, s_vlstart, s_tail, s_live, s_geom, ws.rec, ws.n_rec, a0 - 1 + c0 + b, wave, lane);
 #ifdef RP_STAMPS
         if (n_stamp_ < 7) RP_STAMP();  // short path: 3, 5, 7 = records of rounds 0, 1, 2 stored
 #endif
@@ -1419,26 +1324,9 @@ __global__ __launch_bounds__(kFinishBlock, sizeof(Source) != sizeof(CsrSource) ?
         double p[3] = {0, 0, 0}, q[3] = {0, 0, 0};
         int n[3] = {0, 0, 0}, m[3] = {0, 0, 0};
         FrameScore fr[3];
-        bool scored = false;  // the record already holds the frame scores (a whole-ORF segment's 32-byte record)
         if (len > 0) {
             const long long b_first = tile_of<TILE>(beg + plan.mis);
             const long long b_last = tile_of<TILE>(beg + len - 1 + plan.mis);
-#if RP_NARROW_RECORDS
-            if (b_first == b_last) {  // (the test k_tile_desc made for the descriptor's `whole` bit)
-                const uint4 w0 = ws.rec[orf + b_first], w1 = ws.rec[ws.n_rec + orf + b_first];
-                fr[0].score = (double)__uint_as_float(w0.x);
-                fr[2].score = (double)__uint_as_float(w0.y);
-                fr[1].score = (double)__uint_as_float(w1.x);
-                fr[0].n = (int)(w0.z & 0xffffu);
-                fr[2].n = (int)(w0.z >> 16);
-                fr[1].n = (int)(w1.z & 0xffffu);
-#pragma unroll
-                for (int f = 0; f < 3; ++f) fr[f].m = fr[f].score == fr[f].score ? fr[f].n : 0;  // (only ever asked: is it 0)
-                count = (long long)(((unsigned long long)w1.y << 16) + w0.w);
-                min_codon = (int)w1.w;
-                scored = true;
-            } else
-#endif
             for (long long b = b_first; b <= b_last; ++b) {  // tile order: deterministic sums
                 const uint4 w0 = ws.rec[rec_index(ws.n_rec, orf + b, 0)], w1 = ws.rec[rec_index(ws.n_rec, orf + b, 1)],
                             w2 = ws.rec[rec_index(ws.n_rec, orf + b, 2)];
@@ -1459,10 +1347,8 @@ __global__ __launch_bounds__(kFinishBlock, sizeof(Source) != sizeof(CsrSource) ?
             }
             if (b_last > b_first) split = RP_FLAG_SPLIT;
         }
-        if (!scored) {
 #pragma unroll
-            for (int f = 0; f < 3; ++f) fr[f] = frame_score(p[f], q[f], n[f], m[f]);
-        }
+        for (int f = 0; f < 3; ++f) fr[f] = frame_score(p[f], q[f], n[f], m[f]);
         double phase;
         int valid;
         unsigned flags;
