@@ -25,6 +25,33 @@ from . import _lib
 STRANDS = ("+", "-")
 
 
+class OtherStrand(tuple):
+    """``(strand, chrom)`` standing in for a chromosome name in a ``chroms`` list: rows filed under a strand key other
+    than '+' / '-'.  split_bam never makes one (bam.py:127-133), but the reference looks ``alignments[strand]`` up with
+    whatever the index line's strand column says (detect_orfs.py:176-187), so a hand-made mapping with such a key has
+    defined results.  The rows carry strand code 0 and this pair as their chromosome: every (strand, chrom) -> group
+    lookup below goes through :func:`group_lut`, which knows the convention; nothing on the device changes."""
+
+    __slots__ = ()
+
+
+def group_lut(chroms, group_keys) -> np.ndarray:
+    """``lut[strand_code, chrom_code]`` = group number of a candidate-ORF index (``group_keys`` = its (strand, chrom)
+    pairs), -1 where no ORF lives.  Shape (2, max(1, len(chroms)))."""
+    lut = np.full((2, max(1, len(chroms))), -1, np.int32)
+    where = {name: k for k, name in enumerate(chroms)}
+    for g, (strand, chrom) in enumerate(group_keys):
+        if strand in STRANDS:
+            k = where.get(chrom)
+            if k is not None and not isinstance(chroms[k], OtherStrand):
+                lut[STRANDS.index(strand), k] = g
+        else:
+            k = where.get(OtherStrand((strand, chrom)))
+            if k is not None and isinstance(chroms[k], OtherStrand):
+                lut[0, k] = g
+    return lut
+
+
 def _factorize(values):
     """(unique values in order of first appearance, int codes) -- hash based."""
     seen: dict = {}
@@ -75,11 +102,12 @@ class MergedColumns(NamedTuple):
         names: dict = {}
         name_list: list = []
         for strand, table in merged_alignments.items():
-            if not table or strand not in STRANDS:
+            if not table:
                 continue
+            other = strand not in STRANDS  # (class OtherStrand: filed under strand code 0 with (strand, chrom) as the name)
             n = len(table)
             done = False
-            if fast is not None:  # one PyDict_Next loop in C (csrc/rp_pydict.cpp)
+            if fast is not None and not other:  # one PyDict_Next loop in C (csrc/rp_pydict.cpp)
                 code = np.empty(n, np.int32)
                 pos = np.empty(n, np.int64)
                 cnt = np.empty(n, np.int64)
@@ -98,10 +126,12 @@ class MergedColumns(NamedTuple):
                 pos = np.fromiter(map(itemgetter(1), keys), np.int64, n)
                 cnt = np.fromiter(table.values(), np.int64, n)
                 local, code = _factorize(list(map(itemgetter(0), keys)))
+                if other:
+                    local = [OtherStrand((strand, c)) for c in local]
                 remap = np.array([names.setdefault(c, len(names)) for c in local], np.int32)
                 chrom_codes.append(remap[code])
                 name_list = list(names)
-            strands.append(np.full(n, STRANDS.index(strand), np.uint8))
+            strands.append(np.full(n, 0 if other else STRANDS.index(strand), np.uint8))
             poss.append(pos)
             counts.append(cnt)
         if not poss:
@@ -113,18 +143,17 @@ class MergedColumns(NamedTuple):
         """Back to ``strand -> Counter`` (for ``export_wig`` and other consumers of the reference's format)."""
         out = defaultdict(Counter)
         for s, c, p, n in zip(self.strand.tolist(), self.chrom.tolist(), self.pos.tolist(), self.count.tolist()):
-            out[STRANDS[s]][(self.chroms[c], p)] += n
+            name = self.chroms[c]
+            if isinstance(name, OtherStrand):
+                out[name[0]][(name[1], p)] += n
+            else:
+                out[STRANDS[s]][(name, p)] += n
         return out
 
     def group_codes(self, group_keys) -> np.ndarray:
         """Row -> group number of a candidate-ORF index (``NativeIndex.group_keys`` = (strand, chrom)
         pairs), -1 for rows on a (strand, chrom) no ORF lives on."""
-        lut = np.full((2, max(1, len(self.chroms))), -1, np.int32)
-        where = {name: k for k, name in enumerate(self.chroms)}
-        for g, (strand, chrom) in enumerate(group_keys):
-            if strand in STRANDS and chrom in where:
-                lut[STRANDS.index(strand), where[chrom]] = g
-        return lut[self.strand, self.chrom] if self.pos.size else np.zeros(0, np.int32)
+        return group_lut(self.chroms, group_keys)[self.strand, self.chrom] if self.pos.size else np.zeros(0, np.int32)
 
 
 class AlignmentColumns(NamedTuple):
@@ -165,7 +194,11 @@ class AlignmentColumns(NamedTuple):
     def as_nested(self):
         out = defaultdict(lambda: defaultdict(Counter))
         for ln, s, c, p, n in zip(self.length.tolist(), self.strand.tolist(), self.chrom.tolist(), self.pos.tolist(), self.count.tolist()):
-            out[ln][STRANDS[s]][(self.chroms[c], p)] += n
+            name = self.chroms[c]
+            if isinstance(name, OtherStrand):
+                out[ln][name[0]][(name[1], p)] += n
+            else:
+                out[ln][STRANDS[s]][(name, p)] += n
         return out
 
 
@@ -190,7 +223,10 @@ def merge_read_lengths(alignments, psite_offsets) -> MergedColumns:
     keep = lengths[at_c] == cols.length
     shift = offsets[at_c[keep]]
     strand = cols.strand[keep]
-    pos = cols.pos[keep] + np.where(strand == 0, shift, -shift)
+    forward = strand == 0
+    if any(isinstance(c, OtherStrand) for c in cols.chroms):  # only '+' moves downstream (detect_orfs.py:76-79)
+        forward &= ~np.array([isinstance(c, OtherStrand) for c in cols.chroms])[cols.chrom[keep]]
+    pos = cols.pos[keep] + np.where(forward, shift, -shift)
     return MergedColumns(strand, cols.chrom[keep], pos, cols.count[keep], list(cols.chroms))
 
 
@@ -297,11 +333,7 @@ def build_coverage_device(merged, index, device=None, big=None, cmap=None, out=N
     # without candidate ORFs is never a key of a lookup in the reference, whatever its count:
     # detect_orfs.py:176-187) and the adding-up -- happens on the device: the columns go up as they are.
     n_chroms = max(1, len(cols.chroms))
-    lut = np.full((2, n_chroms), -1, np.int32)
-    where = {name: k for k, name in enumerate(cols.chroms)}
-    for g, (strand, chrom) in enumerate(keys):
-        if strand in STRANDS and chrom in where:
-            lut[STRANDS.index(strand), where[chrom]] = g
+    lut = group_lut(cols.chroms, keys)
 
     def to_dev(a, dt):
         a = np.ascontiguousarray(a, dtype=dt)

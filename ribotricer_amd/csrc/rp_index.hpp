@@ -321,11 +321,19 @@ inline int parse_run(const char *text, size_t len, bool skip_header, Index &ix)
         for (size_t k = 1; k < blocks.size(); ++k) ascending = ascending && blocks[k - 1].first <= blocks[k].first;
         if (!ascending)
             std::stable_sort(blocks.begin(), blocks.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
-        int64_t length = 0;
+        // A block whose end lies below its start is parsable (orf.py:165-170 does not look): it counts with its raw
+        // -- negative -- size in the ORF id (orf.py:103) and contributes no position to the profile (detect_orfs.py:177:
+        // range(start, end + 1) is empty).  Such a block gets no interval here; an ORF made of nothing else has none
+        // and the profile length 0.  id_length = the sum the id prints, length = the positions the profile holds.
+        int64_t length = 0, id_length = 0, lo = INT64_MAX, hi = INT64_MIN;
         for (const auto &b : blocks) {
+            id_length += b.second - b.first + 1;
+            if (b.second < b.first) continue;
             ix.iv_start.push_back(b.first);
             ix.iv_end.push_back(b.second);
             length += b.second - b.first + 1;
+            lo = std::min(lo, b.first);
+            hi = std::max(hi, b.second);
         }
         const int64_t first = blocks.front().first, last = blocks.back().second;
         ix.orf_iv.push_back((int64_t)ix.iv_start.size());
@@ -337,8 +345,8 @@ inline int parse_run(const char *text, size_t len, bool skip_header, Index &ix)
         int32_t gid;
         if (last_gid >= 0 && strand == last_strand && chrom == last_chrom) {
             gid = last_gid;
-            ix.group_lo[gid] = std::min(ix.group_lo[gid], first);
-            ix.group_hi[gid] = std::max(ix.group_hi[gid], last);
+            ix.group_lo[gid] = std::min(ix.group_lo[gid], lo);
+            ix.group_hi[gid] = std::max(ix.group_hi[gid], hi);
         } else {
             key.assign(strand);
             key.push_back('\t');
@@ -349,12 +357,12 @@ inline int parse_run(const char *text, size_t len, bool skip_header, Index &ix)
                 groups.emplace(key, gid);
                 ix.group_names.append(key);
                 ix.group_off.push_back((int64_t)ix.group_names.size());
-                ix.group_lo.push_back(first);
-                ix.group_hi.push_back(last);
+                ix.group_lo.push_back(lo);  // (INT64_MAX / INT64_MIN while the group has no interval: close_extents)
+                ix.group_hi.push_back(hi);
             } else {
                 gid = it->second;
-                ix.group_lo[gid] = std::min(ix.group_lo[gid], first);
-                ix.group_hi[gid] = std::max(ix.group_hi[gid], last);
+                ix.group_lo[gid] = std::min(ix.group_lo[gid], lo);
+                ix.group_hi[gid] = std::max(ix.group_hi[gid], hi);
             }
             last_gid = gid;
             last_strand = strand;  // (views into `text`, which outlives the run)
@@ -365,13 +373,13 @@ inline int parse_run(const char *text, size_t len, bool skip_header, Index &ix)
         std::memcpy(head_at, f[2].data(), f[2].size());
         head_at += f[2].size();
         *head_at++ = '_';
-        if (first < 0 || last < 0 || length < 0) {  // (cannot come out of parse_int / scan_coordinates; kept for the general writer's sake)
+        if (first < 0 || last < 0 || id_length < 0) {  // (a negative sum: blocks with end < start, e.g. tx_10_5_-4)
             Vec<char> tmp;
             append_int(tmp, first);
             tmp.push_back('_');
             append_int(tmp, last);
             tmp.push_back('_');
-            append_int(tmp, length);
+            append_int(tmp, id_length);
             std::memcpy(head_at, tmp.data(), tmp.size());
             head_at += tmp.size();
         } else {
@@ -379,7 +387,7 @@ inline int parse_run(const char *text, size_t len, bool skip_header, Index &ix)
             *head_at++ = '_';
             head_at = put_int(head_at, last);
             *head_at++ = '_';
-            head_at = put_int(head_at, length);
+            head_at = put_int(head_at, id_length);
         }
         *head_at++ = '\t';
         std::memcpy(head_at, f[1].data(), f[1].size());
@@ -410,6 +418,14 @@ inline int64_t count_lines(const char *text, size_t len)
     return n;
 }
 
+// A (strand, chromosome) whose ORFs hold no position at all (every block with end < start) leaves parse_run with the
+// extent (INT64_MAX, INT64_MIN): one position, never looked up, stands in for it.
+inline void close_extents(Index &ix)
+{
+    for (size_t g = 0; g < ix.group_lo.size(); ++g)
+        if (ix.group_lo[g] > ix.group_hi[g]) ix.group_lo[g] = ix.group_hi[g] = 1;
+}
+
 // The whole index text: cut into runs of whole lines, one per thread, parsed independently and
 // stitched together in file order -- same arrays, same group numbering (first appearance in the
 // file) and the same first malformed line as one sequential pass.  The stitch runs on the same
@@ -424,7 +440,11 @@ inline int parse(const char *text, size_t len, bool skip_header, Index &ix, int 
     }
     const size_t min_run = (size_t)4 << 20;
     if ((size_t)threads > len / min_run) threads = (int)(len / min_run);
-    if (threads <= 1) return parse_run(text, len, skip_header, ix);
+    if (threads <= 1) {
+        const int rc = parse_run(text, len, skip_header, ix);
+        close_extents(ix);
+        return rc;
+    }
     std::vector<size_t> cut(threads + 1, len);
     cut[0] = 0;
     for (int t = 1; t < threads; ++t) {  // the first line start at or after t/threads of the text
@@ -520,6 +540,7 @@ inline int parse(const char *text, size_t len, bool skip_header, Index &ix, int 
             });
         for (auto &th : pool) th.join();
     }
+    close_extents(ix);
     return kOk;
 }
 

@@ -131,7 +131,7 @@ def orf_coverage(orf: IndexRecord, alignments, offset_5p: int = 0, offset_3p: in
 
 def pack_profiles(records, merged_alignments):
     """CSR-pack the profiles of all records: ``(counts int32[sum L], offsets int64[n+1])``."""
-    lengths = np.fromiter((sum(e - s + 1 for s, e in r.intervals) for r in records), np.int64, len(records))
+    lengths = np.fromiter((sum(max(0, e - s + 1) for s, e in r.intervals) for r in records), np.int64, len(records))  # (end < start: no positions)
     offsets = np.zeros(len(records) + 1, np.int64)
     np.cumsum(lengths, out=offsets[1:])
     counts = np.zeros(int(offsets[-1]), np.int32)
@@ -666,7 +666,7 @@ def export_wig(merged_alignments, prefix: str) -> None:
     counts as ``{prefix}_pos.wig`` / ``{prefix}_neg.wig``, variableStep, sorted by (chrom, pos).
     ``merged_alignments``: the reference's ``strand -> Counter`` or ``alignments.MergedColumns``
     (rows naming one position are added up first, vectorised)."""
-    from .alignments import STRANDS, MergedColumns
+    from .alignments import STRANDS, MergedColumns, OtherStrand
 
     import ctypes
 
@@ -674,6 +674,19 @@ def export_wig(merged_alignments, prefix: str) -> None:
 
     lib = _lib.load()
     cols = merged_alignments if isinstance(merged_alignments, MergedColumns) else MergedColumns.from_counters(merged_alignments)
+    if any(isinstance(c, OtherStrand) for c in cols.chroms):
+        # a strand key other than '+' / '-' (never out of split_bam): every strand that is not '+' goes to _neg.wig, one
+        # after the other in the mapping's order, the last one staying (detect_orfs.py:338-352).  No fast path for that.
+        by_strand = merged_alignments if not isinstance(merged_alignments, MergedColumns) else cols.as_counters()
+        for strand, table in by_strand.items():
+            with open(f"{prefix}_pos.wig" if strand == "+" else f"{prefix}_neg.wig", "w") as output:
+                section = ""  # (a chromosome named "" gets no header of its own at the top: the reference starts from "")
+                for chrom, pos in sorted(table):
+                    if chrom != section:
+                        section = chrom
+                        output.write(f"variableStep chrom={chrom}\n")
+                    output.write(f"{pos}\t{table[(chrom, pos)]}\n")
+        return
     names = np.asarray(cols.chroms, dtype=object)
     rank = np.argsort(np.argsort(names)) if names.size else np.zeros(0, np.int64)  # sorted() orders by chromosome NAME
     inv = np.empty(names.size, np.int64)

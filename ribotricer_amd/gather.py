@@ -43,7 +43,8 @@ def build_dense_coverage(merged_alignments, records):
     extent: dict = {}
     for r in records:
         key = (r.strand, r.chrom)
-        lo, hi = r.intervals[0][0], r.intervals[-1][1]
+        real = [(s, e) for s, e in r.intervals if e >= s] or [(1, 1)]  # (blocks with end < start hold no position)
+        lo, hi = min(s for s, _ in real), max(e for _, e in real)  # (an exon nested in an earlier one ends before it)
         if key in extent:
             e = extent[key]
             extent[key] = (min(e[0], lo), max(e[1], hi))
@@ -124,7 +125,7 @@ def _factorize(values):
 
 def build_interval_table(records, base) -> IntervalTable:
     n = len(records)
-    n_iv = sum(len(r.intervals) for r in records)
+    n_iv = sum(1 for r in records for s, e in r.intervals if e >= s)  # (a block with end < start holds no position: no interval)
     iv_start = np.empty(n_iv, np.int64)
     iv_len = np.empty(n_iv, np.int32)
     orf_iv = np.zeros(n + 1, np.int64)
@@ -134,6 +135,8 @@ def build_interval_table(records, base) -> IntervalTable:
     for i, r in enumerate(records):
         start0, lo = base[(r.strand, r.chrom)]
         for s, e in r.intervals:  # ascending (orf.py:100)
+            if e < s:
+                continue
             iv_start[k] = start0 + (s - lo)
             iv_len[k] = e - s + 1
             lengths[i] += e - s + 1

@@ -1,0 +1,100 @@
+"""Container-only cross-check (needs /root/reference, which does not travel; not collected by pytest):
+INTEGRATION.md section 2, VERBATIM -- eight names of the reference's own modules rebound to this package -- and then the
+REFERENCE's orchestrator `ribotricer.detect_orfs.detect_orfs()` (detect_orfs.py:354-526) run on a BAM holding the G7
+reads: its six outputs must equal tests/golden/g7_expected_* (which the unpatched reference wrote) byte for byte, and the
+reference's two plot functions must accept the package's return types.  GPU-less backend here.
+
+usage: python tests/golden/check_integration_vs_reference.py       exit 0 = all identical"""
+import os
+import sys
+import tempfile
+import types
+from collections import Counter, defaultdict
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests", "tools"))
+sys.path.insert(0, os.environ.get("RIBOTRICER_REFERENCE", "/root/reference"))
+os.environ["RIBOTRICER_AMD_BACKEND"] = "cpu"
+os.environ.setdefault("MPLBACKEND", "Agg")
+
+# pysam / quicksect are not installed in this image; the orchestrator only touches them through split_bam (rebound
+# below) and through the interval tree of annotated genes that infer_protocol would query (skipped: protocol given)
+for _m in ("pysam", "quicksect"):
+    sys.modules.setdefault(_m, types.ModuleType(_m))
+
+
+class _Tree:
+    def insert(self, *_):
+        pass
+
+
+sys.modules["quicksect"].Interval = lambda *a: a
+sys.modules["quicksect"].IntervalTree = _Tree
+
+# ---- INTEGRATION.md section 2, as printed there -------------------------------------------------------------------
+import ribotricer.detect_orfs as ref  # noqa: E402
+import ribotricer.statistics as ref_stats  # noqa: E402
+import ribotricer_amd.detect_orfs as amd  # noqa: E402
+import ribotricer_amd.statistics as amd_stats  # noqa: E402
+import ribotricer_amd.alignments as amd_al  # noqa: E402
+import ribotricer_amd.metagene as amd_mg  # noqa: E402
+
+ref.export_orf_coverages = amd.export_orf_coverages   # the hot loop -> one GPU launch
+ref.merge_read_lengths = amd_al.merge_read_lengths     # columns instead of Counter arithmetic
+ref.export_wig = amd.export_wig
+ref.split_bam = amd_al.split_bam                       # native BAM reader (no pysam)
+ref.metagene_coverage = amd_mg.metagene_coverage       # metagene profiles on the GPU
+ref.align_metagenes = amd_mg.align_metagenes
+ref.phasescore = amd_stats.phasescore                  # name imported at detect_orfs.py:37
+ref_stats.phasescore = amd_stats.phasescore            # metagene.py:243-244 float profiles
+# -------------------------------------------------------------------------------------------------------------------
+
+from bamwriter import write_bam  # noqa: E402
+
+import json  # noqa: E402
+
+params = json.load(open(os.path.join(HERE, "g7_params.json")))
+nested = defaultdict(lambda: defaultdict(Counter))
+with open(os.path.join(HERE, "g7_alignments.tsv")) as fh:
+    fh.readline()
+    for line in fh:
+        length, strand, chrom, pos, count = line.rstrip("\n").split("\t")
+        nested[int(length)][strand][(chrom, int(pos))] = int(count)
+rng = np.random.default_rng(3)
+reads = []
+for length in sorted(nested):
+    for strand in nested[length]:
+        for (chrom, pos), count in nested[length][strand].items():
+            for _ in range(count):  # forward protocol: '+' reads start at pos, '-' reads END at pos
+                reads.append(dict(name="r", chrom=chrom, pos=pos - 1 if strand == "+" else pos - length, flag=0 if strand == "+" else 16,
+                                  mapq=255, cigar=[("M", length)], tags={"NH": ("C", 1)} if rng.random() < 0.5 else {}))
+# lengths are met in the order the reference's generator met them (its dict order decides the line order of the offsets report)
+lead = []
+for length in [int(k) for k in params["psite_offsets"]]:
+    k = next(i for i, r in enumerate(reads) if r["cigar"][0][1] == length)
+    lead.append(reads.pop(k))
+order = rng.permutation(len(reads))
+bad = 0
+with tempfile.TemporaryDirectory() as tmp:
+    bam = os.path.join(tmp, "g7.bam")
+    write_bam(bam, [("chrI", 400000), ("chrII", 400000), ("chrM", 400000)], lead + [reads[i] for i in order])
+    prefix = os.path.join(tmp, "out", "g7")
+    # the reference's orchestrator, its own argument order (detect_orfs.py:354-369)
+    ref.detect_orfs(bam, os.path.join(HERE, "g6_index.tsv"), prefix, "forward", None, None, 0.428571428571, 5, 0, 0, 0.0, True,
+                    params["meta_min_reads"])
+    for name in ("metagene_profiles_5p.tsv", "metagene_profiles_3p.tsv", "psite_offsets.txt", "pos.wig", "neg.wig", "translating_ORFs.tsv"):
+        got = open(f"{prefix}_{name}", "rb").read()
+        want = open(os.path.join(HERE, f"g7_expected_{name}"), "rb").read()
+        same = got == want
+        bad += not same
+        print(f"{'ok  ' if same else 'DIFF'} {name}: {len(got)} bytes")
+    for name in ("read_length_dist.pdf", "metagene_plots.pdf"):  # the reference's plots took the package's return types
+        ok = os.path.getsize(f"{prefix}_{name}") > 0
+        bad += not ok
+        print(f"{'ok  ' if ok else 'MISSING'} {name}")
+print("integration check:", "all identical" if not bad else f"{bad} differences")
+sys.exit(1 if bad else 0)

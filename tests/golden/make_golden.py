@@ -25,6 +25,8 @@ Fixture sets:
   g8_float_ties.json     400 float-valued profiles built to tie
   g10_bigcounts.npz      240 profiles holding counts 2^24 .. 2^30 (beyond the fp32-exact range of the kernels)
   g10_*                  end-to-end: the g6 index + its alignments with such counts piled on 16 ORFs + the reference's TSVs
+  g12_*                  end-to-end on a 1 500-line index from random_index.py (format corners, malformed-but-parsable
+                         lines) + alignments + the reference's three TSVs (gzip)
 """
 
 from __future__ import annotations
@@ -556,7 +558,32 @@ def g10():
         print(f"g10_expected_{name}.tsv: {text.count(chr(10)) - 1} rows, {len(extra)} piles added")
 
 
+def g12():
+    """A fresh index from tests/golden/random_index.py -- 1 500 lines leaning on the format's corners (abutting /
+    overlapping / duplicated exons, reversed lists, 1-nt exons, L % 3 != 0, a '.' strand, blocks with end < start,
+    dressed numbers) -- with its alignments and the reference's three TSVs (gzip: ~3 MB of text otherwise)."""
+    import gzip
+
+    sys.path.insert(0, HERE)
+    from random_index import PARAM_SETS, random_index, write_alignments
+
+    text, merged = random_index(1500, seed=1212, malformed=0.08, dressed=0.05)
+    index_path = os.path.join(HERE, "g12_index.tsv")
+    with open(index_path, "w", newline="") as fh:
+        fh.write(text)
+    write_alignments(os.path.join(HERE, "g12_alignments.tsv.gz"), merged)
+    for name, kw in PARAM_SETS.items():
+        with tempfile.TemporaryDirectory() as tmp:
+            prefix = os.path.join(tmp, "out")
+            export_orf_coverages(index_path, merged, prefix, **kw)  # the reference (detect_orfs.py:206-324)
+            data = open(prefix + "_translating_ORFs.tsv", "rb").read()
+        with open(os.path.join(HERE, f"g12_expected_{name}.tsv.gz"), "wb") as raw:
+            with gzip.GzipFile(fileobj=raw, mode="wb", mtime=0, filename="") as dst:
+                dst.write(data)
+        print(f"g12_expected_{name}.tsv.gz: {data.count(bytes([10])) - 1} rows, {len(data)} bytes of text")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g10", "g12"]
     for name in which:
         globals()[name]()

@@ -74,3 +74,40 @@ def assert_matches_fixture(res, g, phase_tol=1e-6):
     assert not bad.any(), f"valid_codons differs from the reference on {bad.sum()} ORFs ({(bad & tie).sum()} of them tie-flagged)"
     assert np.array_equal(res["phase"][tie], g["phase"][tie]), "replayed phase scores must be the reference's bits"
     return tie
+
+
+def g12_alignments():
+    """The merged alignments of fixture G12 (tests/golden/make_golden.py::g12): strand -> Counter, a '.' strand included."""
+    import os
+    import sys
+
+    from conftest import GOLDEN
+
+    if GOLDEN not in sys.path:
+        sys.path.insert(0, GOLDEN)
+    from random_index import read_alignments
+
+    return read_alignments(os.path.join(GOLDEN, "g12_alignments.tsv.gz"))
+
+
+def g12_expected(name: str) -> bytes:
+    """The TSV the REFERENCE wrote for G12 under parameter set `name` (random_index.PARAM_SETS)."""
+    import gzip
+    import os
+
+    from conftest import GOLDEN
+
+    with gzip.open(os.path.join(GOLDEN, f"g12_expected_{name}.tsv.gz"), "rb") as fh:
+        return fh.read()
+
+
+def g12_params(name: str) -> dict:
+    import sys
+
+    from conftest import GOLDEN
+
+    if GOLDEN not in sys.path:
+        sys.path.insert(0, GOLDEN)
+    from random_index import PARAM_SETS
+
+    return dict(PARAM_SETS[name])

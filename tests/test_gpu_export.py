@@ -215,6 +215,58 @@ def test_export_edge_indexes(tmp_path):
     assert f[17] == str([0] * 9 + [0, 0, 0, 0, 0, 0, 5, 0, 0])
 
 
+def test_export_line_with_end_below_start(tmp_path):
+    """`10-5` on the HIP path, one GPU and three slices: the rows the reference prints (orf.py:100-103: the id keeps the raw
+    sum; detect_orfs.py:176-187: no positions from such a block) -- tests/test_host_backend_cpu.py holds the same rows."""
+    from collections import Counter, defaultdict
+
+    from ribotricer_amd import detect_orfs as d
+
+    header = "ORF_ID\tORF_type\ttranscript_id\ttranscript_type\tgene_id\tgene_name\tgene_type\tchrom\tstrand\tstart_codon\tcoordinate\n"
+    index = tmp_path / "bad_candidate_orfs.tsv"
+    index.write_text(header + "x\tannotated\ttx\tpc\tg\tn\tpc\tchr1\t+\tATG\t10-5\n"
+                     + "y\tnovel\tty\tpc\tg\tn\tpc\tchr9\t-\tATG\t40-31\n"
+                     + "z\tuORF\ttz\tpc\tg\tn\tpc\tchr1\t+\tATG\t30-25,100-105\n"
+                     + "w\tuORF\ttw\tpc\tg\tn\tpc\tchr1\t+\tATG\t" + ",".join(f"{200 + 9 * k}-{205 + 9 * k}" for k in range(12)) + ",9-3\n")
+    align = defaultdict(Counter)
+    align["+"][("chr1", 100)] = 4
+    align["+"][("chr1", 7)] = 2
+    for k in range(12):
+        align["+"][("chr1", 200 + 9 * k)] = 3 + k
+        align["+"][("chr1", 203 + 9 * k)] = 2
+    for tag, devices, report_all in (("one", None, True), ("three", [0, 0, 0], True), ("one_d", None, False), ("three_d", [0, 0, 0], False)):
+        d._INDEX_CACHE.clear()
+        d.export_orf_coverages(str(index), align, str(tmp_path / tag), report_all=report_all, devices=devices)
+        rows = [r.split("\t") for r in (tmp_path / f"{tag}_translating_ORFs.tsv").read_text().splitlines()[1:]]
+        if report_all:
+            assert rows[0][:9] == ["tx_10_5_-4", "annotated", "nontranslating", "0.0", "0", "0", "0", "0.0", "0.0"] and rows[0][17] == "[]"
+            assert rows[1][:9] == ["ty_40_31_-8", "novel", "nontranslating", "0.0", "0", "0", "0", "0.0", "0.0"] and rows[1][17] == "[]"
+            assert rows[2][:9] == ["tz_30_105_2", "uORF", "nontranslating", "0.0", "4", "6", "0", "0.0", "2.0"] and rows[2][17] == "[4, 0, 0, 0, 0, 0]"
+        assert len(rows) == (4 if report_all else 1)
+        w = rows[-1]  # sorted by start the bad block comes first: id tw_9_304_{72 - 5}; a frame tie (valid 23, not 24) as the reference decides it
+        assert w[:3] == ["tw_9_304_67", "uORF", "translating"] and w[4:9] == ["126", "72", "23", "0.9583333333333334", "5.25"]
+        assert abs(float(w[3]) - 1.0000000000000007) <= 1e-6
+    d._INDEX_CACHE.clear()
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+@pytest.mark.parametrize("name", ["default", "report_all", "strict"])
+def test_export_of_the_corner_index_g12_matches_reference(tmp_path, name, devices):
+    """G12 on the HIP path (one GPU; three slices of it): 1 500 lines from tests/golden/random_index.py -- overlapping /
+    nested / duplicated / abutting / 1-nt exons, shuffled lists, a '.' strand with reads of its own, blocks with end < start,
+    dressed numbers -- against the three TSVs the REFERENCE wrote: every column the same text, the phase score within 1e-6."""
+    from helpers import g12_alignments, g12_expected, g12_params
+    from ribotricer_amd import detect_orfs as d
+
+    d._INDEX_CACHE.clear()
+    prefix = str(tmp_path / "out")
+    timings = {}
+    d.export_orf_coverages(os.path.join(GOLDEN, "g12_index.tsv"), g12_alignments(), prefix, devices=devices, timings=timings, **g12_params(name))
+    assert timings["backend"] == "hip"
+    same_rows(g12_expected(name).decode(), open(prefix + "_translating_ORFs.tsv").read())
+    d._INDEX_CACHE.clear()
+
+
 def same_rows(a_text: str, b_text: str, tol: float = 1e-6) -> None:
     a_rows, b_rows = a_text.splitlines(), b_text.splitlines()
     assert len(a_rows) == len(b_rows) and a_rows[0] == b_rows[0]

@@ -49,6 +49,49 @@ def test_cpu_backend_writes_the_reference_bytes(tmp_path, cpu_backend, fixture, 
         assert got == fh.read()
 
 
+@pytest.mark.parametrize("name", ["default", "report_all", "strict"])
+def test_cpu_backend_on_the_corner_index_g12(tmp_path, cpu_backend, name):
+    """G12: 1 500 lines from tests/golden/random_index.py -- overlapping / duplicated / abutting / 1-nt exons, shuffled
+    lists, a '.' strand with reads of its own, blocks with end < start (alone: a row of length 0 with the raw sum in its
+    id, orf.py:103; among others: no positions from it), numbers spelled '+12' / '0012' / ' 12' -- byte for byte what the
+    reference wrote."""
+    from helpers import g12_alignments, g12_expected, g12_params
+    from ribotricer_amd.detect_orfs import export_orf_coverages
+
+    prefix = str(tmp_path / "out")
+    export_orf_coverages(os.path.join(GOLDEN, "g12_index.tsv"), g12_alignments(), prefix, **g12_params(name))
+    with open(prefix + "_translating_ORFs.tsv", "rb") as fh:
+        got = fh.read()
+    assert got == g12_expected(name)
+    if name == "report_all":
+        rows = [r.split(b"\t") for r in got.split(b"\n")[1:-1]]
+        empty = [r for r in rows if r[5] == b"0"]  # nothing but end < start blocks
+        assert len(empty) >= 20 and all(r[17] == b"[]" and r[2] == b"nontranslating" and int(r[0].rsplit(b"_", 1)[1]) <= 0 for r in empty)
+
+
+def test_cpu_backend_line_with_end_below_start(tmp_path, cpu_backend):
+    """`10-5`: the reference writes tx_10_5_-4 / nontranslating / 0.0 / length 0 / [] (orf.py:100-103, detect_orfs.py:176-187:
+    range(10, 6) is empty); beside a real block the bad one only shows in the id's sum.  Expected rows: what the reference
+    printed for these three lines (run in the build container)."""
+    from collections import Counter, defaultdict
+
+    from ribotricer_amd.detect_orfs import export_orf_coverages
+
+    header = "ORF_ID\tORF_type\ttranscript_id\ttranscript_type\tgene_id\tgene_name\tgene_type\tchrom\tstrand\tstart_codon\tcoordinate\n"
+    index = tmp_path / "bad_candidate_orfs.tsv"
+    index.write_text(header + "x\tannotated\ttx\tpc\tg\tn\tpc\tchr1\t+\tATG\t10-5\n"
+                     + "y\tnovel\tty\tpc\tg\tn\tpc\tchr9\t-\tATG\t40-31\n"  # its (strand, chrom) holds nothing else
+                     + "z\tuORF\ttz\tpc\tg\tn\tpc\tchr1\t+\tATG\t30-25,100-105\n")
+    align = defaultdict(Counter)
+    align["+"][("chr1", 100)] = 4
+    align["+"][("chr1", 7)] = 2
+    export_orf_coverages(str(index), align, str(tmp_path / "o"), report_all=True)
+    rows = [r.split("\t") for r in (tmp_path / "o_translating_ORFs.tsv").read_text().splitlines()[1:]]
+    assert rows[0][:9] == ["tx_10_5_-4", "annotated", "nontranslating", "0.0", "0", "0", "0", "0.0", "0.0"] and rows[0][17] == "[]"
+    assert rows[1][:9] == ["ty_40_31_-8", "novel", "nontranslating", "0.0", "0", "0", "0", "0.0", "0.0"] and rows[1][17] == "[]"
+    assert rows[2][:9] == ["tz_30_105_2", "uORF", "nontranslating", "0.0", "4", "6", "0", "0.0", "2.0"] and rows[2][17] == "[4, 0, 0, 0, 0, 0]"
+
+
 def test_cpu_backend_takes_columns_as_well(tmp_path, cpu_backend):
     """The package's own hand-over format (alignments.MergedColumns) with rows of several read lengths on one position."""
     from ribotricer_amd.alignments import MergedColumns
