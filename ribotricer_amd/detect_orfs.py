@@ -302,6 +302,8 @@ def export_orf_coverages(
         return
     if devices is None:
         devices = _devices_from_env()
+    if timings is not None:
+        timings["backend"] = "hip"
     t0 = time.perf_counter()
     # the alignment columns go up to the device (and a Counter input becomes columns first) BESIDE the index parse:
     # neither needs the other (the parser is C++ without the GIL, the copies release it too)

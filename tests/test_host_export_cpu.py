@@ -199,6 +199,43 @@ def test_native_rows_ragged_and_empty():
     assert none == []
 
 
+def test_derived_columns_on_the_rows_the_reference_publishes():
+    """The only result rows the reference itself holds: the first five of SRX219170_translating_ORFs.tsv as its plotting
+    notebook displays them (notebooks/Plotting_ribotricer_profile.ipynb:348-396; pandas shows 6 decimals, the profile
+    column cut after ~14 counts).  They pin the identities of the derived columns (detect_orfs.py:281-287): length = the
+    id's last field, valid_codons_ratio = valid_codons / (length // 3), read_density = read_count / (length // 3)."""
+    from ribotricer_amd import tsv
+
+    published = [  # (ORF_ID, ORF_type, phase_score, read_count, length, valid_codons, valid_codons_ratio, read_density, displayed profile head)
+        ("AT4G15610.2_8909332_8909406_75", "uORF", 0.855545, 746, 75, 25, 1.0, 29.840000, [17, 2, 4, 21, 3, 2, 11, 12, 0, 16, 3, 1, 8, 4]),
+        ("AT1G68530.2_25712993_25713052_60", "dORF", 0.819610, 199, 60, 20, 1.0, 9.950000, [12, 3, 1, 10, 1, 1, 5, 7, 1, 6, 1, 2, 3, 0, 4]),
+        ("AT5G48485.1_19646320_19646625_306", "annotated", 0.803626, 2094, 306, 102, 1.0, 20.529412, [9, 0, 4, 0, 0, 1, 1, 1, 4, 6, 5, 6, 0, 0, 1]),
+        ("AT1G60950.1_22444565_22445008_444", "annotated", 0.861726, 7208, 444, 148, 1.0, 48.702703, [55, 2, 9, 6, 3, 11, 4, 4, 33, 3, 7, 26, 5, 3]),
+        ("AT1G62660.2_23200187_23200300_114", "uORF", 0.821548, 589, 114, 38, 1.0, 15.500000, [2, 7, 2, 1, 10, 0, 0, 30, 3, 1, 15, 2, 1, 14]),
+    ]
+    profiles = []
+    for _, _, _, reads, length, _, _, _, head in published:  # the displayed head, the rest of the reads spread over the tail
+        tail, left = length - len(head), reads - sum(head)
+        rest = np.full(tail, left // tail, np.int32)
+        rest[: left % tail] += 1
+        profiles.append(np.concatenate([np.array(head, np.int32), rest]))
+    counts = np.concatenate(profiles)
+    offsets = np.concatenate([[0], np.cumsum([p.size for p in profiles])]).astype(np.int64)
+    phase = np.array([r[2] for r in published])
+    valid = np.array([r[5] for r in published], np.int32)
+    reads = np.array([r[3] for r in published], np.int64)
+    tables = (*tsv.string_table([f"{r[0]}\t{r[1]}" for r in published]), *tsv.string_table(["t"] * 5))
+    body = b"".join(tsv.format_rows_native(counts, offsets, phase, valid, reads, np.ones(5, np.uint8), tables, False)).decode()
+    rows = [r.split("\t") for r in body.rstrip("\n").split("\n")]
+    assert len(rows) == 5
+    for row, (oid, otype, score, n_reads, length, n_valid, ratio, density, head) in zip(rows, published):
+        assert row[:3] == [oid, otype, "translating"] and float(row[3]) == score
+        assert row[4:7] == [str(n_reads), str(length), str(n_valid)] and int(oid.rsplit("_", 1)[1]) == length
+        assert float(row[7]) == ratio and row[7] == "1.0"
+        assert f"{float(row[8]):.6f}" == f"{density:.6f}" and row[8] == repr(n_reads / (length // 3))
+        assert row[-1].startswith(str(head)[:-1] + ", ")
+
+
 # ---- native index parser (SURVEY 8(f) f3) ----------------------------------------------
 
 def test_native_index_equals_python_parser(packed):
