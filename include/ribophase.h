@@ -74,6 +74,8 @@ typedef enum rp_status {
                                   replay of the reference's own float64 (numpy / scipy) arithmetic */
 #define RP_FLAG_BIGCOUNT 0x20u /* set by the Python layer (never by a kernel): the ORF holds a count beyond RP_MAX_COUNT and
                                   its results were recomputed in float64 / int64 (engine.rescore_big_count_orfs) */
+#define RP_FLAG_UNRESOLVED 0x40u /* only with RP_FILTER_PRINTED_ONLY: too close to call in fp32 and left at that, because
+                                   no resolution could make the ORF translating (status is 0 for certain) */
 #define RP_FLAG_BIGTIE 0x10u   /* the replay met a codon with a count >= 16: the reference squares through
                                   the host C library's pow() (statistics.py:83), which the device cannot
                                   restate past its host-filled table; phase / valid_codons stand on x*x
@@ -109,8 +111,20 @@ typedef struct rp_filter_params {
     double min_density_over_orf;   /* const.py:39  0.0 */
     double min_reads_per_codon;    /* const.py:32  0 */
     int32_t min_valid_codons;      /* const.py:27  5 */
-    int32_t reserved;
+    int32_t flags;                 /* RP_FILTER_* bits; 0 = every ORF fully resolved */
 } rp_filter_params;
+
+/*
+ * rp_filter_params.flags.  RP_FILTER_PRINTED_ONLY: the caller prints translating ORFs only (the reference's default,
+ * detect_orfs.py:301-302: `if status == "nontranslating" and not report_all: continue`).  An ORF whose frame decision is too close to
+ * call in fp32 is then NOT re-walked in float64 / replayed when no outcome of that decision could make it translating
+ * (every frame's N below min_valid_codons, every frame's score below the cutoff by more than the fp32 margin, or an
+ * integer condition failing): its status is 0 either way.  Such ORFs carry RP_FLAG_UNRESOLVED; their phase is the fp32
+ * tile sums' (within 1e-5 of the reference), their valid_codons one of the tied frames' N.  Everything else -- every ORF
+ * with status 1, every unflagged ORF -- is exactly what flags = 0 gives.  Device tile path only; the host entry points and
+ * the wave kernel resolve everything regardless.
+ */
+#define RP_FILTER_PRINTED_ONLY 0x1
 
 /* Library / error introspection. */
 const char *rp_version(void);

@@ -25,6 +25,8 @@ FLAG_SPLIT = 0x04
 FLAG_REPLAY = 0x08
 FLAG_BIGTIE = 0x10
 FLAG_BIGCOUNT = 0x20
+FLAG_UNRESOLVED = 0x40  # only with FILTER_PRINTED_ONLY: too close to call, left at the fp32 result because status is 0 for certain
+FILTER_PRINTED_ONLY = 0x1  # rp_filter_params.flags: the caller prints translating ORFs only (include/ribophase.h)
 MIN_CODON_COV_EMPTY = 2147483647
 MAX_COUNT = 16777215
 ERR_INTERVALS = -12
@@ -48,7 +50,7 @@ class FilterParams(ctypes.Structure):
         ("min_density_over_orf", ctypes.c_double),
         ("min_reads_per_codon", ctypes.c_double),
         ("min_valid_codons", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("flags", ctypes.c_int32),  # FILTER_* bits
     ]
 
 

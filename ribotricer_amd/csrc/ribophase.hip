@@ -158,6 +158,7 @@ rp::FilterParams make_filter(const rp_filter_params *f, const uint8_t *d_status)
         fp.min_reads_per_codon = f->min_reads_per_codon;
         fp.min_valid_codons = f->min_valid_codons;
         fp.enabled = 1;
+        fp.printed_only = (f->flags & RP_FILTER_PRINTED_ONLY) ? 1 : 0;
     }
     return fp;
 }
@@ -459,7 +460,7 @@ int rp_filter_defaults(rp_filter_params *out)
     out->min_density_over_orf = 0.0;           // const.py:39
     out->min_reads_per_codon = 0.0;            // const.py:32
     out->min_valid_codons = 5;                 // const.py:27
-    out->reserved = 0;
+    out->flags = 0;
     return RP_OK;
 }
 

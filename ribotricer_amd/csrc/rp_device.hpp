@@ -502,7 +502,9 @@ struct FilterParams {
     double min_density_over_orf;
     double min_reads_per_codon;
     int min_valid_codons;
-    int enabled;
+    int enabled;       // thresholds given and a status array to fill
+    int printed_only;  // rp_filter_params.flags & RP_FILTER_PRINTED_ONLY (and enabled)
+    int pad_;
 };
 
 __device__ __forceinline__ unsigned char orf_status(const FilterParams &fp, double phase, int valid,
@@ -527,6 +529,31 @@ __device__ __forceinline__ unsigned char orf_status(const FilterParams &fp, doub
 __device__ __forceinline__ bool near_cutoff(const FilterParams &fp, double phase)
 {
     return fp.enabled && fabs(phase - fp.phase_score_cutoff) <= kCutoffMargin;
+}
+
+// RP_FILTER_PRINTED_ONLY: can NO resolution of this ORF's frame decision make it "translating"?  Whatever the float64
+// re-walk or the tie replay would return, valid_codons is the N of one of the three frames (or 0 after a reset,
+// statistics.py:94-95,109-113) and the phase score is the root of one frame's score (or 0); read_count, min_codon_cov
+// and the length are exact integers already.  So the ORF is nontranslating for sure (detect_orfs.py:289-299) when
+//   max_f N_f < min_valid_codons,  or  max_f N_f / n_codons < min_valid_codons_ratio,  or an integer condition fails,
+//   or  max_f sqrt(score_f) lies below the cutoff by more than the fp32 error margin (kCutoffMargin).
+// In default mode (detect_orfs.py:301-302: only translating rows are printed) such an ORF prints nothing either way.
+__device__ __forceinline__ bool cannot_be_translating(const FilterParams &fp, const FrameScore (&fr)[3], long long read_count,
+                                                      int min_codon_cov, long long length)
+{
+    const int n_max = max(fr[0].n, max(fr[1].n, fr[2].n));
+    if (n_max < fp.min_valid_codons || (double)min_codon_cov < fp.min_reads_per_codon) return true;
+    if (fp.min_valid_codons_ratio > 0.0 || fp.min_density_over_orf > 0.0) {
+        const long long n_codons = (length / 3) > 1 ? (length / 3) : 1;
+        if (!((double)n_max / (double)n_codons >= fp.min_valid_codons_ratio) ||
+            !((double)read_count / (double)n_codons >= fp.min_density_over_orf))
+            return true;
+    }
+    double s_max = 0.0;
+#pragma unroll
+    for (int f = 0; f < 3; ++f) s_max = fmax(s_max, fr[f].score);  // (fmax ignores the NaN of an all-flat frame: it never wins)
+    const double phase_max = s_max > 0.0 ? s_max * rsqrt_f64(s_max) : 0.0;
+    return phase_max + kCutoffMargin < fp.phase_score_cutoff;
 }
 
 // Stores of data that this kernel will not touch again.  Measured on gfx950 (scripts/probe_rw.py,

@@ -1355,7 +1355,14 @@ __global__ __launch_bounds__(kFinishBlock, sizeof(Source) != sizeof(CsrSource) ?
         combine_frames(fr, phase, valid, flags);
         // re-walk in float64 when the frame decision OR the cutoff comparison is too close to call
         unsafe = fp32_decision_unsafe(fr, /*tile_sums=*/true) || near_cutoff(fp, phase);
-        if (!unsafe) store_orf(out, fp, orf, phase, valid, count, min_codon, flags | split, len);
+        unsigned left_open = 0;
+        if (unsafe && fp.printed_only && cannot_be_translating(fp, fr, count, min_codon, len)) {
+            // too close to call, and no way of calling it makes the ORF translating: in default mode it prints nothing
+            // (detect_orfs.py:301-302) -- the fp32 results stand, marked, and no wave spends ~20 us on its re-walk
+            unsafe = false;
+            left_open = RP_FLAG_UNRESOLVED;
+        }
+        if (!unsafe) store_orf(out, fp, orf, phase, valid, count, min_codon, flags | split | left_open, len);
     }
 
     // The too-close-to-call ORFs of this wave (~0.4 %), one after the other, by the whole wave:

@@ -276,6 +276,7 @@ def export_orf_coverages(
     from . import tsv
     from .index import NativeIndex
 
+    import os
     import time
 
     from . import backend
@@ -332,7 +333,14 @@ def export_orf_coverages(
         index, merged_alignments, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
         min_valid_codons_ratio, min_density_over_orf, report_all, devices, timings=timings, profiles_on_device=True,
         reuse_result_buffers=True,  # (the results are written out before this function returns)
+        # default mode prints translating rows only (detect_orfs.py:301-302): too-close-to-call ORFs that cannot be
+        # translating under ANY resolution are not re-walked (RP_FILTER_PRINTED_ONLY; same file, byte for byte)
+        printed_only=not report_all and os.environ.get("RIBOTRICER_AMD_PRINTED_ONLY", "1") != "0",
     )
+    if timings is not None and "flags" in res:
+        from ._lib import FLAG_UNRESOLVED
+
+        timings["unresolved_orfs"] = int(np.count_nonzero(np.asarray(res["flags"]) & FLAG_UNRESOLVED))
     t0 = time.perf_counter()
     tables = index.tables_native
     with open(f"{prefix}_translating_ORFs.tsv", "w+b") as output:  # (read-write: the writer maps the file)
@@ -509,7 +517,7 @@ def _profile_slices(counts, offsets, slice_nt: int = 64 << 20):
 
 def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, min_reads_per_codon,
                 min_valid_codons_ratio, min_density_over_orf, report_all: bool, devices=None, timings=None,
-                profiles_on_device: bool = False, reuse_result_buffers: bool = False):
+                profiles_on_device: bool = False, reuse_result_buffers: bool = False, printed_only: bool = False):
     """Gather + score for a natively parsed index: ``(counts, offsets, results)`` as host arrays,
     ready for the row formatter (``profiles_on_device``: ``counts`` stays a device tensor, for
     ``_profile_slices``).
@@ -520,11 +528,18 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     tiles straight from the dense coverage (``rp_phase_score_coverage_dev``), the profiles are
     never written to HBM -- and only the translating ORFs' profiles are gathered afterwards;
     ``offsets`` then gives every other ORF an empty range.  With several ``devices`` both modes
-    shard the ORFs (``engine.score_sharded`` / ``engine.score_coverage_sharded``)."""
+    shard the ORFs (``engine.score_sharded`` / ``engine.score_coverage_sharded``).
+
+    ``printed_only`` (default mode only; ``export_orf_coverages`` sets it): the caller prints nothing but translating
+    ORFs, so too-close-to-call ORFs that no resolution could make translating keep their fp32 result
+    (``RP_FILTER_PRINTED_ONLY`` / ``FLAG_UNRESOLVED``, ``engine.make_filter``).  The translating ORFs' results, hence the
+    file, are the same bytes; ``results`` of the others are NOT at full resolution then.  Off: every ORF is resolved."""
     import os
 
     import numpy as np
     import torch
+
+    printed_only = bool(printed_only) and not report_all
 
     from .alignments import build_coverage_device
     from .engine import rescore_big_count_orfs, resolve_big_ties
@@ -559,7 +574,8 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
                 cache.clear()
                 cache[key] = IndexShards(index, interval_table_from_index(index, base0), total0, devices)
             t = lap("interval_table_slices", t)
-            thresholds = make_filter(phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio, min_density_over_orf)
+            thresholds = make_filter(phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio, min_density_over_orf,
+                                     printed_only=printed_only)
             res, parts = cache[key].score(merged_alignments, thresholds, report_all, timings=timings, reuse_result_buffers=reuse_result_buffers)
             lap("sharded_build_score_gather", t)
             if profiles_on_device:
@@ -628,7 +644,7 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
         lap("profiles_d2h", t)
         return out
     thresholds = make_filter(
-        phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio, min_density_over_orf
+        phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio, min_density_over_orf, printed_only=printed_only
     )
     if sharded:
         from .engine import CoverageShards

@@ -79,9 +79,16 @@ def make_filter(
     min_reads_per_codon: float = MINIMUM_READS_PER_CODON,
     min_valid_codons_ratio: float = MINIMUM_VALID_CODONS_RATIO,
     min_density_over_orf: float = MINIMUM_DENSITY_OVER_ORF,
+    printed_only: bool = False,
 ) -> FilterParams:
-    """Thresholds in the argument order of export_orf_coverages (detect_orfs.py:206-216)."""
+    """Thresholds in the argument order of export_orf_coverages (detect_orfs.py:206-216).
+
+    ``printed_only`` (``RP_FILTER_PRINTED_ONLY``): the caller prints translating ORFs only (the reference's default mode,
+    detect_orfs.py:301-302).  Too-close-to-call ORFs that no resolution could make translating are then left at their
+    fp32 result (``FLAG_UNRESOLVED``, status 0) instead of being re-walked in float64; every ORF with status 1 and every
+    unflagged ORF is unchanged.  Off by default: scores of ALL ORFs then carry the full resolution."""
     fp = FilterParams()
+    fp.flags = _lib.FILTER_PRINTED_ONLY if printed_only else 0
     fp.phase_score_cutoff = float(phase_score_cutoff)
     fp.min_valid_codons = int(min_valid_codons)
     fp.min_reads_per_codon = float(min_reads_per_codon)
