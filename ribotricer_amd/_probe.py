@@ -21,6 +21,8 @@ def _load():
             fn = getattr(_lib, name)
             fn.restype = ctypes.c_int
             fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.sp_stream_read_lds_dword.restype = ctypes.c_int
+        _lib.sp_stream_read_lds_dword.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         _lib.sp_stream_rw.restype = ctypes.c_int
         _lib.sp_stream_rw.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_void_p, ctypes.c_void_p]
@@ -32,7 +34,13 @@ def stream_read_GBps(buf, launches: int = 20, warmup: int = 3, flavour: str = "r
     import torch
 
     lib = _load()
-    fn = lib.sp_stream_read if flavour == "registers" else lib.sp_stream_read_lds
+    if flavour.startswith("lds_dword"):  # "lds_dword0" / "lds_dword1" / "lds_dword2": the fused kernel's pattern (stream_probe.hip)
+        mode = int(flavour[-1])
+
+        def fn(ptr, n, scratch_ptr, stream_ptr):
+            return lib.sp_stream_read_lds_dword(ptr, n, scratch_ptr, stream_ptr, mode)
+    else:
+        fn = lib.sp_stream_read if flavour == "registers" else lib.sp_stream_read_lds
     nbytes = (buf.numel() * buf.element_size()) // 32768 * 32768
     assert nbytes > 0 and buf.data_ptr() % 16 == 0
     scratch = torch.zeros(1, dtype=torch.int64, device=buf.device)

@@ -53,6 +53,42 @@ __global__ __launch_bounds__(kThreads, 4) void k_stream_read_lds(const char* __r
     if (s == 0x9e3779b9u) atomicAdd(sink, 1ull);
 }
 
+// ---- FETCH_SIZE calibration for the fused kernel's access pattern (round 6) ----
+// k_tile_score<true> stages its tile with global_load_lds_dword: 4 bytes per lane, one chunk of <= 64 consecutive
+// coverage elements per instruction, chunks cut at the 256-byte lines of the source (rp_pieces.hpp: run_head / run_chunks).
+// MI355X_MICROARCH.md calibrates FETCH_SIZE (x2) for 16-byte-per-lane streaming reads only; these kernels read a KNOWN
+// byte count -- every byte of the buffer exactly once -- in the dword pattern, so that one `rocprofv3 --pmc FETCH_SIZE`
+// pass over scripts/fetch_calibration.py gives the factor for it (profiles/r06_fetch_calibration.txt):
+//   MODE 0  whole lines: 64 lanes x 4 bytes, ascending            (a forward chunk in the middle of a run)
+//   MODE 1  a line in two instructions: lanes 0-23, then 24-63    (the head / tail chunks either side of a cut)
+//   MODE 2  whole lines, lane l reads element 63 - l              (a '-' strand chunk: descending addresses)
+template <int MODE>
+__global__ __launch_bounds__(kThreads, 4) void k_stream_read_lds_dword(const char* __restrict__ p, unsigned long long* sink) {
+    __shared__ __attribute__((aligned(16))) unsigned s_tile[kPiece / 4];
+    const char* src = p + (size_t)blockIdx.x * kPiece;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (four loader waves, as the fused kernel has: wave w takes the lines w, w + 4, ...)
+    for (int r = wave; r < kPiece / 256; r += 4) {
+        const char* line = src + r * 256;
+        if (MODE == 0) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(line + lane * 4), (lptr_t)(s_tile + r * 64), 4, 0, 2);
+        } else if (MODE == 1) {
+            if (lane < 24) __builtin_amdgcn_global_load_lds((gptr_t)(line + lane * 4), (lptr_t)(s_tile + r * 64), 4, 0, 2);
+            if (lane >= 24) __builtin_amdgcn_global_load_lds((gptr_t)(line + lane * 4), (lptr_t)(s_tile + r * 64), 4, 0, 2);
+        } else {
+            __builtin_amdgcn_global_load_lds((gptr_t)(line + (63 - lane) * 4), (lptr_t)(s_tile + r * 64), 4, 0, 2);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned s = 0;
+#pragma unroll
+    for (int i = 0; i < kPiece / 4 / kThreads; i += 8) s += s_tile[threadIdx.x + i * kThreads];
+    if (s == 0x9e3779b9u) atomicAdd(sink, 1ull);
+}
+
 // ---- a read stream with a sprinkle of writes: what do ~1.2 KB of records per 32 KiB tile cost, and in which form? ----
 // The piece is DMA'd into LDS as above (one loader wave); then the workgroup writes `w_bytes` to out + block * w_bytes:
 //   mode 0  nothing                     mode 1  one wave, dwordx4 per lane, contiguous
@@ -158,6 +194,19 @@ int sp_stream_read_lds(const void* p, size_t bytes, void* scratch8, void* stream
     if (bytes == 0 || bytes % kPiece || ((uintptr_t)p & 15)) return 1;
     hipLaunchKernelGGL(k_stream_read_lds, dim3((unsigned)(bytes / kPiece)), dim3(kThreads), 0, (hipStream_t)stream,
                        (const char*)p, (unsigned long long*)scratch8);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+// the fused kernel's dword LDS-DMA pattern over a known byte count (mode 0 / 1 / 2: see k_stream_read_lds_dword)
+int sp_stream_read_lds_dword(const void* p, size_t bytes, void* scratch8, void* stream, int mode) {
+    if (bytes == 0 || bytes % kPiece || ((uintptr_t)p & 255) || mode < 0 || mode > 2) return 1;
+    const dim3 grid((unsigned)(bytes / kPiece)), block(kThreads);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_stream_read_lds_dword<0>, grid, block, 0, (hipStream_t)stream, (const char*)p, (unsigned long long*)scratch8);
+    else if (mode == 1)
+        hipLaunchKernelGGL(k_stream_read_lds_dword<1>, grid, block, 0, (hipStream_t)stream, (const char*)p, (unsigned long long*)scratch8);
+    else
+        hipLaunchKernelGGL(k_stream_read_lds_dword<2>, grid, block, 0, (hipStream_t)stream, (const char*)p, (unsigned long long*)scratch8);
     return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

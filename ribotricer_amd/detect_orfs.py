@@ -459,15 +459,6 @@ def _table_and_plan(index, base, coverage_len: int, device, table=None):
     return cache[key]
 
 
-PLACE_WORKSPACE_MIN_NT = 64 << 20  # below this a step is launch-bound: nothing to gain
-
-
-def _place_workspace_for(table) -> bool:
-    import os
-
-    return os.environ.get("RIBOTRICER_AMD_PLACE_WORKSPACE", "0") == "1" and int(table.offsets[-1]) >= PLACE_WORKSPACE_MIN_NT
-
-
 def _shards(extras: dict, kind: str, devices, build):
     """The layout's shards of ``kind`` for ``devices`` (made once per index, layout and device list)."""
     key = (kind, tuple(int(d) if isinstance(d, int) else str(d) for d in devices))
@@ -608,22 +599,11 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
         timings["dense_layout_positions"] = int(total0)
     sharded = devices is not None and len(devices) > 1
     extras["samples"] = extras.get("samples", 0) + 1
-    if plan is not None and not sharded and "workspace_placement" not in extras and extras["samples"] >= 2 and _place_workspace_for(table):
-        # OPT-IN (RIBOTRICER_AMD_PLACE_WORKSPACE=1), once per cached index when its second sample arrives: put the record
-        # workspace where its writes cost the coverage reads least (engine.tune_workspace; nothing but ONE workspace stays
-        # allocated).  Off by default for a reason of PROPORTION: a sample of the 11 M-line index takes 0.21 s here, 5 ms of
-        # it on the device; the best placement buys at most 10 % of the 2.5 ms scoring kernel --
-        # 0.25 ms, a thousandth of a sample -- while the search costs 0.07 s, 0.5 s on boxes whose driver takes 20 ms per GiB
-        # allocated: some 300 samples of one index to pay it back.  (With the compact coverage -- 6.3 GB for that index, not
-        # the 25-85 GB dense layout the round-4 note argued from -- the coverage can lie inside one class of physical memory,
-        # so the search does find 3-10 % on the boxes that have classes: profiles/r05_placement_check.txt.  It is the
-        # kernel's gain, not the export's.)  bench.py, whose step IS the device work, runs the search.
-        extras["workspace_placement"] = get_engine(device).tune_workspace(
-            coverage, thresholds=make_filter(phase_score_cutoff, min_valid_codons, min_reads_per_codon, min_valid_codons_ratio,
-                                             min_density_over_orf), gather_plan=plan, tries=3, spread=0.03)  # (a coverage far larger than a memory class: little to find, profiles/archive/r04_placement_check.txt)
-        if timings is not None:
-            timings["workspace_placement_report"] = extras["workspace_placement"]
-        t = lap("workspace_placement", t)
+    # (No placement search of the record workspace here.  engine.tune_workspace exists for callers whose job IS the device
+    # step -- many samples against one CSR batch, bench.py -- where the best placement buys 3-10 % of a 2.5 ms kernel.  A
+    # sample of an 11 M-line index takes 0.2 s in this function, 5 ms of it on the device: the search (0.07-0.5 s) would
+    # need hundreds of samples of one index to pay for a thousandth of each.  Rounds 4-5 kept it as an opt-in knob
+    # (RIBOTRICER_AMD_PLACE_WORKSPACE, profiles/r05_placement_check.txt); round 6 removed the knob: DESIGN.md section 4.)
     if plan is None or report_all:
         d_counts, d_offsets = gather_profiles_device(coverage, table, device, plan=plan)
         shards = None

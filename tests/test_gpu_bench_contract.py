@@ -11,15 +11,20 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_line_has_the_contract_fields():
+LINE_LIMIT = 8192  # the driver keeps an 8 KB tail of stdout: the whole line must fit
+
+
+def test_bench_line_has_the_contract_fields(tmp_path):
+    detail_path = str(tmp_path / "detail.json")
     out = subprocess.run(
         [sys.executable, os.path.join(REPO, "bench.py"), "--orfs", "60000", "--steps", "3", "--warmup", "1", "--cpu-sample", "100",
-         "--cpu-cores", "4"],
+         "--cpu-cores", "4", "--detail", detail_path],
         capture_output=True, text=True, timeout=600, cwd=REPO,
     )
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
+    assert len(lines[0]) < LINE_LIMIT, len(lines[0])
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -40,15 +45,27 @@ def test_bench_line_has_the_contract_fields():
     assert d["value"] > 0 and d["ms_per_step"] > 0
     assert "configs[2]" in d["config"]["workload"] and d["config"]["orfs_total"] == 60000
     assert d["roofline"]["kernel"] == "rp::k_tile_score"
-    sr = d["roofline"]["stream_read"]  # the live yardstick: a plain read of the same buffer
-    assert sr is not None and sr["GBps"] > 0 and 0 < d["roofline"]["frac_of_stream_read"] < 1.5
-    # after the timed region: head / middle / tail slices against the oracle, the fused section, the single-sample rate
+    assert d["roofline"]["stream_read_GBps"] > 0 and 0 < d["roofline"]["frac_of_stream_read"] < 1.5  # the live yardstick: a plain read of the same buffer
+    # the numbers a reader of the driver's flattened record needs, as top-level scalars
+    for key in ("kernel_ms", "finish_ms", "step_frac", "fused_step_frac", "fused_nested_step_frac", "fused_finish_ms", "fused_nested_finish_ms",
+                "fused_step_frac_all_resolved", "projected_efficiency_g2", "projected_efficiency_g4", "projected_efficiency_g8", "value_single_sample"):
+        assert isinstance(d[key], float) and d[key] > 0, key
+    assert d["kernel_ms"] == r["kernel_ms"] and d["finish_ms"] == r["finish_ms"] and d["step_frac"] == r["step_frac"]
+    # after the timed region: head / middle / tail slices against the oracle, the fused sections, the single-sample rate
     v = d["verify"]
     assert v["ok"] is True and v["orfs_checked"] >= 60000 and v["max_abs_dphase"] <= 1e-6 and v["read_count_checksum_ok"] is True
-    f = d["fused"]
-    assert f["kernel_ms"] > 0 and 0 < f["frac"] < 1 and f["verify"]["ok"] is True and f["verify"]["orfs_checked"] >= 60000
-    assert d["value_single_sample"] > 0 and d["single_sample"]["ms_per_step"] > 0  # (a 60 000-ORF set is launch-bound: no ordering claim)
-    sp = d["slice_projection"]  # rank 0's slice of the 2 / 4 / 8-GPU runs, timed on this GPU: the projected scaling curve
+    for tag in ("fused", "fused_nested"):  # the export's default mode (RP_FILTER_PRINTED_ONLY), all-resolved beside it, each checked
+        f = d[tag]
+        assert f["kernel_ms"] > 0 and 0 < f["frac"] < 1 and f["verify"]["ok"] is True and f["verify"]["orfs_checked"] >= 60000
+        assert f["printed_only_check_ok"] is True and 0 < f["left_open"] <= f["rewalked_when_all_resolved"]
+        assert f["step_frac"] == d[f"{tag}_step_frac"] and f["all_resolved"]["step_frac"] == d[f"{tag}_step_frac_all_resolved"]
+    assert d["quality"]["left_open"] == 0  # (the headline resolves every ORF)
+    assert [row["gpus"] for row in d["slice_projection"]] == [2, 4, 8]
+    # ---- the full record (--detail): every block with its explanations
+    full = json.load(open(detail_path))
+    assert full["value"] == d["value"] and full["roofline"]["stream_read"]["GBps"] == d["roofline"]["stream_read_GBps"]
+    assert full["single_sample"]["ms_per_step"] > 0  # (a 60 000-ORF set is launch-bound: no ordering claim)
+    sp = full["slice_projection"]  # rank 0's slice of the 2 / 4 / 8-GPU runs, timed on this GPU: the projected scaling curve
     assert [row["gpus"] for row in sp["slices"]] == [2, 4, 8] and sp["step_ms_1gpu"] > 0
     for row in sp["slices"]:
         for key in ("orfs", "nt", "step_ms", "kernel_ms", "finish_ms", "step_frac", "projected_value", "projected_efficiency"):
@@ -57,9 +74,10 @@ def test_bench_line_has_the_contract_fields():
         assert abs(row["projected_efficiency"] - sp["step_ms_1gpu"] / (row["gpus"] * row["step_ms"])) < 1e-9
         assert row["integers_equal_headline"] is True and row["max_abs_dphase_vs_headline"] <= 1e-6
         assert abs(row["nt"] - d["config"]["nt_total"] / row["gpus"]) <= 0.02 * d["config"]["nt_total"]  # nt-balanced
-    fn = d["fused_nested"]  # the nested-index law (transcripts on different chromosomes: pieces of a tile gigabytes apart)
-    assert fn["kernel_ms"] > 0 and fn["verify"]["ok"] is True and fn["verify"]["orfs_checked"] >= 60000
+        assert d[f"projected_efficiency_g{row['gpus']}"] == row["projected_efficiency"]
+    fn = full["fused_nested"]  # the nested-index law (transcripts on different chromosomes: pieces of a tile gigabytes apart)
     assert fn["gather_plan"]["slow_tiles"] <= 0.01 * fn["gather_plan"]["tiles"] + 1 and "nested" in fn["workload"]
+    assert fn["printed_only_check"]["ok"] is True and fn["verify"]["slices"]
 
 
 def test_two_ranks_shard_one_set_and_concat_equals_whole():
@@ -96,6 +114,7 @@ def _bare_bench(n, orfs, extra=(), env_extra=None):
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), lines  # stdout is the ONE JSON line (RCCL's banner and the like go to stderr)
+    assert len(lines[0]) < LINE_LIMIT, len(lines[0])
     return json.loads(lines[0])
 
 
@@ -153,22 +172,32 @@ def test_one_rank_has_the_same_value_definition_with_and_without_a_process_group
     assert forced["verify"]["concat_equals_whole"]["ok"] is True and "concat_equals_whole" not in plain["verify"]
 
 
-def test_pipelined_and_first_allocation_values_are_reported_beside_value():
-    """A set large enough for the placement search and the two-stream section: `value_first_allocation` (the step before
-    engine.tune_workspace) and `value_pipelined` (finish(k) beside score(k + 1), a workspace per stream) are extra
-    fields; `value` keeps its definition, and the pipelined results equal the headline's bit for bit."""
-    d = _bare_bench(1, 600000, extra=("--cpu-sample", "0", "--no-fused"))
+def test_pipelined_and_first_allocation_values_are_reported_beside_value(tmp_path):
+    """A set large enough for the placement search and the two-stream section.  `value` is timed with the record workspace
+    placed (engine.tune_workspace: the engine's own buffer) and the counts WHERE THE CALLER PUT THEM; beside it, as extra
+    fields: `value_first_allocation` (the step before the search), `value_source_placed` (the counts moved as well,
+    engine.tune_source -- timed AFTER the headline, no product path does that), `value_pipelined` (two streams: finish(k)
+    beside score(k + 1)) and `value_one_stream_repeat` (the same protocol on one stream right after it): both timings
+    reported, neither chosen; the pipelined results equal the headline's bit for bit."""
+    detail = str(tmp_path / "detail.json")
+    d = _bare_bench(1, 600000, extra=("--cpu-sample", "0", "--no-fused", "--detail", detail))
     assert d["value"] == pytest.approx(600000 * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3), rel=1e-9)
-    assert d["value_first_allocation"] > 0 and d["first_allocation"]["ms_per_step"] > 0
-    wp = d["config"]["workspace_placement"]
+    assert d["value_first_allocation"] > 0 and d["first_allocation_ms_per_step"] > 0
+    assert d["config"]["workspace_placement"]["searched"] is True
+    full = json.load(open(detail))
+    wp = full["config"]["workspace_placement"]
     assert wp["released_to_driver"] is True and wp["spacers"] == len(wp["step_ms"]) - 1
     assert wp["copies"] == 2  # (the second workspace of the chosen block serves the other stream of the two-stream trial)
-    sp = wp["source_placement"]  # (engine.tune_source: the synthetic counts placed like the workspace; same bytes -- verify below)
+    assert "source_placement" not in wp  # (nothing moved the counts before the headline)
+    sp = full["source_placed"]["search"]  # (engine.tune_source: the synthetic counts placed like the workspace; same bytes)
     assert len(sp["step_ms"]) == len(sp["kernel_gbps"]) == sp["spacers"] + 1 <= 4 and 0 <= sp["chosen"] < len(sp["step_ms"])
     assert sp["step_ms"][sp["chosen"]] <= sp["step_ms"][0]
-    p = d["pipelined"]
-    assert d["value_pipelined"] == pytest.approx(600000 / (p["ms_per_step"] * 1e-3), rel=1e-9)
-    assert p["results_equal_headline"] is True and p["streams"] in (1, 2) and d["verify"]["ok"] is True
-    assert p["ms_per_step"] == min(p["two_streams_ms_per_step"], p["one_stream_ms_per_step"])  # the mode runs the faster way
-    assert p["streams"] == (2 if p["two_streams_ms_per_step"] < p["one_stream_ms_per_step"] else 1)
+    if sp["chosen"]:
+        assert d["value_source_placed"] == pytest.approx(600000 / (full["source_placed"]["ms_per_step"] * 1e-3), rel=1e-9)
+    else:
+        assert d["value_source_placed"] is None  # (the first place was the fast one already: nothing else to time)
+    p = full["pipelined"]
+    assert d["value_pipelined"] == pytest.approx(600000 / (p["two_streams_ms_per_step"] * 1e-3), rel=1e-9)
+    assert d["value_one_stream_repeat"] == pytest.approx(600000 / (p["one_stream_ms_per_step"] * 1e-3), rel=1e-9)
+    assert p["results_equal_headline"] is True and d["verify"]["ok"] is True and "ms_per_step" not in p  # (no best-of)
     assert p["workspaces_from_the_headline_placement"] == 2
