@@ -212,33 +212,40 @@ def metagene_coverage(cds, alignments, read_lengths, prefix, max_positions=600, 
     return metagenes
 
 
+def best_lag(reference: np.ndarray, profile: np.ndarray, bound: int) -> int:
+    """The lag the reference's offset step reads off ``np.correlate(reference, profile, "full")`` (metagene.py:317-321):
+    of the ``2 * bound`` lags around the middle of the full cross-correlation, the one with the largest overlap product,
+    counted from the middle of that window.  Only those lags are computed here -- one dot product over the two aligned
+    slices each -- instead of all ``len(reference) + len(profile) - 1`` of them."""
+    n, m = int(reference.size), int(profile.size)
+    if n == 0 or m == 0:
+        raise ValueError("best_lag: a metagene profile is empty")  # (np.correlate refuses empty inputs the same way)
+    middle = (n + m - 1) // 2
+    window = range(n + m - 1)[middle - bound : middle + bound]  # (a range takes the slice the way the array would, ends included)
+    products = np.empty(len(window))
+    for slot, k in enumerate(window):
+        shift = k - (m - 1)  # profile[i] lies over reference[i + shift]
+        lo, hi = max(0, -shift), min(m, n - shift)
+        products[slot] = np.dot(reference[lo + shift : hi + shift], profile[lo:hi])
+    return int(np.argmax(products)) - len(window) // 2
+
+
 def align_metagenes(metagenes, read_lengths, prefix, phase_score_cutoff=CUTOFF, remove_nonperiodic=False):
-    """Drop-in for ``ribotricer.metagene.align_metagenes`` (metagene.py:268-328): optionally drop the
-    read lengths whose 5' metagene is not periodic, take the most abundant length as the base and
-    give every length the lag that maximises its cross-correlation with the base, plus the typical
-    offset.  Writes ``{prefix}_psite_offsets.txt``."""
+    """Drop-in for ``ribotricer.metagene.align_metagenes`` (metagene.py:268-328).  The contract: with
+    ``remove_nonperiodic`` the read lengths whose 5' metagene scores below the cutoff leave BOTH dicts (in place); no
+    length left -> ``sys.exit`` with the reference's warning; the base is the most abundant length (the first one on
+    equal counts); every length gets ``best_lag`` against the base's 5' profile plus ``TYPICAL_OFFSET``, in the order
+    of ``metagenes``; ``{prefix}_psite_offsets.txt`` lists the lags under a "relative lag to base" line."""
     if remove_nonperiodic:
-        for length, entry in list(metagenes.items()):
-            if entry[2] < phase_score_cutoff:
-                del read_lengths[length]
-                del metagenes[length]
-    if len(read_lengths) == 0:
+        for length in [k for k, entry in metagenes.items() if entry[2] < phase_score_cutoff]:  # (a NaN score stays, as `<` has it)
+            del read_lengths[length], metagenes[length]
+    if not read_lengths:
         sys.exit(f"WARNING: no periodic read length found... using cutoff {phase_score_cutoff}")
-    base = n_reads = 0
-    for length, reads in list(read_lengths.items()):
-        if reads > n_reads:
-            base, n_reads = length, reads
-    reference = np.asarray(metagenes[base][0].values)
-    psite_offsets: OrderedDict = OrderedDict()
-    report = f"relative lag to base: {base}\n"
-    for length, entry in list(metagenes.items()):
-        xcorr = np.correlate(reference, np.asarray(entry[0].values), "full")
-        origin = len(xcorr) // 2
-        bound = min(base, length)
-        window = xcorr[(origin - bound) : (origin + bound)]
-        lag = int(np.argmax(window) - len(window) // 2)
-        psite_offsets[length] = lag + TYPICAL_OFFSET
-        report += f"\tlag of {length}: {lag}\n"
+    base = max(read_lengths, key=read_lengths.get)  # (max keeps the first of equals: dict order, as the reference's scan)
+    if not read_lengths[base] > 0:
+        base = 0  # (no length with reads: the reference's scan never leaves its initial 0, and fails on the lookup below)
+    anchor = np.asarray(metagenes[base][0].values, dtype=np.float64)
+    lags = {length: best_lag(anchor, np.asarray(entry[0].values, dtype=np.float64), min(base, length)) for length, entry in metagenes.items()}
     with open(f"{prefix}_psite_offsets.txt", "w") as output:
-        output.write(report)
-    return psite_offsets
+        output.write("".join([f"relative lag to base: {base}\n"] + [f"\tlag of {length}: {lag}\n" for length, lag in lags.items()]))
+    return OrderedDict((length, lag + TYPICAL_OFFSET) for length, lag in lags.items())

@@ -96,5 +96,41 @@ with tempfile.TemporaryDirectory() as tmp:
         ok = os.path.getsize(f"{prefix}_{name}") > 0
         bad += not ok
         print(f"{'ok  ' if ok else 'MISSING'} {name}")
+# ---- align_metagenes (metagene.py:268-328) on random inputs: offsets, report text, what is left in both dicts, and the
+# exception type when the reference raises (no periodic length; no length with reads; empty profiles)
+import importlib  # noqa: E402
+from collections import OrderedDict  # noqa: E402
+
+import pandas as pd  # noqa: E402
+
+ref_align = importlib.import_module("ribotricer.metagene").align_metagenes
+rng = np.random.default_rng(5)
+diffs = 0
+with tempfile.TemporaryDirectory() as tmp:
+    for trial in range(2000):
+        metagenes, reads = OrderedDict(), {}
+        for length in rng.choice(np.arange(1, 45), size=int(rng.integers(1, 7)), replace=False).tolist():
+            n5 = int(rng.integers(1, 130)) if trial % 3 else int(rng.integers(1, 12))
+            kind = int(rng.integers(0, 4))
+            v = rng.random(n5) * (np.array([3.0, 0.4, 0.3])[np.arange(n5) % 3] if kind else 1.0)
+            if kind == 2:
+                v = np.round(v * 2)  # ties and zeros
+            if kind == 3:
+                v[:] = 0.0
+            score = float(rng.random()) if rng.random() > 0.05 else float("nan")
+            metagenes[length] = (pd.Series(v, index=np.arange(-20, n5 - 20)), pd.Series(v[::-1]), np.float64(score), 3, np.float64(0.5), 3)
+            reads[length] = int(rng.integers(0, 4 if trial % 7 == 0 else 100000))
+        for remove in (False, True):
+            outs = []
+            for tag, fn in (("r", ref_align), ("a", amd_mg.align_metagenes)):
+                m, r = OrderedDict(metagenes), dict(reads)
+                try:
+                    offsets = fn(m, r, os.path.join(tmp, tag), 0.428571428571, remove)
+                    outs.append((list(offsets.items()), open(os.path.join(tmp, tag + "_psite_offsets.txt")).read(), list(m), r))
+                except BaseException as e:  # noqa: BLE001  (sys.exit included)
+                    outs.append(type(e).__name__)
+            diffs += outs[0] != outs[1]
+print(f"align_metagenes on 4000 random inputs: {diffs} differences")
+bad += diffs
 print("integration check:", "all identical" if not bad else f"{bad} differences")
 sys.exit(1 if bad else 0)
