@@ -54,6 +54,39 @@ class FilterParams(ctypes.Structure):
     ]
 
 
+from .const import (  # noqa: E402
+    CUTOFF,
+    MINIMUM_DENSITY_OVER_ORF,
+    MINIMUM_READS_PER_CODON,
+    MINIMUM_VALID_CODONS,
+    MINIMUM_VALID_CODONS_RATIO,
+)
+
+
+def make_filter(
+    phase_score_cutoff: float = CUTOFF,
+    min_valid_codons: int = MINIMUM_VALID_CODONS,
+    min_reads_per_codon: float = MINIMUM_READS_PER_CODON,
+    min_valid_codons_ratio: float = MINIMUM_VALID_CODONS_RATIO,
+    min_density_over_orf: float = MINIMUM_DENSITY_OVER_ORF,
+    printed_only: bool = False,
+) -> FilterParams:
+    """Thresholds in the argument order of export_orf_coverages (detect_orfs.py:206-216).
+
+    ``printed_only`` (``RP_FILTER_PRINTED_ONLY``): the caller prints translating ORFs only (the reference's default mode,
+    detect_orfs.py:301-302).  Too-close-to-call ORFs that no resolution could make translating are then left at their
+    fp32 result (``FLAG_UNRESOLVED``, status 0) instead of being re-walked in float64; every ORF with status 1 and every
+    unflagged ORF is unchanged.  Off by default: scores of ALL ORFs then carry the full resolution."""
+    fp = FilterParams()
+    fp.flags = FILTER_PRINTED_ONLY if printed_only else 0
+    fp.phase_score_cutoff = float(phase_score_cutoff)
+    fp.min_valid_codons = int(min_valid_codons)
+    fp.min_reads_per_codon = float(min_reads_per_codon)
+    fp.min_valid_codons_ratio = float(min_valid_codons_ratio)
+    fp.min_density_over_orf = float(min_density_over_orf)
+    return fp
+
+
 # every symbol include/ribophase.h declares: name -> (restype, argtypes)
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64

@@ -8,7 +8,10 @@
            library: index parser -> ``rp_gather_profiles_host`` (orf_coverage, detect_orfs.py:134-203) ->
            ``rp_phase_score_csr_host`` (the loop body of detect_orfs.py:274-299 in the reference's own float64 operation
            sequence, csrc/rp_replay.hpp: every ORF carries the reference's bits, ties or not) -> ``rp_format_rows_host``.
-           No torch, no HIP call.  Byte-identical TSVs to the reference's, phase column included
+           No HIP call, and torch is not imported (tests/test_host_backend_cpu.py runs it with torch made unimportable).
+           What the host still needs: numpy, and the ROCm runtime LIBRARIES on the loader path -- libribophase.so is one
+           library for both backends and links libamdhip64 -- but no GPU and no driver.
+           Byte-identical TSVs to the reference's, phase column included
            (tests/test_host_backend_cpu.py against the reference's own outputs G6 / G10).
 * ``auto`` ``hip`` when a HIP device is visible (``torch.cuda.device_count() > 0``: counting devices does not
            initialise one), else ``cpu`` with one line on stderr.  The choice is made from what is VISIBLE, once per call,
@@ -40,10 +43,13 @@ def selected() -> str:
         raise ValueError(f"RIBOTRICER_AMD_BACKEND must be one of {_CHOICES}, got {want!r}")
     if want != "auto":
         return want
-    import torch
+    try:
+        import torch
 
-    if torch.cuda.device_count() > 0:
-        return "hip"
+        if torch.cuda.device_count() > 0:
+            return "hip"
+    except ImportError:  # (a host without torch has no hip backend to offer)
+        pass
     if not _told[0]:
         _told[0] = True
         print("ribotricer_amd: no HIP device visible -- using the CPU backend (the reference's float64 arithmetic in C++, "

@@ -26,7 +26,14 @@ from .const import (
     MINIMUM_VALID_CODONS,
     MINIMUM_VALID_CODONS_RATIO,
 )
-from .engine import get_engine, make_filter
+from ._lib import make_filter
+
+
+def get_engine(device=None):
+    """``engine.get_engine``, imported on first use: the engine needs torch, the cpu backend of this module does not."""
+    from .engine import get_engine as _get_engine
+
+    return _get_engine(device)
 
 # detect_orfs.py:241-260 (the last name carries the newline, :259)
 COLUMNS = [
@@ -399,9 +406,24 @@ def _index_of(path: str):
     if hit is None:
         hit = NativeIndex.from_file(path)
         while len(_INDEX_CACHE) >= _INDEX_CACHE_MAX:
-            _INDEX_CACHE.pop(next(iter(_INDEX_CACHE)))
+            _forget_index(_INDEX_CACHE.pop(next(iter(_INDEX_CACHE))))
     _INDEX_CACHE[key] = hit  # most recently used last
     return hit
+
+
+def _forget_index(index) -> None:
+    """An index leaves the cache: what hangs on it and holds device memory registered elsewhere -- the per-device shards,
+    whose streams' workspaces and outputs live in the engines -- is released now, not when the garbage collector gets
+    round to it.  (Tables, maps and plans of the one-GPU path are plain attributes: they go with the object.)"""
+    for shards in index.__dict__.pop("_shard_cache", {}).values():
+        if shards is not None:
+            shards.release()
+
+
+def forget_indexes() -> None:
+    """Empty the index cache (tests; a long-lived process that is done with its indexes)."""
+    while _INDEX_CACHE:
+        _forget_index(_INDEX_CACHE.pop(next(iter(_INDEX_CACHE))))
 
 
 def _layout_key(base, coverage_len: int, device):
@@ -559,9 +581,12 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
         cache = index.__dict__.setdefault("_shard_cache", {})
         key = (tuple(str(d) for d in devices), int(total0))
         try:
+            if key in cache and cache[key] is None:  # (this index could not be sharded over these devices before: do not try again)
+                raise RibophaseError(ERR_INTERVALS, "not plannable (remembered)")
             if key not in cache:
                 for old in cache.values():
-                    old.release()
+                    if old is not None:
+                        old.release()
                 cache.clear()
                 cache[key] = IndexShards(index, interval_table_from_index(index, base0), total0, devices)
             t = lap("interval_table_slices", t)
@@ -583,7 +608,10 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
         except RibophaseError as e:  # (a table that cannot be mapped / planned: the per-ORF kernels below cope)
             if e.status != ERR_INTERVALS:
                 raise
-            cache.pop(key, None)
+            half_built = cache.get(key)
+            if half_built is not None:
+                half_built.release()  # (slices that were built hold streams, workspaces, coverage buffers)
+            cache[key] = None  # later samples of this index go straight to the path below
     from .shards import ColumnsOnDevices
 
     if isinstance(merged_alignments, ColumnsOnDevices):  # (the whole-coverage-on-one-device flow below: that device's copy)

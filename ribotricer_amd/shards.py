@@ -62,15 +62,31 @@ def columns_on_devices(merged_alignments, devices) -> ColumnsOnDevices:
     return ColumnsOnDevices(zip(distinct, _run_slices(upload, len(distinct))))
 
 
+class CoverageLayout:
+    """What ``alignments.build_coverage_device`` needs of an index -- the (strand, chrom) groups and their extents -- and
+    nothing else: the shards hang on the cached index, so they must not hold the index (a reference cycle would keep
+    gigabytes of per-slice device buffers alive until a cyclic GC pass)."""
+
+    __slots__ = ("extents", "group_keys")
+
+    def __init__(self, index):
+        self.extents = dict(index.extents)
+        self.group_keys = list(index.group_keys)
+
+
 class IndexShards:
-    """See the module docstring."""
+    """See the module docstring.  Lifetime: built by the first sharded sample of a cached index, kept in that index's
+    ``_shard_cache`` (``detect_orfs.score_index``), released -- streams' workspaces and outputs, coverage buffers, maps,
+    plans, pinned staging -- by :meth:`release` when another device list replaces it, when a build fails, and when the index
+    leaves the index cache (``detect_orfs._forget_index``)."""
 
     def __init__(self, index, dense_table, dense_len: int, devices: Sequence):
         from .engine import _devices
         from .gather import slice_orfs
         from .sharding import slice_bounds
 
-        self.index = index  # (extents / group keys of the coverage layout: alignments.build_coverage_device)
+        self.layout = CoverageLayout(index)  # (NOT the index: see CoverageLayout)
+        self.released = False
         self.devices = _devices(devices)
         self.dense_len = int(dense_len)
         self.n_orfs = int(len(dense_table.offsets) - 1)
@@ -122,6 +138,8 @@ class IndexShards:
         from .engine import _run_slices, _wait_for_producers, get_engine, rescore_big_count_orfs, resolve_big_ties
         from .gather import coverage_profiles_of, orfs_touching
 
+        if self.released:
+            raise RuntimeError("these IndexShards were released: build new ones for the index")
         t0 = time.perf_counter()
         # the sample's columns on every distinct device (export_orf_coverages sends them up beside the index parse)
         ups = merged_alignments if isinstance(merged_alignments, ColumnsOnDevices) else columns_on_devices(merged_alignments, self.devices)
@@ -152,7 +170,7 @@ class IndexShards:
                 _wait_for_producers(stream, ups[dev].pos)
                 with torch.cuda.stream(stream):
                     big: dict = {}
-                    cov, _ = build_coverage_device(ups[dev], self.index, dev, big=big, cmap=b["cmap"], out=b["coverage"])
+                    cov, _ = build_coverage_device(ups[dev], self.layout, dev, big=big, cmap=b["cmap"], out=b["coverage"])
                     res = eng.score_coverage(cov, b["plan"], thresholds=thresholds, reuse_outputs=True, tile_plan=b["tile_plan"])
                     for name, t in res._asdict().items():
                         if t is not None:
@@ -184,11 +202,16 @@ class IndexShards:
         return results, parts
 
     def release(self) -> None:
+        """Hand everything back: every slice's stream (the engine's workspace and outputs registered under it), coverage
+        buffer, map and plans, and the pinned result staging.  Idempotent; the object cannot score afterwards."""
         from .engine import get_engine
 
         for part in self.parts:
             b = part["built"]
             if b is not None:
+                b["stream"].synchronize()
                 get_engine(part["device"]).release_stream(b["stream"])
+                b.clear()
             part["built"] = None
         self._host = {}
+        self.released = True

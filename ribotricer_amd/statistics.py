@@ -16,7 +16,6 @@ from collections.abc import Sequence
 import numpy as np
 
 from . import _lib, backend
-from .engine import get_engine
 
 
 def _is_integral(values: np.ndarray) -> bool:
@@ -29,12 +28,14 @@ def _is_integral(values: np.ndarray) -> bool:
 
 def phasescore_batch(profiles: Sequence[Sequence[float]], device=None):
     """Phase score of many profiles in one launch: ``(phase float64[n], valid int32[n], flags uint8[n])``."""
-    import torch
-
     arrays = [np.asarray(list(p) if not isinstance(p, np.ndarray) else p) for p in profiles]
     arrays = [a.astype(np.float64) if a.size == 0 else a for a in arrays]
-    if backend.selected() == "cpu":
+    if backend.selected() == "cpu":  # (before anything that needs torch: the cpu backend does not)
         return backend.phasescore_batch_host(arrays)
+    import torch
+
+    from .engine import get_engine
+
     lengths = np.array([a.size for a in arrays], np.int64)
     offsets = np.zeros(len(arrays) + 1, np.int64)
     np.cumsum(lengths, out=offsets[1:])

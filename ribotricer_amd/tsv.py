@@ -58,13 +58,16 @@ def record_tables(records):
 _SPARE: dict = {}  # size -> chunk buffers handed back by a consumer that has written them (format_rows_native(recycle=True))
 _SPARE_LOCK = threading.Lock()
 _SPARE_MAX = 96  # buffers kept, all sizes together
+_REGULAR: set = set()  # the chunk sizes callers ask _take_buffer for: only those are worth keeping
 
 
 def _take_buffer(cap: int) -> np.ndarray:
     """A chunk buffer of exactly ``cap`` bytes: a spare one of that size if the pool holds one (its pages are mapped
     already: a fresh 4 MB buffer costs a thousand page faults).  The pool is keyed by size, so callers with different
-    ``chunk_bytes`` -- or one over-long row's one-off buffer -- do not evict each other's spares."""
+    ``chunk_bytes`` do not evict each other's spares; an over-long row's one-off buffer (allocated directly, a size nobody
+    will ask for again) is never pooled."""
     with _SPARE_LOCK:
+        _REGULAR.add(cap)
         spare = _SPARE.get(cap)
         if spare:
             return spare.pop()
@@ -75,7 +78,7 @@ def _give_back(chunk) -> None:
     buf = getattr(chunk, "obj", None)
     if isinstance(buf, np.ndarray):
         with _SPARE_LOCK:
-            if sum(len(v) for v in _SPARE.values()) < _SPARE_MAX:
+            if int(buf.size) in _REGULAR and sum(len(v) for v in _SPARE.values()) < _SPARE_MAX:
                 _SPARE.setdefault(int(buf.size), []).append(buf)
 
 

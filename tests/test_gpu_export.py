@@ -99,7 +99,7 @@ def test_compact_and_dense_coverage_write_the_same_file(tmp_path, report_all):
     outs = {}
     for mode in ("1", "0"):
         os.environ["RIBOTRICER_AMD_COMPACT_COVERAGE"] = mode
-        d._INDEX_CACHE.clear()
+        d.forget_indexes()
         try:
             for tag, align, devices in (("plain", load_alignments(), None), ("big", load_g10_alignments(), None), ("sharded", load_g10_alignments(), [0, 0, 0])):
                 prefix = str(tmp_path / f"{tag}{mode}")
@@ -112,7 +112,7 @@ def test_compact_and_dense_coverage_write_the_same_file(tmp_path, report_all):
                 assert extras["coverage_map"].compact_len < extras["coverage_map"].dense_len
         finally:
             del os.environ["RIBOTRICER_AMD_COMPACT_COVERAGE"]
-    d._INDEX_CACHE.clear()
+    d.forget_indexes()
     for tag in ("plain", "big", "sharded"):
         assert outs[(tag, "1")] == outs[(tag, "0")], tag
     # one GPU vs three slices: another tiling may move an unflagged phase by <= 2e-7; every other column
@@ -235,7 +235,7 @@ def test_export_line_with_end_below_start(tmp_path):
         align["+"][("chr1", 200 + 9 * k)] = 3 + k
         align["+"][("chr1", 203 + 9 * k)] = 2
     for tag, devices, report_all in (("one", None, True), ("three", [0, 0, 0], True), ("one_d", None, False), ("three_d", [0, 0, 0], False)):
-        d._INDEX_CACHE.clear()
+        d.forget_indexes()
         d.export_orf_coverages(str(index), align, str(tmp_path / tag), report_all=report_all, devices=devices)
         rows = [r.split("\t") for r in (tmp_path / f"{tag}_translating_ORFs.tsv").read_text().splitlines()[1:]]
         if report_all:
@@ -246,7 +246,7 @@ def test_export_line_with_end_below_start(tmp_path):
         w = rows[-1]  # sorted by start the bad block comes first: id tw_9_304_{72 - 5}; a frame tie (valid 23, not 24) as the reference decides it
         assert w[:3] == ["tw_9_304_67", "uORF", "translating"] and w[4:9] == ["126", "72", "23", "0.9583333333333334", "5.25"]
         assert abs(float(w[3]) - 1.0000000000000007) <= 1e-6
-    d._INDEX_CACHE.clear()
+    d.forget_indexes()
 
 
 @pytest.mark.parametrize("devices", [None, [0, 0, 0]])
@@ -258,13 +258,13 @@ def test_export_of_the_corner_index_g12_matches_reference(tmp_path, name, device
     from helpers import g12_alignments, g12_expected, g12_params
     from ribotricer_amd import detect_orfs as d
 
-    d._INDEX_CACHE.clear()
+    d.forget_indexes()
     prefix = str(tmp_path / "out")
     timings = {}
     d.export_orf_coverages(os.path.join(GOLDEN, "g12_index.tsv"), g12_alignments(), prefix, devices=devices, timings=timings, **g12_params(name))
     assert timings["backend"] == "hip"
     same_rows(g12_expected(name).decode(), open(prefix + "_translating_ORFs.tsv").read())
-    d._INDEX_CACHE.clear()
+    d.forget_indexes()
 
 
 def same_rows(a_text: str, b_text: str, tol: float = 1e-6) -> None:
@@ -332,7 +332,7 @@ def test_index_is_parsed_once_per_file_and_reparsed_when_it_changes(tmp_path):
     params = json.load(open(os.path.join(GOLDEN, "g6_params.json")))["param_sets"]["default"]
     index_path = str(tmp_path / "index.tsv")
     shutil.copy(os.path.join(GOLDEN, "g6_index.tsv"), index_path)
-    d._INDEX_CACHE.clear()
+    d.forget_indexes()
     outs = []
     for k in range(2):
         prefix = str(tmp_path / f"out{k}")
@@ -352,7 +352,7 @@ def test_index_is_parsed_once_per_file_and_reparsed_when_it_changes(tmp_path):
     rows = open(prefix + "_translating_ORFs.tsv").read().splitlines()
     assert len(rows) - 1 == len(lines) - 2  # header line of the index + the dropped ORF
     assert next(reversed(d._INDEX_CACHE.values())) is not first
-    d._INDEX_CACHE.clear()
+    d.forget_indexes()
 
 
 
@@ -401,17 +401,118 @@ def test_hip_cpu_and_sharded_exports_of_a_random_index_agree(tmp_path, report_al
 
     index = str(tmp_path / "rnd_candidate_orfs.tsv")
     cols = _random_index_and_columns(index, seed=11 + int(report_all))
-    d._INDEX_CACHE.clear()
+    d.forget_indexes()
     outs = {}
     for tag, backend, devices in (("hip", "hip", None), ("shards", "hip", [0, 0, 0]), ("cpu", "cpu", None)):
         monkeypatch.setenv("RIBOTRICER_AMD_BACKEND", backend)
         prefix = str(tmp_path / tag)
         d.export_orf_coverages(index, cols, prefix, report_all=report_all, devices=devices)
         outs[tag] = open(prefix + "_translating_ORFs.tsv").read()
-    d._INDEX_CACHE.clear()
+    d.forget_indexes()
     n_rows = outs["cpu"].count("\n") - 1
     assert n_rows == 40_000 if report_all else 1000 < n_rows < 40_000
     same_rows(outs["cpu"], outs["hip"])
     same_rows(outs["cpu"], outs["shards"])
     exact = sum(a.split("\t")[3] == b.split("\t")[3] for a, b in zip(outs["cpu"].splitlines()[1:], outs["hip"].splitlines()[1:]))
     assert exact >= 0.01 * n_rows  # (the replayed ties, phase 0 / 1 ORFs: the same bits on both roads)
+
+
+def test_shards_come_and_go_without_leaving_anything_behind(tmp_path):
+    """The lifetime rules of shards.IndexShards, rehearsed on the one GPU (devices=[0, 0, 0, 0]: four slices, four streams):
+    samples of two different indexes alternate, default mode and report_all, with the shards released in between the three
+    ways the product releases them -- the index leaving the cache (detect_orfs._forget_index), another device list for the
+    same index, an explicit release().  Every file equals the one-GPU run's; a released shard's buffers are never touched
+    again (they are poisoned and checked); scoring through a released object raises; and the device memory held when it is
+    all over is what was held before."""
+    import gc
+
+    import torch
+
+    from ribotricer_amd import detect_orfs as d
+
+    paths, cols = {}, {}
+    for tag, seed in (("a", 301), ("b", 302)):
+        paths[tag] = str(tmp_path / f"{tag}_candidate_orfs.tsv")
+        cols[tag] = _random_index_and_columns(paths[tag], seed=seed, n_orfs=12_000)
+    d.forget_indexes()
+
+    def export(tag, report_all, devices, name):
+        d.export_orf_coverages(paths[tag], cols[tag], str(tmp_path / name), report_all=report_all, devices=devices)
+        return open(str(tmp_path / name) + "_translating_ORFs.tsv").read()
+
+    one = {(tag, ra): export(tag, ra, None, f"one_{tag}_{int(ra)}") for tag in "ab" for ra in (False, True)}
+    d.forget_indexes()
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    reserved_before = torch.cuda.memory_reserved("cuda:0")
+
+    def shards_of(tag):
+        index = next(v for k, v in d._INDEX_CACHE.items() if k[0] == os.path.realpath(paths[tag]))
+        (shards,) = index.__dict__["_shard_cache"].values()
+        return shards
+
+    poisoned = []  # buffers of released shards, filled with 0x7F bytes: nobody may write them again
+
+    def buffers_of(shards):
+        return [part["built"]["coverage"] for part in shards.parts if part["built"] is not None] + list(shards._host.values())
+
+    def retire(shards_list, how):
+        bufs = [t for sh in shards_list for t in buffers_of(sh)]
+        assert bufs
+        how()
+        for sh in shards_list:
+            assert sh.released and all(p["built"] is None for p in sh.parts) and not sh._host
+        for t in bufs:
+            t.view(torch.uint8).fill_(0x7F)
+        torch.cuda.synchronize()
+        poisoned.extend(bufs)
+
+    four = [0, 0, 0, 0]
+    for round_ in range(3):
+        for tag in "ab":
+            for ra in (False, True):
+                same_rows(one[(tag, ra)], export(tag, ra, four, f"four_{tag}_{int(ra)}_{round_}"))
+            assert shards_of(tag).plans_built == 4  # (built by the round's first sample of the index, reused by its second)
+        sa, sb = shards_of("a"), shards_of("b")
+        if round_ == 1:
+            # another device list for the same index replaces its shards; an explicit release(); a released object refuses
+            retire([sa], lambda: export("a", False, [0, 0], "two_a"))
+            same_rows(one[("a", False)], open(str(tmp_path / "two_a_translating_ORFs.tsv")).read())
+            assert shards_of("a") is not sa and len(shards_of("a").devices) == 2
+            retire([sb], sb.release)
+            with pytest.raises(RuntimeError):
+                sb.score(cols["b"], None, True)
+            d.forget_indexes()
+        else:  # the indexes leave the cache (detect_orfs._forget_index)
+            retire([sa, sb], d.forget_indexes)
+    for t in poisoned:  # nothing wrote into a released buffer
+        assert bool((t.view(torch.uint8) == 0x7F).all())
+    del poisoned, sa, sb
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    assert torch.cuda.memory_reserved("cuda:0") <= reserved_before + (8 << 20), (torch.cuda.memory_reserved("cuda:0"), reserved_before)
+
+
+def test_export_over_two_real_devices_equals_the_cpu_backend(tmp_path, monkeypatch):
+    """Two DISTINCT devices (skipped on a one-GPU box): per-device column uploads, a thread, a stream and pinned staging per
+    device -- against the cpu backend (the reference's own arithmetic) on a random index, default mode and report_all.  The
+    phase text may differ between device counts by <= 1e-6 (every slice is tiled on its own: DESIGN.md section 5);
+    every other column is the same text."""
+    import torch
+
+    from ribotricer_amd import detect_orfs as d
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices")
+    index = str(tmp_path / "rnd_candidate_orfs.tsv")
+    cols = _random_index_and_columns(index, seed=77, n_orfs=30_000)
+    for report_all in (False, True):
+        d.forget_indexes()
+        monkeypatch.setenv("RIBOTRICER_AMD_BACKEND", "hip")
+        d.export_orf_coverages(index, cols, str(tmp_path / "two"), report_all=report_all, devices=[0, 1])
+        monkeypatch.setenv("RIBOTRICER_AMD_BACKEND", "cpu")
+        d.export_orf_coverages(index, cols, str(tmp_path / "cpu"), report_all=report_all)
+        same_rows(open(str(tmp_path / "cpu_translating_ORFs.tsv")).read(), open(str(tmp_path / "two_translating_ORFs.tsv")).read())
+    d.forget_indexes()

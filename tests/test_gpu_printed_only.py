@@ -104,16 +104,16 @@ def test_default_mode_export_is_the_same_file_with_and_without_the_shortcut(tmp_
     texts, open_counts = {}, {}
     for tag, env, devices in (("on", "1", None), ("off", "0", None), ("on3", "1", [0, 0, 0]), ("off3", "0", [0, 0, 0])):
         monkeypatch.setenv("RIBOTRICER_AMD_PRINTED_ONLY", env)
-        d._INDEX_CACHE.clear()
+        d.forget_indexes()
         timings = {}
         d.export_orf_coverages(index, cols, str(tmp_path / tag), devices=devices, timings=timings)
         texts[tag] = open(str(tmp_path / tag) + "_translating_ORFs.tsv", "rb").read()
         open_counts[tag] = timings["unresolved_orfs"]
-    d._INDEX_CACHE.clear()
+    d.forget_indexes()
     assert texts["on"] == texts["off"] and texts["on3"] == texts["off3"]
     assert open_counts["off"] == 0 and open_counts["off3"] == 0 and open_counts["on"] > 0 and open_counts["on3"] > 0
     # report_all never takes it: every row is printed
     timings = {}
     d.export_orf_coverages(index, cols, str(tmp_path / "all"), report_all=True, timings=timings)
     assert timings["unresolved_orfs"] == 0
-    d._INDEX_CACHE.clear()
+    d.forget_indexes()
