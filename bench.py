@@ -191,20 +191,22 @@ def cpu_baseline(pool, counts_host, offsets_host, per_core):
 
 
 def measured_traffic(cfg, n_orfs, algo, seed, kernel="rp::k_tile_score<false>"):
-    """HBM bytes per launch of the dominant kernel, REPLAYED from the committed rocprofv3
-    PMC passes of this very command (profiles/traffic.json: FETCH_SIZE and WRITE_SIZE in KiB
-    from separate --pmc runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
-    wide streaming reads).  Counters cannot be read from inside the run, so this is None
-    unless a profile of exactly this workload is on file."""
+    """HBM bytes per launch of the dominant kernel, REPLAYED from the committed rocprofv3 PMC passes of this very command
+    (profiles/traffic.json: FETCH_SIZE and WRITE_SIZE in KiB from separate --pmc runs), each counter times its CALIBRATED
+    factor for the kernel's access pattern (`fetch_factor` / `write_factor` of the record; profiles/r06_fetch_calibration.txt:
+    FETCH_SIZE x 2.0000 for 16-byte-per-lane loads AND for the fused kernel's dword LDS-DMA chunks, WRITE_SIZE x 1.0000 for the
+    nt record stores).  Counters cannot be read from inside the run, so this is None unless a profile of exactly this
+    workload is on file.  Returns (bytes, source, fetch_factor)."""
     path = os.path.join(REPO, "profiles", "traffic.json")
     if not os.path.exists(path):
-        return None, None
+        return None, None, None
     with open(path) as fh:
         for rec in json.load(fh):
             if (rec["cfg"] == cfg and rec["orfs_per_gpu"] == n_orfs and rec["algo"] == algo and rec["seed"] == seed
                     and rec.get("kernel", "rp::k_tile_score<false>") == kernel):
-                return int((2 * rec["fetch_size_kib"] + rec["write_size_kib"]) * 1024), rec.get("source", "profiles/traffic.json")
-    return None, None
+                ff, wf = float(rec.get("fetch_factor", 2.0)), float(rec.get("write_factor", 1.0))
+                return int((ff * rec["fetch_size_kib"] + wf * rec["write_size_kib"]) * 1024), rec.get("source", "profiles/traffic.json"), ff
+    return None, None, None
 
 
 def verify_slices(out, counts, offsets, n_orfs, profiles_of=None):
@@ -357,8 +359,8 @@ def fused_section(args, eng, dev, thresholds, n_set, layout="exons"):
         "algorithmic_bytes_per_launch": algo_bytes,
         "translating": int(out.status.sum()),
     }
-    traffic, traffic_src = measured_traffic(args.cfg if layout == "exons" else "nested", n, "tile", args.seed, kernel="rp::k_tile_score<true>")
-    rep["traffic"], rep["traffic_source"] = traffic, traffic_src
+    rep["traffic"], rep["traffic_source"], rep["fetch_factor"] = measured_traffic(args.cfg if layout == "exons" else "nested", n, "tile", args.seed,
+                                                                                  kernel="rp::k_tile_score<true>")
     if not args.no_verify:
         if layout == "nested":  # neighbouring ORFs lie gigabytes apart: fetch the slices with the per-ORF gather kernel (a code path of its own)
             def profiles_of(lo, hi):
@@ -1103,7 +1105,7 @@ def main():
         k_main, k_fin, dev_ms_per_step = slow["kernel_ms"], slow["finish_ms"], slow["step_device_ms"]
         achieved = algo_bytes / (k_main * 1e-3) / 1e9
         node_bytes = sum(r["algorithmic_bytes_per_launch"] for r in ranks)
-        traffic, traffic_src = (measured_traffic(args.cfg, n_orfs, resolved, args.seed) if world == 1 else (None, None))
+        traffic, traffic_src, fetch_factor = (measured_traffic(args.cfg, n_orfs, resolved, args.seed) if world == 1 else (None, None, None))
         nt_set = int(offsets_set[-1]) if strong else total_nt * world
         result = {
             "metric": "ORFs phase-scored/sec (whole node)",
@@ -1149,6 +1151,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "fetch_factor": fetch_factor,
                 "kernel": "rp::k_tile_score" if resolved == "tile" else "rp::k_wave_score",
                 "rank": slow["rank"],
                 "node_achieved": node_bytes / (k_main * 1e-3) / 1e9,

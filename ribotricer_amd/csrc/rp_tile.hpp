@@ -25,11 +25,8 @@
 //      outputs; ORFs whose fp32 frame decision is too close to call are re-walked in float64
 //      from global memory by a whole wave (wave_walk, rp_wave.hpp).
 //
-// The scoring kernel does NOT finish ORFs itself: round 1 did (frame scores and float64 re-walk
-// out of LDS by one wave per workgroup: 0.317 vs 0.276 ms on BASELINE configs[1]), and round 3
-// tried again with only the cheap part (ORFs inside one tile, a wave per reading frame, pending
-// ORFs left to k_orf_finish): the float64 chain at the end of every workgroup costs the kernel
-// +12 %, three times what the 48 bytes of write + read per segment cost.
+// The scoring kernel does NOT finish ORFs itself: the float64 chain at the end of every workgroup costs it three times
+// what the 48 bytes of write + read per segment cost (measured twice: DESIGN_HISTORY.md, "Notes moved out of rp_tile.hpp").
 //
 // Ownership rule: a triplet (3 positions from an ORF-relative multiple of 3) belongs
 // to the tile that holds its FIRST position; its frame-1/2 codons may reach 4
@@ -96,17 +93,7 @@ struct TilePlan {
 //   plane f  p[f]  q[f]  n_f | m_f << 16  extra_f     p, q fp32: the float64 sum of <= 11 fp32 row
 //            records, rounded once; the read count is (extra_2 << 16) + extra_0 (sums of the row
 //            records' high and low halves), extra_1 = min_codon (a tile owns < 2^16 triplets)
-// (Finishing the ORFs that lie inside one tile in the scoring kernel itself -- no record, no
-// round trip -- was built and measured in round 3: the float64 chain at the end of every
-// workgroup costs the scoring kernel +12 %, three times what the round trip costs;
-// profiles/archive/r03_ab_inkernel_finish.txt.)
-constexpr size_t kRecordBytes = 48;
-// Round 5 built two other record formats to parity and dropped both (the builds are kept as patches):
-// 32-byte records for whole-ORF segments -- the three frame scores instead of the raw sums, wave 2's words handed to waves
-// 0 / 1 through LDS; a lossless 32-byte record of the sums themselves does not exist (six fp32 sums 24 B + six 12-bit
-// census counts 9 B + read count and minimum 8 B) -- 2-7 % slower on three boxes (profiles/r05_ab_narrow_records.txt,
-// r05_ab_narrow_aos_records.patch); and a tile's records as ONE contiguous run (rec[3 * id + f], the waves' words meeting
-// in LDS first): inside the placement spread (profiles/r05_ab_aos_records.txt, same patch).
+constexpr size_t kRecordBytes = 48;  // (other formats -- 32-byte records, one contiguous run per tile -- were built to parity and lost: DESIGN.md section 4)
 __device__ __forceinline__ long long rec_index(long long n_rec, long long id, int f)
 {
     return f * n_rec + id;
@@ -1209,15 +1196,9 @@ __global__ __launch_bounds__(kTileBlock, RP_MIN_WAVES) void k_tile_score_probe(c
 // pass 3: one thread per ORF -- add the records of the tiles it spans, score, filter,
 // store.  Too-close-to-call ORFs (~0.4 %) are re-walked in float64 by the wave that found
 // them, one after the other: short ones on the spot, long ones queued for pass 4.
-// (Round 4 measured what the re-walks cost the pass -- 0.258 ms with them, 0.162 without at 11 M ORFs; 0.063 / 0.022 at
-// 1 M -- and rebuilt the queue with 64 lists in 64 cache lines and a wave-per-ORF drain kernel behind the pass: 0.297 /
-// 0.074 ms, slower again.  It is not the imbalance: 0.6 % of the ORFs are exact frame ties, each replay is a serial
-// float64 fold, and spread over the 172 000 waves of this pass that work hides better than in a kernel of its own;
-// profiles/archive/r04_ab_finish_rewalk.txt, r04_ab_finish_rewalk_queue.patch.)
-// (Measured alternatives, both slower: a global queue filled with one atomicAdd per wave and
-// drained by a wave-per-ORF kernel -- 40 000 atomics on one word cost 0.46 ms at 11 M ORFs,
-// profiles/archive/r03_ab_finish_split.txt; finishing one-tile ORFs inside the scoring kernel -- +12 %
-// on that kernel, profiles/archive/r03_ab_inkernel_finish.txt.)
+// The re-walks stay INSIDE this pass: spread over its 172 000 waves they overlap the other waves' record reads; every split
+// into a queue + drain kernel (rounds 3-5) was slower.  What round 6 changed is WHICH ORFs are
+// re-walked: with RP_FILTER_PRINTED_ONLY a too-close-to-call ORF that cannot be translating is left at its fp32 result.
 // The fused path (CoverageSource) first copies the ORF's profile out of the coverage into LDS,
 // piece by piece and coalesced ('-' strand pieces backwards): walk and replay then read plain
 // LDS instead of finding the piece of every position they touch.
@@ -1304,15 +1285,8 @@ __global__ __launch_bounds__(kFinishBlock, sizeof(Source) != sizeof(CsrSource) ?
     const int lane = threadIdx.x & (kWave - 1);
     ReplayLds &s_replay = s_replay_w[threadIdx.x / kWave];
     int *const s_stage = s_stage_w[threadIdx.x / kWave];
-    // One batch of 64 ORFs per one-wave workgroup.  (Round 5 tried PERSISTENT waves -- as many workgroups as the chip holds,
-    // each looping over batches, the cure for a pass bound by the rate at which waves start: SLOWER, 0.347 vs 0.302 ms at
-    // 11 M ORFs, 0.329 with twice and 0.303 with four times as many workgroups; fused 0.545 / 0.511 / 0.460 vs 0.450
-    // (profiles/r05_ab_finish_persist.txt, .patch).  The pass is bound by WAVE TIME at full occupancy: SQ_WAVE_CYCLES
-    // (quad-cycles) over the elapsed time puts 4 500 of the 5 120 wave slots in use, and 83 % of that wave time is the
-    // re-walks and replays of the 0.6 % too-close-to-call ORFs, ~15 us of a whole wave each.  A one-shot grid hands a
-    // finished wave's slot to the next batch, which balances that tail perfectly; statically assigned batches do not.  And
-    // the loop itself cost four VGPRs -- 97 instead of 93, i.e. FOUR waves per SIMD instead of five: 0.256 -> 0.30 ms even
-    // with one batch per wave, which is how much every wave slot is worth to this pass.)
+    // One batch of 64 ORFs per one-wave workgroup: a one-shot grid hands a finished wave's slot to the next batch, which
+    // balances the tail of re-walking waves; persistent looping waves were slower.
     const long long orf = (long long)blockIdx.x * kFinishBlock + threadIdx.x;
     long long beg = 0, len = 0, count = 0;
     int min_codon = RP_MIN_CODON_COV_EMPTY;

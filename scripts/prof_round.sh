@@ -10,7 +10,7 @@ cd $R
 OUT=$R/gpurun_out/prof_$TAG
 W=/tmp/prof_$TAG
 rm -rf $W; mkdir -p $W $OUT
-timeout 600 python3 bench.py $ARGS > $OUT/bench_default.json 2> $OUT/bench_default.err
+timeout 600 python3 bench.py $ARGS --detail $OUT/bench_default_detail.json > $OUT/bench_default.json 2> $OUT/bench_default.err
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $W/stats -o stats -- python3 $R/bench.py $ARGS --steps 20 --warmup 3 --cpu-sample 0 > $OUT/bench_under_rocprofv3.json 2> $OUT/stats.err
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $W/pmc1 -o pmc1 -- python3 $R/bench.py $ARGS --steps 3 --warmup 1 --cpu-sample 0 --no-pipelined --no-slice-projection --no-fused-nested > $OUT/pmc1_bench.log 2>&1
