@@ -516,3 +516,37 @@ def test_export_over_two_real_devices_equals_the_cpu_backend(tmp_path, monkeypat
         d.export_orf_coverages(index, cols, str(tmp_path / "cpu"), report_all=report_all)
         same_rows(open(str(tmp_path / "cpu_translating_ORFs.tsv")).read(), open(str(tmp_path / "two_translating_ORFs.tsv")).read())
     d.forget_indexes()
+
+
+@pytest.mark.parametrize("seed", [41, 42, 43, 44, 45, 46])
+def test_corner_indexes_hip_equals_cpu_backend(tmp_path, seed, monkeypatch):
+    """Fresh corner-case indexes (tests/golden/random_index.py: overlapping / nested / duplicated / 1-nt exons, shuffled
+    lists, a '.' strand, blocks with end < start, dressed numbers, CRLF, no final newline) through the HIP export -- one GPU
+    and three slices, default mode and report_all -- against the cpu backend, whose bytes equal the reference's on this
+    generator's indexes (tests/golden/check_export_vs_reference.py; G12).  Zero-interval ORFs, ORFs whose exons overlap
+    inside one gather plan, groups without a single position: every column the same text, the phase within 1e-6."""
+    import sys
+
+    if GOLDEN not in sys.path:
+        sys.path.insert(0, GOLDEN)
+    from random_index import random_index
+
+    from ribotricer_amd import detect_orfs as d
+
+    shape = [dict(), dict(malformed=0.15), dict(dressed=0.2), dict(crlf=True), dict(final_newline=False, malformed=0.1),
+             dict(malformed=0.3, dressed=0.3)][seed % 6]
+    text, merged = random_index(2500, seed, **shape)
+    index = str(tmp_path / "corner_candidate_orfs.tsv")
+    with open(index, "w", newline="") as fh:
+        fh.write(text)
+    for report_all in (False, True):
+        outs = {}
+        for tag, backend, devices in (("cpu", "cpu", None), ("hip", "hip", None), ("three", "hip", [0, 0, 0])):
+            monkeypatch.setenv("RIBOTRICER_AMD_BACKEND", backend)
+            d.forget_indexes()
+            d.export_orf_coverages(index, merged, str(tmp_path / tag), report_all=report_all, devices=devices)
+            outs[tag] = open(str(tmp_path / tag) + "_translating_ORFs.tsv", newline="").read()
+        assert outs["cpu"].count("\n") - 1 == (2500 if report_all else outs["cpu"].count("\ttranslating\t"))
+        same_rows(outs["cpu"], outs["hip"])
+        same_rows(outs["cpu"], outs["three"])
+    d.forget_indexes()
