@@ -25,8 +25,11 @@ def main():
     hi = int(sys.argv[2]) if len(sys.argv) > 2 else 600
     eng = PhaseScoreEngine("cuda:0")
     th = make_filter()
+    th_printed = make_filter(printed_only=True)  # RP_FILTER_PRINTED_ONLY: status everywhere and everything not left open must not change
+    from ribotricer_amd._lib import FLAG_RECHECK64, FLAG_UNRESOLVED
+
     t0 = time.time()
-    n_orfs = n_fused = 0
+    n_orfs = n_fused = n_open = n_rewalked = 0
     for seed in range(lo, hi):
         rng = np.random.default_rng(1000 + seed)
         lens = lengths_for(seed, 7936)
@@ -47,6 +50,16 @@ def main():
         res = eng.score(view, d_off, thresholds=th, algo="tile").cpu_numpy()
         assert_matches_oracle({k: v.copy() for k, v in res.items()}, counts, offsets)
         n_orfs += lens.size
+        pr = eng.score(view, d_off, thresholds=th_printed, algo="tile").cpu_numpy()
+        left = (pr["flags"] & FLAG_UNRESOLVED) != 0
+        assert np.array_equal(pr["status"], res["status"]) and not pr["status"][left].any(), seed
+        assert not (left & ((res["flags"] & FLAG_RECHECK64) == 0)).any(), seed  # only ORFs that would have been re-walked
+        for key in res:
+            assert np.array_equal(pr[key][~left], res[key][~left], equal_nan=True), (seed, key)
+        for key in ("read_count", "min_codon_cov"):
+            assert np.array_equal(pr[key][left], res[key][left]), (seed, key)
+        n_open += int(left.sum())
+        n_rewalked += int(((res["flags"] & FLAG_RECHECK64) != 0).sum())
         if seed % 4 == 0 and total and (lens > 0).all():
             table = IntervalTable(offsets[:-1].copy(), lens.astype(np.int32), np.arange(lens.size + 1, dtype=np.int64),
                                   np.zeros(lens.size, np.uint8), offsets)
@@ -61,7 +74,8 @@ def main():
             for key in plain:
                 assert np.array_equal(fused[key], plain[key], equal_nan=True), (seed, key)
             n_fused += 1
-    print(f"seeds {lo}..{hi - 1}: {n_orfs} ORFs against the oracle, {n_fused} batches fused == CSR bit for bit, {time.time() - t0:.0f} s")
+    print(f"seeds {lo}..{hi - 1}: {n_orfs} ORFs against the oracle, {n_fused} batches fused == CSR bit for bit; RP_FILTER_PRINTED_ONLY on every batch: "
+          f"{n_open} of {n_rewalked} too-close-to-call ORFs left open, status and every other ORF's outputs unchanged; {time.time() - t0:.0f} s")
 
 
 if __name__ == "__main__":
