@@ -963,7 +963,7 @@ def main():
             eng.release_stream(st)
         del lanes, out_p
     # SECONDARY, after the headline: the other half of the placement relation is where the COUNTS lie (a step is slow
-    # whenever counts and records share a class of physical memory, profiles/r05_source_placement.txt).  engine.tune_source
+    # whenever counts and records share a class of physical memory, profiles/archive/r05_source_placement.txt).  engine.tune_source
     # copies this program's own synthetic array behind spacers until the kernel runs at the fast class's rate (same bytes)
     # and the same K steps are timed again: value_source_placed.  No product path moves a caller's array -- which is why
     # this is not `value` -- but a caller who owns his allocation can.

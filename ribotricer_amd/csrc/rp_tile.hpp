@@ -1214,7 +1214,7 @@ static_assert(kFinishBlock % kWave == 0 && kFinishBlock <= 1024, "whole waves");
 // fused path: profiles up to this long are copied to LDS first.  632 nt = 2.5 KB per wave: with the replay's 4.7 KB that
 // leaves room for five one-wave workgroups per SIMD (20 per CU), which the fused flavour is then asked to fit its registers
 // into (95 VGPRs instead of 103, 12 bytes of scratch per lane): every wave slot counts in this pass.
-// Measured against 1 016 nt / four waves (profiles/r05_ab_finish_occupancy.txt): fused finish 0.413 -> 0.388 ms; 760 nt:
+// Measured against 1 016 nt / four waves (profiles/archive/r05_ab_finish_occupancy.txt): fused finish 0.413 -> 0.388 ms; 760 nt:
 // 0.405; 504 nt: 0.393; 440 nt / six waves: 0.457 (spills).  Longer profiles are read through their pieces.
 constexpr int kStageNt = RP_STAGE_NT;
 #ifndef RP_FINISH_WAVES_FUSED

@@ -631,7 +631,7 @@ def score_index(index, merged_alignments, phase_score_cutoff, min_valid_codons, 
     # step -- many samples against one CSR batch, bench.py -- where the best placement buys 3-10 % of a 2.5 ms kernel.  A
     # sample of an 11 M-line index takes 0.2 s in this function, 5 ms of it on the device: the search (0.07-0.5 s) would
     # need hundreds of samples of one index to pay for a thousandth of each.  Rounds 4-5 kept it as an opt-in knob
-    # (RIBOTRICER_AMD_PLACE_WORKSPACE, profiles/r05_placement_check.txt); round 6 removed the knob: DESIGN.md section 4.)
+    # (RIBOTRICER_AMD_PLACE_WORKSPACE, profiles/archive/r05_placement_check.txt); round 6 removed the knob: DESIGN.md section 4.)
     if plan is None or report_all:
         d_counts, d_offsets = gather_profiles_device(coverage, table, device, plan=plan)
         shards = None

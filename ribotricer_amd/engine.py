@@ -328,7 +328,7 @@ class PhaseScoreEngine:
         """The other half of the placement: where the COUNTS lie.  ``tune_workspace`` walks the record workspace through
         physical memory; what it cannot change is the class of memory the read stream itself comes from, and a step is
         slow whenever the two share one (one process, six copies of the same 16 GB of counts against two workspaces:
-        2.63-3.04 ms per launch, some copies slow with every workspace -- profiles/r05_source_placement.txt).  For an
+        2.63-3.04 ms per launch, some copies slow with every workspace -- profiles/archive/r05_source_placement.txt).  For an
         input the CALLER OF THIS METHOD owns -- the bench's synthetic counts, the export's own coverage buffer -- the
         same search is run on the source: unless the scoring kernel already moves its bytes at ``good_gbps`` (the fast
         class on MI355X: 6.0-6.1 TB/s of algorithmic bytes for the CSR kernel; ``None``: no absolute mark -- stop at a

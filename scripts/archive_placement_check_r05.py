@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 # ARCHIVED (round 6): measured the opt-in RIBOTRICER_AMD_PLACE_WORKSPACE knob of export_orf_coverages, which round 6 removed
-# (profiles/r05_placement_check.txt is its record).  Kept for the record; the product half no longer places anything.
+# (profiles/archive/r05_placement_check.txt is its record).  Kept for the record; the product half no longer places anything.
 """Does the PRODUCT get the placement the bench enjoys?  (round-3 verdict, item 2)
 
 P fresh processes each of
