@@ -1579,3 +1579,16 @@ int rp_validate_csr_dev(int device, const int32_t *d_counts, const int64_t *d_of
 }
 
 }  // extern "C"
+
+#ifdef RP_REWALK_STAMPS  // (timing-experiment builds only: scripts/ab_finish_tail.py)
+extern "C" int rp_debug_rewalk_stamps(unsigned long long *out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rp::g_rewalk_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(rp::g_rewalk_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+

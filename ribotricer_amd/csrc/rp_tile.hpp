@@ -1247,12 +1247,20 @@ __device__ __forceinline__ void stage_profile(const CoverageSource &source, long
 
 // float64 walk of one too-close-to-call ORF by one wave, the tie replay if need be, and the stores
 // (the integer results of the fp32 pass stand: they are exact)
+#ifdef RP_REWALK_STAMPS  // timing experiment: where does a re-walk's time go?  (s_memtime deltas summed per phase)
+__device__ unsigned long long g_rewalk_stamps[16];
+#define RP_RW_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define RP_RW_STAMP(var)
+#endif
 template <typename Counts>
 __device__ __forceinline__ void finish_unsafe(Counts v, long long orf, long long len, long long count, int min_codon, unsigned split,
                                               int lane, ReplayLds *replay, const OrfOutputs &out, const FilterParams &fp)
 {
+    RP_RW_STAMP(ts0);
     WalkResult<double> w;
     wave_walk<double>(v, len, lane, w);
+    RP_RW_STAMP(ts1);
     FrameScore fr2[3];
 #pragma unroll
     for (int f = 0; f < 3; ++f)
@@ -1261,11 +1269,23 @@ __device__ __forceinline__ void finish_unsafe(Counts v, long long orf, long long
     int valid;
     unsigned flags;
     combine_frames(fr2, phase, valid, flags);
+    RP_RW_STAMP(ts2);
     if (flags & RP_FLAG_TIE) {
         const bool big = replay_tie_wave(v, len, lane, phase, valid, replay);
         flags |= RP_FLAG_REPLAY | (big ? RP_FLAG_BIGTIE : 0u);
     }
+    RP_RW_STAMP(ts3);
     if (lane == 0) store_orf(out, fp, orf, phase, valid, count, min_codon, flags | split | RP_FLAG_RECHECK64, len);
+#ifdef RP_REWALK_STAMPS
+    if (lane == 0) {
+        const int t = (flags & RP_FLAG_TIE) ? 8 : 0;
+        atomicAdd(&g_rewalk_stamps[t + 0], 1ull);
+        atomicAdd(&g_rewalk_stamps[t + 1], ts1 - ts0);
+        atomicAdd(&g_rewalk_stamps[t + 2], ts2 - ts1);
+        atomicAdd(&g_rewalk_stamps[t + 3], ts3 - ts2);
+        atomicAdd(&g_rewalk_stamps[t + 4], (unsigned long long)len);
+    }
+#endif
 }
 
 #ifndef RP_FINISH_WAVES
@@ -1345,6 +1365,17 @@ __global__ __launch_bounds__(kFinishBlock, sizeof(Source) != sizeof(CsrSource) ?
     unsigned long long todo = __ballot(unsafe);
 #ifdef RP_EXPERIMENT_NO_REWALK  // timing experiment only (results wrong): what the in-wave re-walks cost the finish pass
     todo = 0;
+#endif
+#ifdef RP_EXPERIMENT_MAX_REWALKS  // timing experiment only (results wrong): a wave re-walks at most this many of its ORFs
+    for (int keep = 0; keep < RP_EXPERIMENT_MAX_REWALKS; ++keep) {}
+    {
+        unsigned long long kept = 0, rest = todo;
+        for (int k = 0; k < RP_EXPERIMENT_MAX_REWALKS && rest != 0; ++k) {
+            kept |= rest & (0ull - rest);
+            rest &= rest - 1;
+        }
+        todo = kept;
+    }
 #endif
     while (todo != 0) {
         const int l = __builtin_ctzll(todo);

@@ -24,13 +24,6 @@ import torch
 
 from . import _lib
 from ._lib import FilterParams, RibophaseError, make_filter  # noqa: F401  (make_filter: re-exported, it lives beside FilterParams)
-from .const import (
-    CUTOFF,
-    MINIMUM_DENSITY_OVER_ORF,
-    MINIMUM_READS_PER_CODON,
-    MINIMUM_VALID_CODONS,
-    MINIMUM_VALID_CODONS_RATIO,
-)
 
 
 class PhaseScores(NamedTuple):
