@@ -1590,5 +1590,14 @@ extern "C" int rp_debug_rewalk_stamps(unsigned long long *out16, int reset)
     }
     return 0;
 }
+extern "C" int rp_debug_replay_stamps(unsigned long long *out8, int reset)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(rp::g_replay_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(rp::g_replay_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
 #endif
 

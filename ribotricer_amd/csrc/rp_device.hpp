@@ -360,6 +360,9 @@ __device__ __forceinline__ void replay_codon_compute(int a, int b, int c, double
     pxi = (-xi * kScale) * 2.0;
 }
 
+#ifdef RP_REWALK_STAMPS
+__device__ unsigned long long g_replay_stamps[8];
+#endif
 // One wave, one ORF.  Lane t takes triplets t, t + 64, ...: five counts give it one codon of
 // each reading frame (one pass over the profile for all three frames).  The per-frame sums are
 // plain left folds in codon order, exactly as numpy performs them -- inherently sequential, so
@@ -377,20 +380,30 @@ template <typename Counts>
 __device__ __forceinline__ bool replay_tie_wave(Counts v, long long len, int lane,
                                              double &phase, int &valid, ReplayLds *lds)
 {
+#ifdef RP_REWALK_STAMPS  // (timing experiment: phases of the replay, summed into g_replay_stamps)
+    unsigned long long rs_mem = 0, rs_fold = 0, rs_tail = 0;
+    unsigned long long rs_t = __builtin_amdgcn_s_memtime();
+#define RP_RS_LAP(acc) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - rs_t; rs_t = now_; } while (0)
+#else
+#define RP_RS_LAP(acc)
+#endif
     bool any_big = false;
     constexpr double kPyySeg = 0x1.5555555555555p-1;
     double sxx = 0.0, sxr = 0.0, sxi = 0.0;  // lane f < 3: the running sums of frame f
     int n = 0;
     const long long n_trip = len / 3;  // frame f has a codon at triplet j iff 3j + f + 2 < len
     const long long last = len > 0 ? len - 1 : 0;
-    auto load5 = [&](long long j, int (&w)[5]) {  // the five counts of triplet j (clamped reads, masked)
-        const long long p = 3 * j;
+    // the five counts of triplet j: five back-to-back loads at clamped (always in-range) indices, masked afterwards -- a
+    // select per value, no per-lane branch.  (Until round 6 every load sat behind `if (j < n_trip)`: five branches, a wait
+    // behind each, FIVE dependent memory round trips where this is one -- 70 % of a tie's re-walk, profiles/r06_ab_finish_tail.txt.)
+    auto load5 = [&](long long j, int (&w)[5]) {
+        const bool live = j < n_trip;
+        const long long p = live ? 3 * j : 0;
+        int x[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            int x = 0;
-            if (j < n_trip) x = v[p + k < last ? p + k : last];
-            w[k] = (j < n_trip && p + k < len) ? x : 0;
-        }
+        for (int k = 0; k < 5; ++k) x[k] = len > 0 ? v[p + k < last ? p + k : last] : 0;  // (len > 0: wave-uniform)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) w[k] = (live && p + k < len) ? x[k] : 0;
     };
     int w[5], wn[5];
     load5(lane, w);
@@ -407,6 +420,9 @@ __device__ __forceinline__ bool replay_tie_wave(Counts v, long long len, int lan
             const int a = w[f], b = w[f + 1], c = w[f + 2];
             nz[f] = j < n_trip && p + f + 2 < len && (a | b | c) != 0;
             big[f] = (unsigned)(a | b | c) >= (1u << kCodonTabBits);
+#ifdef RP_EXPERIMENT_NO_TABLE  // timing experiment only (x*x where the reference has pow(): last bits differ on 0.8 % of the codons)
+            big[f] = true;
+#endif
             t[f] = rp_codon_tab[(nz[f] && !big[f]) ? ((a << (2 * kCodonTabBits)) | (b << kCodonTabBits) | c) : 0];
         }
 #pragma unroll
@@ -427,6 +443,7 @@ __device__ __forceinline__ bool replay_tie_wave(Counts v, long long len, int lan
         }
         __builtin_amdgcn_wave_barrier();  // (one wave: its LDS operations complete in order)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RP_RS_LAP(rs_mem);  // the chunk's counts and table rows have arrived, its terms are in LDS
         if (lane < 3) {
             const double(*row)[3] = lds->t[lane];
             for (int i = 0; i < mine; ++i) {  // numpy's reductions here are plain left folds in segment order
@@ -445,6 +462,7 @@ __device__ __forceinline__ bool replay_tie_wave(Counts v, long long len, int lan
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the rows are rewritten by the next chunk
+        RP_RS_LAP(rs_fold);
 #pragma unroll
         for (int k = 0; k < 5; ++k) w[k] = wn[k];
     }
@@ -491,6 +509,16 @@ __device__ __forceinline__ bool replay_tie_wave(Counts v, long long len, int lan
     }
     phase = __builtin_sqrt(coh);
     valid = val;
+#ifdef RP_REWALK_STAMPS
+    RP_RS_LAP(rs_tail);
+    if (lane == 0) {
+        atomicAdd(&g_replay_stamps[0], 1ull);
+        atomicAdd(&g_replay_stamps[1], rs_mem);
+        atomicAdd(&g_replay_stamps[2], rs_fold);
+        atomicAdd(&g_replay_stamps[3], rs_tail);
+        atomicAdd(&g_replay_stamps[4], (unsigned long long)__builtin_amdgcn_readlane(n, 0));
+    }
+#endif
     return __ballot(any_big) != 0;
 }
 #pragma clang fp contract(fast)

@@ -28,6 +28,8 @@ for _ in range(5):
     eng.score(counts, offsets, thresholds=thr, algo="tile", reuse_outputs=True, plan=plan)
 torch.cuda.synchronize()
 lib.rp_debug_rewalk_stamps(out, 1)
+out8 = (ctypes.c_ulonglong * 8)()
+lib.rp_debug_replay_stamps(out8, 1)
 reps = 20
 tm = []
 for _ in range(reps):
@@ -43,3 +45,8 @@ for name, b in (("not a tie", 0), ("exact tie", 8)):
         continue
     print(f"  {name}: {c / reps:.0f} per launch, mean length {v[b + 4] / c:.0f} nt; per re-walk: float64 walk {v[b + 1] / c * tick_us:.2f}, "
           f"reductions + scores {v[b + 2] / c * tick_us:.2f}, replay {v[b + 3] / c * tick_us:.2f}  (sum {(v[b + 1] + v[b + 2] + v[b + 3]) / c * tick_us:.2f}; unit: 100 s_memtime ticks)")
+lib.rp_debug_replay_stamps(out8, 1)
+r = np.array(list(out8), np.float64)
+if r[0]:
+    print(f"  inside the replay ({r[0] / reps:.0f} per launch, {r[4] / r[0]:.1f} non-zero codons in frame 0 on average): counts + table rows + terms into LDS "
+          f"{r[1] / r[0] * tick_us:.2f}, serial fold {r[2] / r[0] * tick_us:.2f}, scores + state machine {r[3] / r[0] * tick_us:.2f}  (unit: 100 s_memtime ticks)")
