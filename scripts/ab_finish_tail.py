@@ -36,8 +36,8 @@ if __name__ == "__main__":
         child(int(sys.argv[2]), sys.argv[3])
         sys.exit(0)
     libs = [("product", None), ("max 1 re-walk per wave", "variants/max_rewalks_1.so"), ("max 2", "variants/max_rewalks_2.so"), ("no re-walk", "variants/no_rewalk.so")]
-    if os.path.exists(os.path.join(REPO, "variants/notable.so")):
-        libs.append(("replay computes its terms (no table)", "variants/notable.so"))
+    if len(sys.argv) > 1:  # explicit list: name=path ...
+        libs = [tuple(a.split("=", 1)) for a in sys.argv[1:]]
     for n, cfg in ((344_000, "cfg3"), (1_000_000, "cfg2"), (1_374_000, "cfg3"), (2_750_000, "cfg3"), (11_000_000, "cfg3")):
         for name, lib in libs:
             env = dict(os.environ)
