@@ -1520,13 +1520,17 @@ size_t rp_wig_render_host(const uint64_t *sorted_words, int64_t lo, int64_t hi, 
         for (; i < hi && (sorted_words[i] >> 22) == key; ++i) total += (int64_t)(sorted_words[i] & 0x3fffffull);
         const long long rank = (long long)(key >> 32);
         if (rank != prev_rank) {
-            static const char head[] = "variableStep chrom=";
-            std::memcpy(o, head, sizeof(head) - 1);
-            o += sizeof(head) - 1;
             const int64_t a = name_off[rank], b = name_off[rank + 1];
-            std::memcpy(o, names + a, (size_t)(b - a));
-            o += b - a;
-            *o++ = '\n';
+            // (a chromosome named "" -- it sorts first -- gets no header: the reference's loop starts from cur_chrom = "",
+            // detect_orfs.py:340-345)
+            if (b > a) {
+                static const char head[] = "variableStep chrom=";
+                std::memcpy(o, head, sizeof(head) - 1);
+                o += sizeof(head) - 1;
+                std::memcpy(o, names + a, (size_t)(b - a));
+                o += b - a;
+                *o++ = '\n';
+            }
             prev_rank = rank;
         }
         o += rpfmt::int_str((int64_t)(key & 0xffffffffull), o);

@@ -699,11 +699,16 @@ def export_wig(merged_alignments, prefix: str) -> None:
     from . import _lib
 
     lib = _lib.load()
-    cols = merged_alignments if isinstance(merged_alignments, MergedColumns) else MergedColumns.from_counters(merged_alignments)
-    if any(isinstance(c, OtherStrand) for c in cols.chroms):
+    is_mapping = not isinstance(merged_alignments, MergedColumns)
+    if is_mapping and any(k not in STRANDS for k in merged_alignments):
+        cols = None  # (a foreign strand key, even over an empty table, takes the general road below)
+    else:
+        cols = merged_alignments if not is_mapping else MergedColumns.from_counters(merged_alignments)
+    if cols is None or any(isinstance(c, OtherStrand) for c in cols.chroms):
         # a strand key other than '+' / '-' (never out of split_bam): every strand that is not '+' goes to _neg.wig, one
-        # after the other in the mapping's order, the last one staying (detect_orfs.py:338-352).  No fast path for that.
-        by_strand = merged_alignments if not isinstance(merged_alignments, MergedColumns) else cols.as_counters()
+        # after the other in the mapping's order, the last one staying -- an empty table leaves an empty file
+        # (detect_orfs.py:338-352).  No fast path for that.
+        by_strand = merged_alignments if is_mapping else cols.as_counters()
         for strand, table in by_strand.items():
             with open(f"{prefix}_pos.wig" if strand == "+" else f"{prefix}_neg.wig", "w") as output:
                 section = ""  # (a chromosome named "" gets no header of its own at the top: the reference starts from "")
@@ -783,7 +788,8 @@ def export_wig(merged_alignments, prefix: str) -> None:
         ends = np.concatenate((block[1:], [key_chrom.size])) if block.size else block
         with open(path, "wb") as output:
             for a, b in zip(block.tolist(), ends.tolist()):
-                output.write(f"variableStep chrom={cols.chroms[int(key_chrom[a])]}\n".encode("utf-8"))
+                if cols.chroms[int(key_chrom[a])] != "":  # (no header for a chromosome named "": detect_orfs.py:340-345 starts from "")
+                    output.write(f"variableStep chrom={cols.chroms[int(key_chrom[a])]}\n".encode("utf-8"))
                 for lo in range(a, b, 1 << 22):  # 4 Mi positions per call: <= 176 MB of text buffer
                     hi = min(b, lo + (1 << 22))
                     buf = np.empty(42 * (hi - lo), np.uint8)

@@ -33,7 +33,13 @@ class _CdsLayout:
         ext: dict = {}
         for r in records:
             key = (r.strand, r.chrom)
+            # every position a profile can name: the flanks hang on the FIRST block's start and the LAST block's end
+            # (metagene.py:66-71), the blocks themselves may reach further (an exon nested in an earlier one ends before
+            # it; a block with end < start names nothing)
             lo, hi = r.intervals[0][0] - flank, r.intervals[-1][1] + flank
+            for s, e in r.intervals:
+                if e >= s:
+                    lo, hi = min(lo, s), max(hi, e)
             if key in ext:
                 ext[key] = (min(ext[key][0], lo), max(ext[key][1], hi))
             else:

@@ -2,7 +2,8 @@
 INTEGRATION.md section 2, VERBATIM -- eight names of the reference's own modules rebound to this package -- and then the
 REFERENCE's orchestrator `ribotricer.detect_orfs.detect_orfs()` (detect_orfs.py:354-526) run on a BAM holding the G7
 reads: its six outputs must equal tests/golden/g7_expected_* (which the unpatched reference wrote) byte for byte, and the
-reference's two plot functions must accept the package's return types.  GPU-less backend here.
+reference's two plot functions must accept the package's return types.  Then, function by function against the reference on random
+inputs: align_metagenes, export_wig, merge_read_lengths, metagene_coverage.  GPU-less backend here.
 
 usage: python tests/golden/check_integration_vs_reference.py       exit 0 = all identical"""
 import os
@@ -43,6 +44,8 @@ import ribotricer_amd.statistics as amd_stats  # noqa: E402
 import ribotricer_amd.alignments as amd_al  # noqa: E402
 import ribotricer_amd.metagene as amd_mg  # noqa: E402
 
+REFERENCE_EXPORT_WIG = ref.export_wig  # (the reference's own function objects, kept for the comparisons further down)
+REFERENCE_MERGE = ref.merge_read_lengths
 ref.export_orf_coverages = amd.export_orf_coverages   # the hot loop -> one GPU launch
 ref.merge_read_lengths = amd_al.merge_read_lengths     # columns instead of Counter arithmetic
 ref.export_wig = amd.export_wig
@@ -132,5 +135,96 @@ with tempfile.TemporaryDirectory() as tmp:
             diffs += outs[0] != outs[1]
 print(f"align_metagenes on 4000 random inputs: {diffs} differences")
 bad += diffs
+# ---- export_wig (detect_orfs.py:327-352) on random mappings: strand keys beyond '+' / '-' (every strand that is not '+' lands in
+# _neg.wig, the last one staying, an empty table leaving an empty file), a chromosome named "" (no header of its own), counts past
+# the packed sort key (the column-sort road)
+wig_diffs = 0
+with tempfile.TemporaryDirectory() as tmp:
+    for trial in range(600):
+        mapping = defaultdict(Counter)
+        keys = [["+", "-"], ["-", "+"], ["+", ".", "-"], [".", "+"], ["-", "."], ["*", "-", "+", "."], ["."], ["+"], ["-"], []][trial % 10]
+        for k in keys:
+            for _ in range(int(rng.integers(0, 30))):
+                mapping[k][(str(rng.choice(["chr1", "chr10", "chr2", ""])), int(rng.integers(1, 500)))] += int(rng.integers(1, 9))
+            mapping[k]  # (the key exists even over an empty table)
+        if trial % 5 == 0 and "+" in keys:
+            mapping["+"][("chr2", 7)] += 1 << 23
+        outs = []
+        for tag, fn in (("r", REFERENCE_EXPORT_WIG), ("a", amd.export_wig)):
+            d_out = os.path.join(tmp, f"{tag}{trial}")
+            os.makedirs(d_out)
+            fn(mapping, os.path.join(d_out, "w"))
+            outs.append({f: open(os.path.join(d_out, f)).read() for f in sorted(os.listdir(d_out))})
+        wig_diffs += outs[0] != outs[1]
+print(f"export_wig on 600 random mappings: {wig_diffs} differences")
+bad += wig_diffs
+# ---- merge_read_lengths (detect_orfs.py:54-83) on random nested mappings: lengths without an offset, offsets without a length,
+# strand keys beyond '+' / '-' (only '+' moves downstream), negative offsets; the columnar result read back as Counters
+merge_diffs = 0
+for trial in range(1000):
+    nested = defaultdict(lambda: defaultdict(Counter))
+    lengths = rng.choice(np.arange(20, 40), size=int(rng.integers(0, 6)), replace=False).tolist()
+    for length in lengths:
+        for strand in [["+", "-"], ["+"], ["-", "."], ["+", "-", "*"]][trial % 4]:
+            for _ in range(int(rng.integers(0, 25))):
+                nested[length][strand][(str(rng.choice(["chr1", "chrM", "2"])), int(rng.integers(1, 60)))] += int(rng.integers(1, 5))
+    offsets_of = OrderedDict((int(length), int(rng.integers(-3, 16))) for length in (lengths + [99] if trial % 3 == 0 else lengths) if rng.random() < 0.8)
+    want = {k: dict(v) for k, v in REFERENCE_MERGE(nested, offsets_of).items() if v}
+    got = {k: dict(v) for k, v in amd_al.merge_read_lengths(nested, offsets_of).as_counters().items() if v}
+    merge_diffs += want != got
+print(f"merge_read_lengths on 1000 random inputs: {merge_diffs} differences")
+bad += merge_diffs
+
+# ---- metagene_coverage (metagene.py:160-265) on corner-case indexes (random_index.py: overlapping / nested exons, a '.' strand,
+# blocks with end < start) x random per-length alignments x window sizes / offsets / read thresholds: both profile files byte for
+# byte, what is left in read_lengths, the Series' index ranges, valid codons
+sys.path.insert(0, HERE)
+from random_index import random_index  # noqa: E402
+
+ref_mg = importlib.import_module("ribotricer.metagene")
+ref_orf = importlib.import_module("ribotricer.orf").ORF
+mg_diffs = 0
+with tempfile.TemporaryDirectory() as tmp:
+    for trial in range(45):
+        shape = [dict(malformed=0.0), dict(malformed=0.1), dict(malformed=0.0, dressed=0.2)][trial % 3]
+        text, merged = random_index(int(rng.integers(8, 120)), 5000 + trial, **shape)
+        path = os.path.join(tmp, f"i{trial}.tsv")
+        with open(path, "w", newline="") as fh:
+            fh.write(text)
+        cds_ref = []
+        with open(path) as fh:
+            fh.readline()
+            for line in fh:
+                if "annotated" not in line:
+                    break
+                orf = ref_orf.from_string(line)
+                if orf is not None and orf.category == "annotated":
+                    cds_ref.append(orf)
+        nested = defaultdict(lambda: defaultdict(Counter))
+        reads = defaultdict(int)
+        for strand, table in merged.items():
+            for (chrom, pos), count in table.items():
+                for _ in range(min(count, 6)):
+                    length = int(rng.choice([27, 28, 29, 30]))
+                    nested[length][strand][(chrom, int(pos + rng.integers(-15, 16)))] += 1
+                    reads[length] += 1
+        meta_min, window = int(rng.choice([1, 50, 10**9])), int(rng.choice([600, 30, 7]))
+        o5, o3 = [(20, 0), (0, 0), (5, 7), (50, 50)][trial % 4]
+        outs = []
+        for tag, fn, cds in (("r", ref_mg.metagene_coverage, cds_ref), ("a", amd_mg.metagene_coverage, amd_mg.annotated_records(path))):
+            left = dict(reads)
+            try:
+                m = fn(cds, nested, left, os.path.join(tmp, tag), max_positions=window, offset_5p=o5, offset_3p=o3, meta_min_reads=meta_min)
+                files = tuple(open(os.path.join(tmp, f"{tag}_metagene_profiles_{side}.tsv")).read() for side in ("5p", "3p"))
+                outs.append((sorted(left.items()), {k: (list(v[0].index), list(v[1].index), int(v[3]), int(v[5])) for k, v in m.items()}, files))
+            except BaseException as e:  # noqa: BLE001
+                outs.append(type(e).__name__)
+        if outs[0] != outs[1]:
+            mg_diffs += 1
+            print(f"  metagene_coverage differs: trial {trial} {shape} window {window} offsets {o5}/{o3} meta_min {meta_min}: "
+                  + (f"{outs[0]} vs {outs[1]}" if isinstance(outs[0], str) or isinstance(outs[1], str) else
+                     "; ".join(name for name, x, y in zip(("read_lengths", "series", "files"), outs[0], outs[1]) if x != y)))
+print(f"metagene_coverage on 45 corner-case indexes: {mg_diffs} differences")
+bad += mg_diffs
 print("integration check:", "all identical" if not bad else f"{bad} differences")
 sys.exit(1 if bad else 0)

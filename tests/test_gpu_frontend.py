@@ -245,3 +245,49 @@ def test_native_detect_orfs_from_a_bam(tmp_path, capsys):
     for g, w in zip(got[1:], want[1:]):
         assert g[:3] == w[:3] and g[4:] == w[4:]
         assert abs(float(g[3]) - float(w[3])) <= 1e-6
+
+
+@pytest.mark.parametrize("seed", [7, 8, 9])
+def test_metagene_on_corner_case_indexes_hip_equals_cpu_backend(tmp_path, seed, monkeypatch):
+    """metagene_coverage on annotated ORFs with overlapping / nested / duplicated exons, a '.' strand and blocks with
+    end < start (tests/golden/random_index.py), several windows / flanks: the device path against the cpu backend, which equals
+    the reference on such inputs (tests/golden/check_integration_vs_reference.py; round 6 found an exon nested in an earlier
+    one losing the reads past the LAST exon's end there).  Profiles: the same floats; phase scores within 1e-9."""
+    import ast
+    import sys
+    from collections import Counter, defaultdict
+
+    from conftest import GOLDEN
+
+    if GOLDEN not in sys.path:
+        sys.path.insert(0, GOLDEN)
+    from random_index import random_index
+
+    from ribotricer_amd import metagene as mg
+
+    rng = np.random.default_rng(seed)
+    text, merged = random_index(150, 7000 + seed, malformed=0.1)
+    path = tmp_path / "i_candidate_orfs.tsv"
+    with open(path, "w", newline="") as fh:
+        fh.write(text)
+    nested = defaultdict(lambda: defaultdict(Counter))
+    reads = defaultdict(int)
+    for strand, table in merged.items():
+        for (chrom, pos), count in table.items():
+            for _ in range(min(count, 6)):
+                length = int(rng.choice([27, 28, 29]))
+                nested[length][strand][(chrom, int(pos + rng.integers(-15, 16)))] += 1
+                reads[length] += 1
+    cds = mg.annotated_records(str(path))
+    for window, o5, o3 in ((600, 20, 0), (30, 5, 7), (600, 50, 50)):
+        files = {}
+        for backend in ("cpu", "hip"):
+            monkeypatch.setenv("RIBOTRICER_AMD_BACKEND", backend)
+            mg.metagene_coverage(cds, nested, dict(reads), str(tmp_path / backend), max_positions=window, offset_5p=o5, offset_3p=o3, meta_min_reads=1)
+            files[backend] = [open(str(tmp_path / backend) + f"_metagene_profiles_{side}.tsv").read().splitlines() for side in ("5p", "3p")]
+        for a_side, b_side in zip(files["cpu"], files["hip"]):
+            assert len(a_side) == len(b_side) and a_side[0] == b_side[0]
+            for a, b in zip(a_side[1:], b_side[1:]):
+                fa, fb = a.split("\t"), b.split("\t")
+                assert fa[:2] == fb[:2] and ast.literal_eval(fa[2]) == ast.literal_eval(fb[2]) and fa[4] == fb[4]
+                assert abs(float(fa[3]) - float(fb[3])) <= 1e-9
