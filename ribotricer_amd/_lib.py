@@ -41,6 +41,11 @@ class RibophaseError(RuntimeError):
         self.status = status
 
 
+class IndexCoordinateError(RibophaseError, ValueError):
+    """A coordinate field that does not parse (status RP_ERR_INDEX_COORD).  Also a ``ValueError``: that is what the
+    reference raises for the same line (``start, end = group.split("-")`` / ``int(start)``, orf.py:165-168)."""
+
+
 class FilterParams(ctypes.Structure):
     """rp_filter_params -- thresholds of detect_orfs.py:289-299 (defaults const.py:20-39)."""
 

@@ -126,9 +126,12 @@ inline bool parse_int(std::string_view t, int64_t &out)
     if (a < b && t[a] == '+') ++a;
     if (a == b) return false;
     int64_t v = 0;
+    size_t digits = 0;
     for (size_t k = a; k < b; ++k) {
         const char c = t[k];
         if (c < '0' || c > '9') return false;
+        if (v != 0 || c != '0') ++digits;  // (leading zeros do not count)
+        if (digits > 18) return false;     // >= 1e18: no genome position; Python's int would go on, this parser reports the line
         v = v * 10 + (c - '0');
     }
     out = v;

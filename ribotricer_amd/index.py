@@ -17,6 +17,7 @@ import numpy as np
 from . import _lib
 
 RP_ERR_INDEX_COLUMNS = -9
+RP_ERR_INDEX_COORD = -10
 
 
 class _View(ctypes.Structure):  # rp_index_view
@@ -95,6 +96,8 @@ class NativeIndex:
                     "please run ribotricer prepare-orfs to regenerate",
                 )
             )
+        if rc == RP_ERR_INDEX_COORD:  # a ValueError in the reference (orf.py:165-168): the same here, with the library's message
+            raise _lib.IndexCoordinateError(rc, lib.rp_last_error().decode("utf-8", "replace"))
         _lib.check(rc)
         self._parsed = own = _Parsed(handle)
         v = _View()

@@ -38,7 +38,18 @@ with tempfile.TemporaryDirectory() as tmp:
         index_path = os.path.join(tmp, f"index{k}.tsv")
         with open(index_path, "w", newline="") as fh:
             fh.write(text)
-        for name, kw in PARAM_SETS.items():
+        # the three fixed threshold sets, and two drawn per index -- values that sit ON what the data produce (a density of
+        # exactly 1.0 or 2.5, a ratio of exactly 0.5, a cutoff equal to a printed score) included
+        import numpy as np
+
+        trng = np.random.default_rng(seed0 + k)
+        drawn = {}
+        for j in range(2):
+            drawn[f"drawn{j}"] = dict(report_all=bool(trng.integers(0, 2)), phase_score_cutoff=float(trng.choice([0.0, 0.25, 0.428571428571, 0.5, 1.0, float(trng.random())])),
+                                      min_valid_codons=int(trng.integers(0, 12)), min_reads_per_codon=float(trng.choice([0, 0, 1, 2, 0.5])),
+                                      min_valid_codons_ratio=float(trng.choice([0, 0.5, 0.25, 1.0, float(trng.random())])),
+                                      min_density_over_orf=float(trng.choice([0.0, 1.0, 2.5, 0.1, float(trng.random() * 3)])))
+        for name, kw in {**PARAM_SETS, **drawn}.items():
             total += 1
             outs = []
             for tag, fn in (("ref", ref_export), ("amd", amd_export)):
