@@ -272,7 +272,7 @@ def upload_columns(merged, device=None) -> UploadedColumns:
     dev = get_engine(device).device
 
     def to_dev(a, dt):
-        return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev, non_blocking=True)
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)  # (blocking: the source may be a temporary, and it is pageable)
 
     return UploadedColumns(to_dev(cols.strand, np.uint8), to_dev(cols.chrom, np.int32), to_dev(cols.pos, np.int64),
                            to_dev(cols.count, np.int64), list(cols.chroms), dev)
@@ -337,7 +337,7 @@ def build_coverage_device(merged, index, device=None, big=None, cmap=None, out=N
 
     def to_dev(a, dt):
         a = np.ascontiguousarray(a, dtype=dt)
-        return torch.from_numpy(a).to(dev, non_blocking=True)
+        return torch.from_numpy(a).to(dev)  # (blocking: `a` may be a converted temporary; pageable sources gain nothing from "async")
 
     if up is not None:
         d_strand, d_chrom, d_pos, d_count = up.strand, up.chrom, up.pos, up.count

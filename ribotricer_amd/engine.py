@@ -90,7 +90,11 @@ def _as_device(x, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
     if x.dtype != dtype:
         x = x.to(dtype)
     if x.device != device:
-        x = x.to(device, non_blocking=True)
+        # Asynchronous only from PINNED host memory.  A pageable source is often a temporary of the caller (a sub-table, a
+        # slice): an asynchronous copy that outlived it would read freed memory.  CUDA stages pageable sources before it
+        # returns; whether every ROCm path does is not something this package should depend on (round 6: one unexplained
+        # after-the-fact verify failure whose device results were right and whose re-gathered comparison profiles were not).
+        x = x.to(device, non_blocking=bool(x.device.type == "cpu" and x.is_pinned()))
     return x.contiguous()
 
 
@@ -837,7 +841,7 @@ class CsrShards:
             lo, hi = int(self.bounds[k]), int(self.bounds[k + 1])
             stream = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(stream):
-                o = torch.from_numpy(self.offsets[lo : hi + 1] - self.offsets[lo]).to(dev, non_blocking=True)
+                o = torch.from_numpy(self.offsets[lo : hi + 1] - self.offsets[lo]).to(dev)  # (a temporary: a blocking copy)
             self._slices[k] = (stream, o, {})  # {counts phase: TilePlan}
         return self._slices[k]
 
@@ -861,7 +865,7 @@ class CsrShards:
                 with torch.cuda.stream(stream):
                     c = counts[a:b]
                     c = torch.from_numpy(np.ascontiguousarray(c, dtype=np.int32)) if not isinstance(c, torch.Tensor) else c
-                    c = c.to(dev, non_blocking=True)
+                    c = c.to(dev, non_blocking=bool(c.device.type != "cpu" or c.is_pinned()))
                     plan = "auto"
                     if algo == "tile" or (algo == "auto" and c.numel() >= AUTO_WAVE_NT):  # the tile path: this slice's plan, kept HERE
                         phase = (c.data_ptr() // 4) % 4 if c.numel() else 0  # (an engine's own cache holds 4 plans)

@@ -337,8 +337,8 @@ class GatherPlan:
         k = int(n_chosen.value)
         chosen, out_off, offsets = scratch["chosen"][:k], scratch["chosen_off"][: k + 1], scratch["offsets"]
         counts = torch.empty(int(out_off[-1]), dtype=torch.int32, device=self.device)
-        d_chosen = torch.from_numpy(chosen).to(self.device, non_blocking=True)
-        d_off = torch.from_numpy(out_off[:-1].copy()).to(self.device, non_blocking=True)
+        d_chosen = torch.from_numpy(chosen).to(self.device)
+        d_off = torch.from_numpy(out_off[:-1].copy()).to(self.device)  # (a temporary: a blocking copy)
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(_lib.load().rp_gather_selected_plan_dev(self.handle, _ptr(cov), cov.numel(), _ptr(d_chosen), d_chosen.numel(),
                                                           _ptr(d_off), _ptr(counts), stream))
