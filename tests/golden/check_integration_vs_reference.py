@@ -46,6 +46,7 @@ import ribotricer_amd.metagene as amd_mg  # noqa: E402
 
 REFERENCE_EXPORT_WIG = ref.export_wig  # (the reference's own function objects, kept for the comparisons further down)
 REFERENCE_MERGE = ref.merge_read_lengths
+REFERENCE_EXPORT = ref.export_orf_coverages
 ref.export_orf_coverages = amd.export_orf_coverages   # the hot loop -> one GPU launch
 ref.merge_read_lengths = amd_al.merge_read_lengths     # columns instead of Counter arithmetic
 ref.export_wig = amd.export_wig
@@ -226,5 +227,62 @@ with tempfile.TemporaryDirectory() as tmp:
                      "; ".join(name for name, x, y in zip(("read_lengths", "series", "files"), outs[0], outs[1]) if x != y)))
 print(f"metagene_coverage on 45 corner-case indexes: {mg_diffs} differences")
 bad += mg_diffs
+# ---- the whole chain behind split_bam, function for function: the reference's own metagene_coverage -> align_metagenes ->
+# merge_read_lengths -> export_wig -> export_orf_coverages against this package's, on corner-case indexes with periodic reads of
+# several lengths: six files each, byte for byte (and the case where no read length is periodic: both must exit the same way)
+ref_pure = importlib.import_module("ribotricer.detect_orfs")
+chain_diffs = 0
+with tempfile.TemporaryDirectory() as tmp:
+    for trial in range(16):
+        text, merged = random_index(int(rng.integers(30, 160)), 8000 + trial, malformed=0.05 * (trial % 3))
+        path = os.path.join(tmp, f"c{trial}.tsv")
+        with open(path, "w", newline="") as fh:
+            fh.write(text)
+        nested = defaultdict(lambda: defaultdict(Counter))
+        reads = defaultdict(int)
+        true_offset = {27: 11, 28: 12, 29: 12, 30: 13}
+        for strand, table in merged.items():
+            for (chrom, pos), count in table.items():
+                for _ in range(min(count, 8)):
+                    length = int(rng.choice([27, 28, 29, 30], p=[0.1, 0.4, 0.3, 0.2]))
+                    five = pos - true_offset[length] if strand == "+" else pos + true_offset[length]
+                    nested[length][strand][(chrom, int(five))] += 1
+                    reads[length] += 1
+        cds_ref = []
+        with open(path) as fh:
+            fh.readline()
+            for line in fh:
+                if "annotated" not in line:
+                    break
+                orf = ref_orf.from_string(line)
+                if orf is not None and orf.category == "annotated":
+                    cds_ref.append(orf)
+        outs = []
+        for tag in ("r", "a"):
+            prefix = os.path.join(tmp, f"{tag}{trial}")
+            left = dict(reads)
+            try:
+                if tag == "r":
+                    m = ref_mg.metagene_coverage(cds_ref, nested, left, prefix, meta_min_reads=20)
+                    offs = ref_mg.align_metagenes(m, left, prefix, 0.428571428571, trial % 4 != 3)
+                    merged_now = REFERENCE_MERGE(nested, offs)
+                    REFERENCE_EXPORT_WIG(merged_now, prefix)
+                    REFERENCE_EXPORT(path, merged_now, prefix, report_all=bool(trial % 2))
+                else:
+                    m = amd_mg.metagene_coverage(amd_mg.annotated_records(path), nested, left, prefix, meta_min_reads=20)
+                    offs = amd_mg.align_metagenes(m, left, prefix, 0.428571428571, trial % 4 != 3)
+                    merged_now = amd_al.merge_read_lengths(nested, offs)
+                    amd.export_wig(merged_now, prefix)
+                    amd.export_orf_coverages(path, merged_now, prefix, report_all=bool(trial % 2))
+                files = {f: open(os.path.join(tmp, f), "rb").read() for f in sorted(os.listdir(tmp)) if f.startswith(f"{tag}{trial}_")}
+                outs.append((list(offs.items()), {k[len(f"{tag}{trial}"):]: v for k, v in files.items()}))
+            except BaseException as e:  # noqa: BLE001
+                outs.append(type(e).__name__)
+        if outs[0] != outs[1]:
+            chain_diffs += 1
+            what = "exception" if isinstance(outs[0], str) or isinstance(outs[1], str) else [k for k in outs[0][1] if outs[0][1].get(k) != outs[1][1].get(k)] or "offsets"
+            print(f"  chain differs: trial {trial}: {what}")
+print(f"the chain behind split_bam on 16 corner-case samples: {chain_diffs} differences")
+bad += chain_diffs
 print("integration check:", "all identical" if not bad else f"{bad} differences")
 sys.exit(1 if bad else 0)
