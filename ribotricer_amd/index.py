@@ -145,6 +145,14 @@ class NativeIndex:
                 return cls(b"", skip_header=True)
             mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
             try:  # (not `with mm`: closing a mapping that an in-flight exception still exports raises BufferError)
+                # The reference reads the file in text mode: a lone '\r' ends a line too (universal newlines).  The native
+                # parser cuts lines at '\n' (a '\r' in front of it is blank space to its number parser: CRLF files are
+                # fine); a file whose HEADER line already holds a lone '\r' -- classic Mac line ends -- is translated first,
+                # as Python would.  (A lone '\r' inside a data line of an otherwise '\n'-ended file is not looked for.)
+                first_nl = mm.find(b"\n")
+                header = mm[: first_nl if first_nl >= 0 else len(mm)]
+                if b"\r" in (header[:-1] if header.endswith(b"\r") else header):
+                    return cls(mm[:].replace(b"\r\n", b"\n").replace(b"\r", b"\n"), skip_header=True)
                 return cls(mm, skip_header=True)  # header line skipped: detect_orfs.py:273
             finally:
                 try:

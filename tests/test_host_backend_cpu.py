@@ -290,3 +290,25 @@ def test_native_export_equals_the_python_restatement_on_corner_indexes(tmp_path,
         d.export_orf_coverages(str(index), merged, str(tmp_path / "n"), report_all=report_all)
         want = "\t".join(d.COLUMNS) + "\n" + "".join(d.format_rows(records, counts, offsets, res, report_all))
         assert open(str(tmp_path / "n") + "_translating_ORFs.tsv", newline="").read() == want
+
+
+def test_classic_mac_line_ends_are_lines(tmp_path, cpu_backend):
+    """The reference opens the index in text mode: '\\r' alone ends a line (universal newlines).  A '\\r'-ended file gives the
+    same rows as its '\\n'-ended twin (it used to parse as ONE header line: an empty result without an error)."""
+    from collections import Counter, defaultdict
+
+    from ribotricer_amd.detect_orfs import export_orf_coverages
+
+    header = "ORF_ID\tORF_type\ttranscript_id\ttranscript_type\tgene_id\tgene_name\tgene_type\tchrom\tstrand\tstart_codon\tcoordinate\n"
+    line = "x\tannotated\tt1\tpc\tg\tn\tpc\tchr1\t+\tATG\t10-39\n"
+    align = defaultdict(Counter)
+    align["+"][("chr1", 10)] = 5
+    align["+"][("chr1", 13)] = 4
+    outs = {}
+    for tag, text in (("lf", header + line + line), ("cr", (header + line + line).replace("\n", "\r")), ("crlf", (header + line + line).replace("\n", "\r\n")),
+                      ("cr_no_final", (header + line + line).replace("\n", "\r")[:-1])):
+        with open(tmp_path / f"{tag}.tsv", "w", newline="") as fh:
+            fh.write(text)
+        export_orf_coverages(str(tmp_path / f"{tag}.tsv"), align, str(tmp_path / tag), report_all=True)
+        outs[tag] = (tmp_path / f"{tag}_translating_ORFs.tsv").read_bytes()
+    assert outs["lf"].count(b"\n") == 3 and outs["cr"] == outs["lf"] and outs["crlf"] == outs["lf"] and outs["cr_no_final"] == outs["lf"]
