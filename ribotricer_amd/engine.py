@@ -326,7 +326,8 @@ class PhaseScoreEngine:
         physical memory; what it cannot change is the class of memory the read stream itself comes from, and a step is
         slow whenever the two share one (one process, six copies of the same 16 GB of counts against two workspaces:
         2.63-3.04 ms per launch, some copies slow with every workspace -- profiles/archive/r05_source_placement.txt).  For an
-        input the CALLER OF THIS METHOD owns -- the bench's synthetic counts, the export's own coverage buffer -- the
+        input the CALLER OF THIS METHOD owns and may swap for a copy (no product path calls this; bench.py times it AFTER its headline as
+        value_source_placed) the
         same search is run on the source: unless the scoring kernel already moves its bytes at ``good_gbps`` (the fast
         class on MI355X: 6.0-6.1 TB/s of algorithmic bytes for the CSR kernel; ``None``: no absolute mark -- stop at a
         copy 5 % faster than the slowest seen) copies of ``counts`` are made one after the other, each behind a spacer
