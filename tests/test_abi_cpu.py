@@ -140,3 +140,30 @@ def test_tile_positions_rule():
     assert _lib.tile_positions(0, 0) == 7936
     # the sizing functions follow the same rule: a short-ORF index needs the bigger plan per nucleotide
     assert _lib.plan_bytes(1000, 100_000) > 0 and _lib.workspace_bytes(1000, 100_000, _lib.RP_ALGO_TILE) > 0
+
+
+def test_bench_line_of_the_full_size_record_fits_the_drivers_tail():
+    """bench.compact_line on the FULL record of the round's evidence run (profiles/r06_bench_default_detail.json: 11 M ORFs, every
+    section on): the one JSON line must stay under the 8 KB the driver keeps of stdout, and carry the contract fields and the
+    top-level scalars a reader of the flattened record needs.  (The GPU contract test checks the same on small runs.)"""
+    import importlib.util
+    import json
+    import os
+
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(repo, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with open(os.path.join(repo, "profiles", "r06_bench_default_detail.json")) as fh:
+        full = json.load(fh)
+    line = json.dumps(bench.compact_line(full))
+    assert len(line) < 8192, len(line)
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "kernel_ms", "finish_ms", "step_frac", "fused_step_frac", "fused_nested_step_frac",
+                "projected_efficiency_g8", "value_first_allocation", "value_source_placed", "value_pipelined", "value_one_stream_repeat",
+                "value_single_sample", "verify", "quality"):
+        assert key in d, key
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "fetch_factor"):
+        assert key in d["roofline"], key
+    assert d["value"] == full["value"] and d["roofline"]["frac"] == full["roofline"]["frac"] and "workload" in d["config"]
