@@ -709,14 +709,17 @@ def export_wig(merged_alignments, prefix: str) -> None:
         # after the other in the mapping's order, the last one staying -- an empty table leaves an empty file
         # (detect_orfs.py:338-352).  No fast path for that.
         by_strand = merged_alignments if is_mapping else cols.as_counters()
+        from itertools import groupby
+        from operator import itemgetter
+
         for strand, table in by_strand.items():
+            text = []
+            for chrom, keys in groupby(sorted(table), key=itemgetter(0)):  # one block per chromosome, positions ascending
+                if chrom != "":  # (a chromosome named "" sorts first and gets no header: the reference's loop starts from "")
+                    text.append(f"variableStep chrom={chrom}\n")
+                text.extend(f"{pos}\t{table[(chrom, pos)]}\n" for _, pos in keys)
             with open(f"{prefix}_pos.wig" if strand == "+" else f"{prefix}_neg.wig", "w") as output:
-                section = ""  # (a chromosome named "" gets no header of its own at the top: the reference starts from "")
-                for chrom, pos in sorted(table):
-                    if chrom != section:
-                        section = chrom
-                        output.write(f"variableStep chrom={chrom}\n")
-                    output.write(f"{pos}\t{table[(chrom, pos)]}\n")
+                output.write("".join(text))
         return
     names = np.asarray(cols.chroms, dtype=object)
     rank = np.argsort(np.argsort(names)) if names.size else np.zeros(0, np.int64)  # sorted() orders by chromosome NAME
